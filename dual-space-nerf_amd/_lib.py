@@ -1,0 +1,257 @@
+"""ctypes binding of libdsnerf_hip.so (include/dsnerf.h) + thin torch-tensor plumbing.
+
+PyTorch is used for device memory, streams and (elsewhere) torch.distributed only.  There is no
+eager / CPU fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsnerf_hip.so")
+_lib = None
+
+PARAM_ORDER = [
+    "nerf.embedding.weight",
+    "nerf.stage1.0.weight", "nerf.stage1.0.bias", "nerf.stage1.2.weight", "nerf.stage1.2.bias",
+    "nerf.stage1.4.weight", "nerf.stage1.4.bias", "nerf.stage1.6.weight", "nerf.stage1.6.bias",
+    "nerf.stage2.0.weight", "nerf.stage2.0.bias", "nerf.stage2.2.weight", "nerf.stage2.2.bias",
+    "nerf.stage2.4.weight", "nerf.stage2.4.bias",
+    "nerf.density_net.0.weight", "nerf.density_net.0.bias",
+    "nerf.rgb_net.1.weight", "nerf.rgb_net.1.bias", "nerf.rgb_net.3.weight", "nerf.rgb_net.3.bias",
+    "lighting_mlp.lights_encoding.0.weight", "lighting_mlp.lights_encoding.0.bias",
+    "lighting_mlp.lights_encoding.2.weight", "lighting_mlp.lights_encoding.2.bias",
+    "lighting_mlp.lights_encoding.4.weight", "lighting_mlp.lights_encoding.4.bias",
+    "pose_mlp.0.weight", "pose_mlp.0.bias", "pose_mlp.2.weight", "pose_mlp.2.bias",
+    "pose_mlp.4.weight", "pose_mlp.4.bias",
+]
+
+EXPORTS = [
+    "dsn_abi_version", "dsn_last_error", "dsn_packed_param_bytes", "dsn_pack_params",
+    "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
+    "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_shade", "dsn_composite",
+    "dsn_render_workspace_bytes", "dsn_render_rays",
+]
+
+SKIP_TRANSPARENT = 1
+
+
+def lib():
+    """Load the HIP library (raises if it has not been built: python dual-space-nerf_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing - build it with `python dual-space-nerf_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        L = C.CDLL(LIB_PATH)
+        L.dsn_last_error.restype = C.c_char_p
+        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes"):
+            getattr(L, n).restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().dsn_last_error().decode()}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("dsnerf_amd needs a ROCm device (gfx950); no CPU fallback exists")
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class PackedParams:
+    """MFMA-ordered device image of the 33 state_dict tensors (dsn_pack_params)."""
+
+    def __init__(self, device):
+        require_gpu()
+        self.device = torch.device(device)
+        self.buf = torch.empty(lib().dsn_packed_param_bytes(), dtype=torch.uint8, device=self.device)
+        self._versions = None
+        self._keep = None
+
+    def update(self, state: dict, force=False):
+        """state: name -> tensor (any device).  Re-packs only when a tensor changed (version counters)."""
+        tensors = [state[k] for k in PARAM_ORDER]
+        versions = tuple((t.data_ptr(), t._version) for t in tensors)
+        if not force and versions == self._versions:
+            return self
+        dev = [_f32(t.detach(), self.device) for t in tensors]
+        ptrs = (C.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
+        _check(lib().dsn_pack_params(ptrs, _ptr(self.buf), _stream()), "dsn_pack_params")
+        self._keep = dev  # keep sources alive until the pack kernel has run (stream-ordered)
+        self._versions = versions
+        return self
+
+
+class Scene:
+    """Body model + per-frame state blob (dsn_set_body / dsn_set_frame)."""
+
+    def __init__(self, canonical_vertex, faces, device):
+        require_gpu()
+        self.device = torch.device(device)
+        canon = _f32(canonical_vertex.reshape(-1, 3), self.device)
+        f = faces.to(device=self.device, dtype=torch.int32).contiguous()
+        self.V, self.F = canon.shape[0], f.shape[0]
+        self.buf = torch.empty(lib().dsn_scene_bytes(self.V, self.F), dtype=torch.uint8, device=self.device)
+        _check(lib().dsn_set_body(_ptr(self.buf), _ptr(canon), _ptr(f), self.V, self.F, _stream()), "dsn_set_body")
+        self._keep = (canon, f)
+        self.frame_key = None
+
+    def set_frame(self, packed: PackedParams, xyz, poses, frame_idx: int, zero_code: bool = False,
+                  light_shift=None, rot=None, rot_center=None):
+        xyz = _f32(xyz.reshape(-1, 3), self.device)
+        assert xyz.shape[0] == self.V, "xyz must have the body model's vertex count"
+        poses = _f32(poses.reshape(24, 3), self.device)
+        ls = None if light_shift is None else _f32(light_shift.reshape(-1)[:3], self.device)
+        r = None if rot is None else _f32(rot.reshape(-1)[:4], self.device)
+        rc = None if rot_center is None else _f32(rot_center.reshape(-1)[:2], self.device)
+        _check(lib().dsn_set_frame(_ptr(self.buf), self.V, self.F, _ptr(packed.buf), _ptr(xyz), _ptr(poses),
+                                   int(frame_idx), int(bool(zero_code)), _ptr(ls), _ptr(r), _ptr(rc), _stream()),
+               "dsn_set_frame")
+        self._keep_frame = (xyz, poses, ls, r, rc)
+        return self
+
+
+# ------------------------------------------------------------------------------------------------
+# stage calls (device tensors in, device tensors out)
+# ------------------------------------------------------------------------------------------------
+def sample(scene: Scene, ray_o, ray_d, near, far, S, t_vals, jitter=None, want_pts=True, gg=True):
+    """near/far are updated in place (like utils/pts_utils.py:52-53)."""
+    R = ray_o.shape[0]
+    dev = scene.device
+    z = torch.empty(R, S, dtype=torch.float32, device=dev)
+    pts = torch.empty(R, S, 3, dtype=torch.float32, device=dev) if want_pts else None
+    fn = lib().dsn_sample_gg if gg else lib().dsn_sample_uniform
+    _check(fn(_ptr(scene.buf), scene.V, scene.F, _ptr(ray_o, torch.float32), _ptr(ray_d, torch.float32),
+              _ptr(near, torch.float32), _ptr(far, torch.float32), R, S, _ptr(t_vals, torch.float32), _ptr(jitter),
+              _ptr(z), _ptr(pts), _stream()), "dsn_sample")
+    return pts, z
+
+
+def warp(scene: Scene, pts, ray_d, S, want_dir=True, want_uvh=False, want_active=False):
+    pts = pts.reshape(-1, 3)
+    N = pts.shape[0]
+    dev = scene.device
+    out = {
+        "face_idx": torch.empty(N, dtype=torch.int32, device=dev),
+        "transparent": torch.empty(N, dtype=torch.uint8, device=dev),
+        "x_c": torch.empty(N, 3, dtype=torch.float32, device=dev),
+    }
+    uv = h = rdc = lst = cnt = None
+    if want_uvh:
+        uv = out["uv"] = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        h = out["h"] = torch.empty(N, dtype=torch.float32, device=dev)
+    if want_dir and ray_d is not None:
+        rdc = out["ray_d_can"] = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    if want_active:
+        lst = out["active_list"] = torch.empty(N, dtype=torch.int32, device=dev)
+        cnt = out["active_count"] = torch.zeros(64, dtype=torch.int32, device=dev)
+    _check(lib().dsn_warp(_ptr(scene.buf), scene.V, scene.F, _ptr(pts, torch.float32), _ptr(ray_d), C.c_int64(N), S,
+                          _ptr(out["face_idx"]), _ptr(uv), _ptr(h), _ptr(out["transparent"]), _ptr(out["x_c"]),
+                          _ptr(rdc), _ptr(lst), _ptr(cnt), _stream()), "dsn_warp")
+    return out
+
+
+def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=True, active=None):
+    x_c = x_c.reshape(-1, 3)
+    N = x_c.shape[0]
+    dev = scene.device
+    sigma = torch.zeros(N, dtype=torch.float32, device=dev)
+    ess = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_essence else None
+    g = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_grad else None
+    lst, cnt = (None, None) if active is None else active
+    _check(lib().dsn_field(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
+                           _ptr(lst), _ptr(cnt), _ptr(sigma), _ptr(ess), _ptr(g), _stream()), "dsn_field")
+    return sigma, ess, g
+
+
+def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None):
+    x_c = x_c.reshape(-1, 3)
+    N = x_c.shape[0]
+    dev = scene.device
+    idx = torch.zeros(N, dtype=torch.int32, device=dev)
+    n_w = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+    col = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+    lst, cnt = (None, None) if active is None else active
+    _check(lib().dsn_shade(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32),
+                           _ptr(grad.reshape(-1, 3), torch.float32), _ptr(x_w.reshape(-1, 3), torch.float32),
+                           _ptr(ray_d, torch.float32), _ptr(essence.reshape(-1, 3), torch.float32), C.c_int64(N), S,
+                           _ptr(lst), _ptr(cnt), _ptr(idx), _ptr(n_w), _ptr(col), _stream()), "dsn_shade")
+    return idx, n_w, col
+
+
+def composite(colour, sigma, transparent, z_vals, ray_d, noise=None):
+    R, S = z_vals.shape
+    dev = z_vals.device
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    disp = torch.empty(R, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, dtype=torch.float32, device=dev)
+    w = torch.empty(R, S, dtype=torch.float32, device=dev)
+    dep = torch.empty(R, dtype=torch.float32, device=dev)
+    _check(lib().dsn_composite(_ptr(colour.reshape(-1, 3), torch.float32), _ptr(sigma.reshape(-1), torch.float32),
+                               _ptr(transparent), _ptr(z_vals, torch.float32), _ptr(ray_d, torch.float32), _ptr(noise),
+                               R, S, _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(w), _ptr(dep), _stream()), "dsn_composite")
+    return rgb, disp, acc, w, dep
+
+
+class RenderWorkspace:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.buf = None
+        self.cap = 0
+
+    def get(self, R, S):
+        need = lib().dsn_render_workspace_bytes(R, S)
+        if self.buf is None or self.cap < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.cap = need
+        return self.buf
+
+
+def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
+                jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None):
+    """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
+    R = ray_o.shape[0]
+    dev = scene.device
+    if out is None:
+        out = {
+            "color": torch.empty(R, 3, dtype=torch.float32, device=dev),
+            "disp_map": torch.empty(R, dtype=torch.float32, device=dev),
+            "acc_map": torch.empty(R, dtype=torch.float32, device=dev),
+            "depth_map": torch.empty(R, dtype=torch.float32, device=dev),
+            "z_vals": torch.empty(R, S, dtype=torch.float32, device=dev),
+        }
+        if want_weights:
+            out["weights"] = torch.empty(R, S, dtype=torch.float32, device=dev)
+    flags = SKIP_TRANSPARENT if (skip_transparent and noise is None) else 0
+    buf = ws.get(R, S)
+    _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
+                                 _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
+                                 _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
+                                 _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
+                                 _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
+           "dsn_render_rays")
+    return out

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's Renderer (the upper drop-in boundary).
+
+Same constructor, attributes and methods as /root/reference/can_render.py:14-406 so that
+trainer.py:70 (`render.render(batch)`), test.py:60 / validate.py:50 (`render.render_view(batch)`),
+utils/visualizer.py:47-66 (`w2l_without_lbs`, `query_volume`, `.canonical_model`) and
+validate.py:27 (`render.net.load_state_dict`) can use it unchanged.  Orchestration is Python; every
+number is produced by libdsnerf_hip.so (no torch math, no fallback).
+
+What differs from the reference, on purpose (DESIGN.md "boundary"):
+  * a frame is rendered in one pass over ALL its rays (the reference loops over 3072-ray chunks with
+    an empty_cache + 6 device->host copies each, can_render.py:172-245); one device->host copy at the end;
+  * in eval mode the networks are evaluated only on non-transparent samples (their sigma is zeroed and
+    their colour has weight 0 in the reference, can_render.py:115-120) - outputs are identical;
+  * `render()` is forward-only this round (no autograd graph).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def load_bodydata(model_type="smpl", gender="neutral", model_path=""):
+    """utils/smpl_utils.py:3-14: unpickle the SMPL model (dict with 'f', 'weights', 'kintree_table')."""
+    import os
+    import pickle
+
+    if os.path.isdir(model_path):
+        model_path = os.path.join(model_path, "{}_{}.pkl".format(model_type.upper(), gender.upper()))
+    assert os.path.exists(model_path), "Path {} does not exist!".format(model_path)
+    with open(model_path, "rb") as f:
+        return pickle.load(f, encoding="latin1")
+
+
+class Renderer:
+    def __init__(self, net, fine_net=None, cfg=None, canonical_vertex=None, body_data=None, device=None):
+        """`body_data` (optional, not in the reference): dict with 'f' [F,3] (and optionally 'weights',
+        'kintree_table') used instead of unpickling cfg.DATASETS.SMPL_PATH - the SMPL file is licensed."""
+        _lib.require_gpu()
+        self.net = net
+        self.cfg = cfg
+        self.fine_net = fine_net
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.canonical_vertex = canonical_vertex
+        self._body_data = body_data
+        self.load_body_model(gender="neutral", body_model="smpl", model_path=getattr(cfg.DATASETS, "SMPL_PATH", ""))
+        self.sample_points_mode = cfg.MODEL.sample_points_mode
+        self._ws = _lib.RenderWorkspace(self.device)
+        self._tvals = {}
+        self.skip_transparent = True
+        self.last_active_fraction = None
+
+    # ---- mode switches (reference :26-38) ----
+    def train(self):
+        self.net.training = True
+        self.net.train()
+        if self.fine_net is not None:
+            self.fine_net.training = True
+            self.fine_net.train()
+
+    def eval(self):
+        self.net.training = False
+        self.net.eval()
+        if self.fine_net is not None:
+            self.fine_net.training = False
+            self.fine_net.eval()
+
+    # ---- body model (reference :382-406) ----
+    def load_body_model(self, gender, body_model, model_path):
+        tmp = self._body_data if self._body_data is not None else load_bodydata(body_model, gender, model_path)
+        if "kintree_table" in tmp:
+            parents = torch.as_tensor(np.asarray(tmp["kintree_table"])[0].astype(np.int64)).long()
+            parents[0] = -1
+            self.parents = parents
+        if "weights" in tmp:
+            self.smpl_blend_weight = torch.as_tensor(np.asarray(tmp["weights"], np.float32))[None].to(self.device)
+        self.face_idx = torch.as_tensor(np.asarray(tmp["f"]).astype(np.int64)).long().to(self.device)
+        if self.canonical_vertex is not None:
+            cv = torch.as_tensor(self.canonical_vertex, dtype=torch.float32).reshape(-1, 3).to(self.device)
+            self.canonical_model = {"vertex": cv, "meshes": cv[self.face_idx]}
+            self.scene = _lib.Scene(cv, self.face_idx, self.device)
+
+    # ---- helpers ----
+    def _t_vals(self, S):
+        # torch.linspace on the host, exactly as utils/pts_utils.py:4 does, then uploaded once
+        if S not in self._tvals:
+            self._tvals[S] = torch.linspace(0.0, 1.0, steps=S).to(self.device)
+        return self._tvals[S]
+
+    def _dev(self, t, dtype=torch.float32):
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _set_frame(self, batch):
+        frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
+        zero_code, ls, rot, rc = self.net.frame_args(batch)
+        self.scene.set_frame(self.net.packed(self.device), batch["xyz"][0], batch["poses"][0], frame, zero_code, ls,
+                             rot, rc)
+        return frame
+
+    def _draws(self, R, S):
+        """Train-mode random draws from the CPU default generator in the reference's order:
+        torch.rand([1,R,S]) (utils/pts_utils.py:12) then torch.randn([R,S]) (utils/nerf_net_utils.py:31)."""
+        jitter = noise = None
+        if self.net.training and self.cfg.MODEL.perturb > 0.0:
+            jitter = torch.rand(1, R, S).reshape(R, S).to(self.device)
+        if self.net.training and self.cfg.MODEL.raw_noise_std > 0.0:
+            noise = (torch.randn(R, S) * self.cfg.MODEL.raw_noise_std).to(self.device)
+        return jitter, noise
+
+    # ---- sampling (reference :40-63) ----
+    def get_sampling_points(self, ray_o, ray_d, near, far, xyz, mode="GG"):
+        """ray_o/ray_d [1,R,3], near/far [1,R] (updated in place in GG mode), xyz [1,V,3] ->
+        pts [1,R,S,3], z_vals [1,R,S].  Needs the frame's xyz in the scene: Renderer.render does that;
+        direct callers get it set here from `xyz` with the current pose state untouched."""
+        S = self.cfg.MODEL.COARSE_RAY_SAMPLING
+        R = ray_o.shape[1]
+        o, d = self._dev(ray_o[0]), self._dev(ray_d[0])
+        n_dev, f_dev = self._dev(near[0]), self._dev(far[0])
+        jitter = None
+        if self.net.training and self.cfg.MODEL.perturb > 0.0:
+            jitter = torch.rand(1, R, S).reshape(R, S).to(self.device)
+        if getattr(self, "_frame_xyz_ptr", None) != xyz.data_ptr():
+            self._upload_xyz(xyz)
+        pts, z = _lib.sample(self.scene, o, d, n_dev, f_dev, S, self._t_vals(S), jitter, want_pts=True, gg=(mode == "GG"))
+        if mode == "GG":   # in-place update like the reference (:52-53)
+            near[0].copy_(n_dev.to(near.device))
+            far[0].copy_(f_dev.to(far.device))
+        return pts[None], z[None]
+
+    def _upload_xyz(self, xyz):
+        # posed mesh only (callers without a full batch: the pose code is zeroed until _set_frame runs)
+        x = self._dev(xyz.reshape(-1, 3))
+        poses = torch.zeros(24, 3, device=self.device)
+        self.scene.set_frame(self.net.packed(self.device), x, poses, 0, True, None, None, None)
+        self._frame_xyz_ptr = xyz.data_ptr()
+
+    # ---- warp (reference :299-379) ----
+    def w2l(self, pts_world, ray_o_W, ray_d_W, batch):
+        B, ray, sp, _ = pts_world.shape
+        pts_smpl_can, transparent_mask, ray_d_can = self.w2l_without_lbs(
+            pts_world, batch, self.canonical_model, ray_d_W=ray_d_W.unsqueeze(2).expand([-1, -1, sp, -1]).reshape(B, -1, 3))
+        d = self._dev(ray_d_W.reshape(-1, 3))
+        rays = torch.cat([d[:, None, :].expand(-1, sp, -1).reshape(-1, 3), ray_d_can], dim=-1).reshape(B * ray, sp, 6)
+        pw = self._dev(pts_world.reshape(B * ray, sp, 3))
+        return torch.cat([pw, pts_smpl_can.reshape(-1, sp, 3)], dim=-1), rays, transparent_mask
+
+    def w2l_without_lbs(self, pts_world, batch, canonical_model, ray_d_W=None, floor=-4, ceil=5):
+        """pts_world [B,R,S,3] -> (pts_smpl_can [N,3], transparent_mask [B,N] bool[, ray_d_can [N,3]]).
+        ray_d_W, when given, is the per-POINT direction tensor [B,N,3] the reference passes."""
+        assert floor == -4 and ceil == 5, "the uv clamp range is compiled in (utils/render_utils.py:103)"
+        B, ray, sp, _ = pts_world.shape
+        xyz = batch["xyz"]
+        if getattr(self, "_frame_xyz_ptr", None) != xyz.data_ptr():
+            if "poses" in batch and "frame" in batch:
+                self._set_frame(batch)
+                self._frame_xyz_ptr = xyz.data_ptr()
+            else:
+                self._upload_xyz(xyz)
+        pts = self._dev(pts_world.reshape(-1, 3))
+        N = pts.shape[0]
+        if ray_d_W is not None:
+            d = self._dev(ray_d_W.reshape(-1, 3))   # per point -> S=1 addressing
+            out = _lib.warp(self.scene, pts, d, 1, want_dir=True)
+            return out["x_c"], out["transparent"].bool().reshape(B, -1), out["ray_d_can"]
+        out = _lib.warp(self.scene, pts, None, 1, want_dir=False)
+        return out["x_c"], out["transparent"].bool().reshape(B, -1)
+
+    # ---- network + compositing on explicit points (reference :65-134) ----
+    def render_rays(self, pts, rays, z_vals, frame_idx, net, transparent_mask=None, batch_info=None):
+        pts, rays, z_vals = self._dev(pts), self._dev(rays), self._dev(z_vals)
+        rays_d = rays[:, 0, :3].contiguous()
+        B, sp = pts.shape[:2]
+        noise = None
+        if self.net.training and self.cfg.MODEL.raw_noise_std > 0.0:
+            noise = (torch.randn(B, sp) * self.cfg.MODEL.raw_noise_std).to(self.device)
+        rgbs, density, _ = net(pts.reshape(-1, 6), rays.reshape(-1, 6), frame_idx, batch_info=batch_info)
+        tm = None if transparent_mask is None else transparent_mask.to(self.device).reshape(B, sp).to(torch.uint8).contiguous()
+        rgb_map, disp_map, acc_map, weights, depth_map = _lib.composite(
+            rgbs.reshape(B, sp, 3).contiguous(), density.reshape(B, sp).contiguous(), tm, z_vals, rays_d, noise)
+        return {"color": rgb_map, "disp_map": disp_map, "acc_map": acc_map, "depth_map": depth_map,
+                "weights": weights, "z_vals": z_vals}
+
+    def batchify_pts(self, pts, rays, z_vals, frame_idx, chunk=1024 * 32, net=None, batch_info=None):
+        net = self.net if net is None else net
+        return self.render_rays(pts, rays, z_vals, frame_idx, net=net,
+                                transparent_mask=batch_info["transparent_mask"], batch_info=batch_info)
+
+    # ---- the trainer's call (reference :137-168) ----
+    def render(self, batch):
+        o, d = self._dev(batch["ray_o"][0]), self._dev(batch["ray_d"][0])
+        near, far = self._dev(batch["near"][0]), self._dev(batch["far"][0])
+        R = o.shape[0]
+        S = self.cfg.MODEL.COARSE_RAY_SAMPLING
+        self._set_frame(batch)
+        self._frame_xyz_ptr = batch["xyz"].data_ptr()
+        jitter, noise = self._draws(R, S)
+        if self.sample_points_mode != "GG":
+            raise NotImplementedError("fused path implements the shipped configs' sample_points_mode='GG'")
+        out = _lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o, d, near, far, S, self._t_vals(S),
+                               jitter, noise, skip_transparent=self.skip_transparent and not self.net.training)
+        if batch["near"].is_cuda:   # in-place semantics of the reference when the batch already lives on the device
+            batch["near"][0].copy_(near)
+            batch["far"][0].copy_(far)
+        batch["canonical_model"] = self.canonical_model
+        batch["face_idx"] = self.face_idx
+        return {"coarse": out}
+
+    # ---- whole-image path (reference :172-278) ----
+    def batchify_rays_view(self, ray_o, ray_d, near, far, batch, chunk=None):
+        o, d = self._dev(ray_o[0]), self._dev(ray_d[0])
+        n, f = self._dev(near[0]).clone(), self._dev(far[0]).clone()
+        S = self.cfg.MODEL.COARSE_RAY_SAMPLING
+        self._set_frame(batch)
+        self._frame_xyz_ptr = batch["xyz"].data_ptr()
+        R = o.shape[0]
+        chunk = R if chunk is None else int(chunk)
+        outs = []
+        for i in range(0, R, chunk):
+            j = min(R, i + chunk)
+            jitter, noise = self._draws(j - i, S)
+            outs.append(_lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o[i:j].contiguous(),
+                                         d[i:j].contiguous(), n[i:j].contiguous(), f[i:j].contiguous(), S,
+                                         self._t_vals(S), jitter, noise,
+                                         skip_transparent=self.skip_transparent and not self.net.training))
+        coarse = {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
+        return coarse, {}
+
+    def render_view(self, batch, chunk=None):
+        coarse, _ = self.batchify_rays_view(batch["ray_o"], batch["ray_d"], batch["near"], batch["far"], batch, chunk)
+        _, H, W, _ = batch["img"].shape
+        mask = batch["mask_at_box"][0].to(self.device).bool()
+        # utils/render_utils.py:466-472 post_process, done on the device; ONE device->host copy
+        packed = torch.zeros(H * W, 6, dtype=torch.float32, device=self.device)
+        packed[mask] = torch.cat([coarse["color"], coarse["disp_map"][:, None], coarse["acc_map"][:, None],
+                                  coarse["depth_map"][:, None]], dim=1)
+        img = packed.cpu().reshape(H, W, 6)
+        return {"coarse_color": img[..., 0:3].contiguous(), "coarse_disp": img[..., 3:4].contiguous(),
+                "coarse_acc": img[..., 4:5].contiguous(), "coarse_depth": img[..., 5:6].contiguous()}
+
+    # ---- density query for marching cubes (reference :280-296) ----
+    def query_volume(self, pts, code_idx, transparent_mask=None, batch_info={}):
+        B, N = pts.shape[:2]
+        density = self.net(pts, None, code_idx, batch_info, density_only=True)
+        if transparent_mask is not None:
+            density[transparent_mask.to(density.device).reshape([-1, 1])] = 0
+        return density.reshape(B, N, 1)

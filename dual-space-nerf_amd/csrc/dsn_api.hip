@@ -1,0 +1,221 @@
+// dsn_api.hip - the C ABI of libdsnerf_hip.so (include/dsnerf.h): argument checks, scene/workspace
+// carving and kernel launches on the caller's stream.  No allocation, no synchronisation, no CPU
+// fallback: every entry point only enqueues gfx950 kernels.
+#include "../../include/dsnerf.h"
+#include "dsn_common.h"
+#include "dsn_kernels.h"
+
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int dsn_fail(const char* fmt, const char* a = "", long long b = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return 1;
+}
+static int dsn_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e)); return 1; }
+    return 0;
+}
+#define DSN_REQUIRE(cond, msg) do { if (!(cond)) return dsn_fail("%s", msg); } while (0)
+
+struct DsnSceneHeader { int magic, V, F, has_body, has_frame; };
+#define DSN_MAGIC 0x44534e31
+
+extern "C" {
+
+int dsn_abi_version(void) { return DSN_ABI_VERSION; }
+const char* dsn_last_error(void) { return g_err; }
+
+size_t dsn_packed_param_bytes(void) { return sizeof(float) * (size_t)OFF_END; }
+
+int dsn_pack_params(const float* const* params33_host, void* packed, void* stream) {
+    DSN_REQUIRE(params33_host && packed, "dsn_pack_params: null argument");
+    for (int i = 0; i < DSN_NUM_PARAMS; ++i) DSN_REQUIRE(params33_host[i], "dsn_pack_params: null parameter pointer");
+    dsn_launch_pack_params(params33_host, (float*)packed, (hipStream_t)stream);
+    return dsn_check_launch("dsn_pack_params");
+}
+
+// layout utility (no device work): the packed image of HOST parameter arrays, for tests / tooling
+int dsn_pack_params_host_image(const float* const* params33_host, float* packed_host) {
+    DSN_REQUIRE(params33_host && packed_host, "dsn_pack_params_host_image: null argument");
+    dsn_pack_params_host(params33_host, packed_host);
+    return 0;
+}
+
+size_t dsn_scene_bytes(int V, int F) { return (V > 0 && F > 0) ? dsn_scene_size(V, F) : 0; }
+
+int dsn_set_body(void* scene, const float* canon_vertex, const int32_t* faces, int V, int F, void* stream) {
+    DSN_REQUIRE(scene && canon_vertex && faces && V > 0 && F > 0, "dsn_set_body: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DsnSceneView s = dsn_scene_view(scene, V, F);
+    DsnSceneHeader h = {DSN_MAGIC, V, F, 1, 0};
+    // header lives in device memory too (sanity for later calls is done with the V/F the caller passes)
+    if (hipMemcpyAsync(scene, &h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) return dsn_fail("%s", "dsn_set_body: header copy failed");
+    if (hipMemcpyAsync(s.canon, canon_vertex, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(s.faces, faces, sizeof(int32_t) * 3 * (size_t)F, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return dsn_fail("%s", "dsn_set_body: copy failed");
+    dsn_launch_face_setup(s.canon, s.faces, F, s.face_canon, s.cent_canon, st);
+    return dsn_check_launch("dsn_set_body");
+}
+
+int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
+                  int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
+                  void* stream) {
+    DSN_REQUIRE(scene && packed && xyz && poses24x3, "dsn_set_frame: null argument");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_set_frame: bad V/F");
+    DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_set_frame: frame index outside the embedding table (maxFrame=500)");
+    hipStream_t st = (hipStream_t)stream;
+    DsnSceneView s = dsn_scene_view(scene, V, F);
+    if (hipMemcpyAsync(s.xyz, xyz, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return dsn_fail("%s", "dsn_set_frame: copy failed");
+    dsn_launch_face_setup(s.xyz, s.faces, F, s.face_world, s.cent_world, st);
+    dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2,
+                          s.frame, st);
+    return dsn_check_launch("dsn_set_frame");
+}
+
+int dsn_sample_gg(const void* scene, int V, int F, const float* ray_o, const float* ray_d, float* near, float* far, int R, int S,
+                  const float* t_vals, const float* jitter, float* z_vals, float* pts, void* stream) {
+    DSN_REQUIRE(scene && ray_o && ray_d && near && far && t_vals && z_vals, "dsn_sample_gg: null argument");
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_sample_gg: empty ray batch");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_sample_gg: bad V/F");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_sample_gg(s.xyz, V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z_vals, pts, (hipStream_t)stream);
+    return dsn_check_launch("dsn_sample_gg");
+}
+
+// utils/pts_utils.py:3-16 uniform_sampling alone (sample_points_mode == "uniform", can_render.py:42-51)
+int dsn_sample_uniform(const void* scene, int V, int F, const float* ray_o, const float* ray_d, float* near, float* far,
+                       int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts, void* stream) {
+    DSN_REQUIRE(ray_o && ray_d && near && far && t_vals && z_vals, "dsn_sample_uniform: null argument");
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_sample_uniform: empty ray batch");
+    (void)scene; (void)V; (void)F;
+    dsn_launch_sample_gg(nullptr, 0, ray_o, ray_d, near, far, R, S, t_vals, jitter, z_vals, pts, (hipStream_t)stream);
+    return dsn_check_launch("dsn_sample_uniform");
+}
+
+int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray_d, int64_t N, int S, int32_t* face_idx, float* uv,
+             float* h, uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list,
+             int32_t* active_count, void* stream) {
+    DSN_REQUIRE(scene && pts, "dsn_warp: null argument");
+    DSN_REQUIRE(N > 0 && S > 0, "dsn_warp: empty point batch");
+    DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_warp: active_list and active_count go together");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_warp: bad V/F");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_warp(s, pts, nullptr, ray_d, nullptr, N, S, face_idx, uv, h, transparent, x_c, ray_d_can, active_list,
+                    active_count, (hipStream_t)stream);
+    return dsn_check_launch("dsn_warp");
+}
+
+int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
+              const int32_t* active_count, float* sigma, float* essence, float* grad, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && sigma, "dsn_field: null argument");
+    DSN_REQUIRE(N > 0, "dsn_field: empty point batch");
+    DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_field: active_list and active_count go together");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_field: bad V/F");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_field((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
+                     (hipStream_t)stream);
+    return dsn_check_launch("dsn_field");
+}
+
+int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
+              const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
+              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && grad && x_w && ray_d && essence && n_w && colour, "dsn_shade: null argument");
+    DSN_REQUIRE(N > 0 && S > 0, "dsn_shade: empty point batch");
+    DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_shade: active_list and active_count go together");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_shade: bad V/F");
+    hipStream_t st = (hipStream_t)stream;
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_normal(s, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, st);
+    dsn_launch_light((const float*)packed, s.frame, n_w, x_w, nullptr, ray_d, nullptr, essence, N, S, active_list,
+                     active_count, colour, st);
+    return dsn_check_launch("dsn_shade");
+}
+
+int dsn_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
+                  const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
+                  float* acc_map, float* weights, float* depth_map, void* stream) {
+    DSN_REQUIRE(colour && sigma && z_vals && ray_d && rgb_map && disp_map && acc_map && depth_map, "dsn_composite: null argument");
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_composite: empty ray batch");
+    dsn_launch_composite(colour, sigma, transparent, z_vals, ray_d, noise, R, S, rgb_map, disp_map, acc_map, weights,
+                         depth_map, (hipStream_t)stream);
+    return dsn_check_launch("dsn_composite");
+}
+
+// workspace carve for the fused path
+struct DsnWorkspace {
+    int32_t* count;       // [64] (first word = number of active samples)
+    int32_t* active;      // [N]
+    uint8_t* transparent; // [N]
+    float* z;             // [N] (used when the caller does not want z_vals)
+    float* x_c;           // [N,3]
+    float* sigma;         // [N]
+    float* essence;       // [N,3]
+    float* grad;          // [N,3]
+    float* n_w;           // [N,3]
+    float* colour;        // [N,3]
+    size_t bytes;
+};
+static DsnWorkspace dsn_carve(void* base, int R, int S) {
+    DsnWorkspace w;
+    size_t N = (size_t)R * S;
+    char* p = (char*)base;
+    w.count = (int32_t*)p;        p += 256;
+    w.active = (int32_t*)p;       p += dsn_align256(4 * N);
+    w.transparent = (uint8_t*)p;  p += dsn_align256(N);
+    w.z = (float*)p;              p += dsn_align256(4 * N);
+    w.x_c = (float*)p;            p += dsn_align256(12 * N);
+    w.sigma = (float*)p;          p += dsn_align256(4 * N);
+    w.essence = (float*)p;        p += dsn_align256(12 * N);
+    w.grad = (float*)p;           p += dsn_align256(12 * N);
+    w.n_w = (float*)p;            p += dsn_align256(12 * N);
+    w.colour = (float*)p;         p += dsn_align256(12 * N);
+    w.bytes = (size_t)(p - (char*)base);
+    return w;
+}
+
+size_t dsn_render_workspace_bytes(int R, int S) {
+    if (R <= 0 || S <= 0) return 0;
+    return dsn_carve(nullptr, R, S).bytes;
+}
+
+int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                    float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
+                    int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
+                    float* out_weights, float* out_z, void* workspace, void* stream) {
+    DSN_REQUIRE(scene && packed && ray_o && ray_d && near && far && t_vals && workspace, "dsn_render_rays: null argument");
+    DSN_REQUIRE(out_rgb && out_disp && out_acc && out_depth, "dsn_render_rays: null output");
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays: empty ray batch");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_render_rays: bad V/F");
+    const bool skip = (flags & DSN_SKIP_TRANSPARENT) != 0;
+    DSN_REQUIRE(!(skip && noise), "dsn_render_rays: DSN_SKIP_TRANSPARENT is only exact without noise (eval mode)");
+    hipStream_t st = (hipStream_t)stream;
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    DsnWorkspace w = dsn_carve(workspace, R, S);
+    const int64_t N = (int64_t)R * S;
+    float* z = out_z ? out_z : w.z;
+    dsn_launch_sample_gg(s.xyz, V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+    int32_t* list = skip ? w.active : nullptr;
+    int32_t* cnt = skip ? w.count : nullptr;
+    if (skip) {
+        if (hipMemsetAsync(w.count, 0, 256, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
+        // untouched (skipped) samples must still hold finite colour / sigma for the compositor
+        if (hipMemsetAsync(w.sigma, 0, sizeof(float) * N, st) != hipSuccess ||
+            hipMemsetAsync(w.colour, 0, sizeof(float) * 3 * N, st) != hipSuccess)
+            return dsn_fail("%s", "dsn_render_rays: memset failed");
+    }
+    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, st);
+    dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+    dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, st);
+    dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
+    dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
+                         out_weights, out_depth, st);
+    return dsn_check_launch("dsn_render_rays");
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// dsn_common.h - shared device helpers and the scene / packed-parameter layouts (gfx950 only).
+//
+// Arithmetic contract.  Every geometric quantity follows the reference's float32 operation order
+// exactly (one rounding per torch op, fma only where the torch CPU kernel has one); the whole
+// library is compiled with -ffp-contract=off so that `a*b+c` is never fused implicitly and fmaf()
+// marks every intended fusion.  With IEEE add/mul/fma/div/sqrt this makes sampler, warp and normal
+// stages bit-reproducible against the oracle (oracle/dsn_oracle.c) and the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DSN_WAVE 64
+#define DSN_NUM_PARAMS_INTERNAL 33
+
+// ---------------------------------------------------------------------------------------------
+// scene blob (device memory owned by the caller, dsn_scene_bytes(V,F) bytes)
+// ---------------------------------------------------------------------------------------------
+struct DsnFaceRec {   // 16 floats = 64 B per face: everything utils/geo_utils.py:181-200,96-113,138-156 derive
+    float m0[3];      // vertex 0
+    float d00;        // dot(v20,v20)
+    float v10[3];     // v1 - v0
+    float d01;        // dot(v20,v10)
+    float v20[3];     // v2 - v0
+    float d11;        // dot(v10,v10)
+    float n[3];       // normalize(cross(v10, v20))
+    float inv;        // 1 / (d00*d11 - d01*d01)
+};
+
+struct DsnFrameState {   // small per-frame vectors
+    float pose_feat[16];
+    float code[8];
+    float light_shift[3];
+    float has_light;
+    float rot[4];
+    float rot_center[2];
+    float has_rot;
+    float pad[29];
+    float bias0[256];    // stage1.0 bias with the 24 constant input columns (code, pose) folded in
+};
+
+struct DsnSceneView {
+    int V, F;
+    float* canon;            // [V,3] copy
+    int32_t* faces;          // [F,3] copy
+    float* xyz;              // [V,3] copy of the posed vertices (sampler reads it)
+    float4* cent_world;      // [F] xyz + bit-cast index
+    float4* cent_canon;      // [F]
+    DsnFaceRec* face_world;  // [F]
+    DsnFaceRec* face_canon;  // [F]
+    DsnFrameState* frame;
+};
+
+__host__ __device__ inline size_t dsn_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+__host__ __device__ inline DsnSceneView dsn_scene_view(void* base, int V, int F) {
+    DsnSceneView s;
+    char* p = (char*)base;
+    // header: V, F stored for sanity checks
+    s.V = V; s.F = F;
+    p += 256;
+    s.canon = (float*)p;            p += dsn_align256(sizeof(float) * 3 * (size_t)V);
+    s.faces = (int32_t*)p;          p += dsn_align256(sizeof(int32_t) * 3 * (size_t)F);
+    s.xyz = (float*)p;              p += dsn_align256(sizeof(float) * 3 * (size_t)V);
+    s.cent_world = (float4*)p;      p += dsn_align256(sizeof(float4) * (size_t)F);
+    s.cent_canon = (float4*)p;      p += dsn_align256(sizeof(float4) * (size_t)F);
+    s.face_world = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
+    s.face_canon = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
+    s.frame = (DsnFrameState*)p;    p += dsn_align256(sizeof(DsnFrameState));
+    return s;
+}
+__host__ __device__ inline size_t dsn_scene_size(int V, int F) {
+    return 256 + 2 * dsn_align256(sizeof(float) * 3 * (size_t)V) + dsn_align256(sizeof(int32_t) * 3 * (size_t)F) +
+           2 * dsn_align256(sizeof(float4) * (size_t)F) + 2 * dsn_align256(sizeof(DsnFaceRec) * (size_t)F) +
+           dsn_align256(sizeof(DsnFrameState));
+}
+
+// ---------------------------------------------------------------------------------------------
+// float32 helpers with the reference's rounding sequence (see oracle/dsn_oracle.c helpers)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dsn_sum3(float a, float b, float c) { return (a + b) + c; }
+__device__ __forceinline__ float dsn_dot3(const float* a, const float* b) {
+    return dsn_sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]);
+}
+// torch.norm(dim=-1) on 3 floats: fma-accumulated sum of squares, then sqrt
+__device__ __forceinline__ float dsn_norm3(const float* a) {
+    return __fsqrt_rn(fmaf(a[2], a[2], fmaf(a[1], a[1], a[0] * a[0])));
+}
+// torch.cross: fma(a_i, b_j, -(a_j*b_i))
+__device__ __forceinline__ void dsn_cross3(const float* a, const float* b, float* o) {
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+__device__ __forceinline__ float dsn_div(float a, float b) { return __fdiv_rn(a, b); }
+
+// per-face record: identical values to what the reference recomputes per point
+__device__ __forceinline__ void dsn_make_face(const float* v0, const float* v1, const float* v2, DsnFaceRec& r) {
+    float n[3];
+    for (int c = 0; c < 3; ++c) { r.m0[c] = v0[c]; r.v10[c] = v1[c] - v0[c]; r.v20[c] = v2[c] - v0[c]; }
+    dsn_cross3(r.v10, r.v20, n);
+    float nn = dsn_norm3(n);
+    for (int c = 0; c < 3; ++c) r.n[c] = dsn_div(n[c], nn);
+    r.d00 = dsn_dot3(r.v20, r.v20);
+    r.d01 = dsn_dot3(r.v20, r.v10);
+    r.d11 = dsn_dot3(r.v10, r.v10);
+    r.inv = dsn_div(1.0f, r.d00 * r.d11 - r.d01 * r.d01);
+}
+
+// utils/geo_utils.py:181-200 project_point2mesh + :96-113 get_barycentric_coordinates
+__device__ __forceinline__ void dsn_project(const float* p, const DsnFaceRec& f, float& u, float& v, float& h) {
+    float tmp[3], q[3], w[3];
+    for (int c = 0; c < 3; ++c) tmp[c] = p[c] - f.m0[c];
+    float sd = dsn_dot3(tmp, f.n);
+    for (int c = 0; c < 3; ++c) q[c] = p[c] - f.n[c] * sd;
+    for (int c = 0; c < 3; ++c) w[c] = q[c] - f.m0[c];
+    float d02 = dsn_dot3(f.v20, w), d12 = dsn_dot3(f.v10, w);
+    u = (f.d11 * d02 - f.d01 * d12) * f.inv;
+    v = (f.d00 * d12 - f.d01 * d02) * f.inv;
+    h = sd;
+}
+// utils/geo_utils.py:138-156 barycentric_map2can
+__device__ __forceinline__ void dsn_map2face(float u, float v, float h, const DsnFaceRec& f, float* out) {
+    for (int c = 0; c < 3; ++c) {
+        float proj = (f.m0[c] + u * f.v20[c]) + v * f.v10[c];
+        out[c] = proj + h * f.n[c];
+    }
+}
+// F.normalize(x, dim=-1, eps=1e-12)
+__device__ __forceinline__ void dsn_normalize3(const float* a, float* o) {
+    float n = dsn_norm3(a);
+    n = n < 1e-12f ? 1e-12f : n;
+    for (int c = 0; c < 3; ++c) o[c] = dsn_div(a[c], n);
+}
+__device__ __forceinline__ DsnFaceRec dsn_load_face(const DsnFaceRec* __restrict__ recs, int f) {
+    const float4* p = (const float4*)(recs + f);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    DsnFaceRec r;
+    r.m0[0] = a.x; r.m0[1] = a.y; r.m0[2] = a.z; r.d00 = a.w;
+    r.v10[0] = b.x; r.v10[1] = b.y; r.v10[2] = b.z; r.d01 = b.w;
+    r.v20[0] = c.x; r.v20[1] = c.y; r.v20[2] = c.z; r.d11 = c.w;
+    r.n[0] = d.x; r.n[1] = d.y; r.n[2] = d.z; r.inv = d.w;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed network parameters (device blob, dsn_packed_param_bytes())
+// MFMA-ordered images of every matrix; float offsets.  See dsn_field.hip for the lane mapping.
+// ---------------------------------------------------------------------------------------------
+// A-operand image of one [32 out rows] x [32 k] block: 16 k-steps x 64 lanes = 1024 floats, stored
+// [r4][lane][4] so that one 16-byte load per lane fetches 4 consecutive k-steps.
+#define DSN_BLK 1024
+
+enum {
+    // forward images (M = out features)
+    OFF_L0   = 0,                          // stage1.0 : 8 m x 2 kb(pe)     (code/pose columns folded into bias0)
+    OFF_L1   = OFF_L0 + 8 * 2 * DSN_BLK,   // stage1.2 : 8 x 8
+    OFF_L2   = OFF_L1 + 8 * 8 * DSN_BLK,
+    OFF_L3   = OFF_L2 + 8 * 8 * DSN_BLK,
+    OFF_L4   = OFF_L3 + 8 * 8 * DSN_BLK,   // stage2.0 : 8 x 10 (8 h + 2 pe)
+    OFF_L5   = OFF_L4 + 8 * 10 * DSN_BLK,
+    OFF_L6   = OFF_L5 + 8 * 8 * DSN_BLK,
+    OFF_RGB1 = OFF_L6 + 8 * 8 * DSN_BLK,   // rgb_net.1 : 4 x 8
+    // transposed images (M = in features) for d sigma / d x
+    OFF_L6T  = OFF_RGB1 + 4 * 8 * DSN_BLK, // 8 x 8
+    OFF_L5T  = OFF_L6T + 8 * 8 * DSN_BLK,
+    OFF_L4T  = OFF_L5T + 8 * 8 * DSN_BLK,  // 10 m (8 h + 2 pe) x 8
+    OFF_L3T  = OFF_L4T + 10 * 8 * DSN_BLK,
+    OFF_L2T  = OFF_L3T + 8 * 8 * DSN_BLK,
+    OFF_L1T  = OFF_L2T + 8 * 8 * DSN_BLK,
+    OFF_L0T  = OFF_L1T + 8 * 8 * DSN_BLK,  // 2 m (pe) x 8
+    // lighting MLP
+    OFF_LT0  = OFF_L0T + 2 * 8 * DSN_BLK,  // lights_encoding.0 : 4 m x 1 kb (5 k-steps used, rest zero)
+    OFF_LT1  = OFF_LT0 + 4 * 1 * DSN_BLK,  // lights_encoding.2 : 4 x 4
+    // vectors in accumulator (C-layout) order: [m][half][16] floats per 32-row block
+    OFF_B1   = OFF_LT1 + 4 * 4 * DSN_BLK,  // biases of stage1.2/4/6, stage2.0/2/4 : 6 x 256
+    OFF_BRGB1 = OFF_B1 + 6 * 256,          // 128
+    OFF_WDEN = OFF_BRGB1 + 128,            // density_net weight in C-layout order : 256
+    OFF_WRGB3 = OFF_WDEN + 256,            // rgb_net.3 weight, 3 x 128 in C-layout order
+    OFF_BLT0 = OFF_WRGB3 + 3 * 128,        // lighting biases 128, 128
+    OFF_BLT1 = OFF_BLT0 + 128,
+    OFF_WLT2 = OFF_BLT1 + 128,             // lights_encoding.4 weight in C-layout order : 128
+    OFF_SCAL = OFF_WLT2 + 128,             // [0]=density bias, [1..3]=rgb3 bias, [4]=lights_encoding.4 bias
+    // raw (unpacked) copies used by the per-frame setup kernel
+    OFF_RAW_W0 = OFF_SCAL + 64,            // stage1.0.weight [256,87]
+    OFF_RAW_B0 = OFF_RAW_W0 + 256 * 87,    // stage1.0.bias [256]
+    OFF_RAW_EMB = OFF_RAW_B0 + 256,        // embedding [500,8]
+    OFF_RAW_PM0W = OFF_RAW_EMB + 500 * 8,  // pose_mlp
+    OFF_RAW_PM0B = OFF_RAW_PM0W + 64 * 92,
+    OFF_RAW_PM2W = OFF_RAW_PM0B + 64,
+    OFF_RAW_PM2B = OFF_RAW_PM2W + 64 * 64,
+    OFF_RAW_PM4W = OFF_RAW_PM2B + 64,
+    OFF_RAW_PM4B = OFF_RAW_PM4W + 16 * 64,
+    OFF_END = OFF_RAW_PM4B + 16
+};
+
+// accumulator (C/D) layout of v_mfma_f32_32x32x2_f32: lane l, register r holds
+//   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31
+__host__ __device__ inline int dsn_crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// positional-encoding k-steps: 32 steps, (step t, half) -> index into the 63-vector of
+// model/dimension_kernel.py:34-35, or -1 for the single pad slot.
+__host__ __device__ inline int dsn_pe_index(int t, int half) {
+    if (t < 30) { int j = t / 3, a = t % 3; return 3 + 6 * j + (half ? 3 : 0) + a; }
+    if (t == 30) return half ? 1 : 0;
+    return half ? -1 : 2;
+}

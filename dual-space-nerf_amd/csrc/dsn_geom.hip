@@ -1,0 +1,421 @@
+// dsn_geom.hip - geometry kernels of the hot path for gfx950: body/frame setup, geometry-guided
+// sampler, nearest-face warp, compositing.  HBM/VALU-bound integer+float work: coalesced loads,
+// LDS-staged broadcast tiles, wave-level scans; no MFMA here (the networks live in dsn_field.hip).
+#include "dsn_common.h"
+#include "dsn_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// setup: per-face records + centroids  (utils/render_utils.py:94, utils/geo_utils.py:181-200)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_face_setup(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F,
+                             DsnFaceRec* __restrict__ recs, float4* __restrict__ cent) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    float v0[3], v1[3], v2[3];
+    for (int c = 0; c < 3; ++c) { v0[c] = verts[3 * i0 + c]; v1[c] = verts[3 * i1 + c]; v2[c] = verts[3 * i2 + c]; }
+    DsnFaceRec r;
+    dsn_make_face(v0, v1, v2, r);
+    recs[f] = r;
+    // meshes.mean(dim=-2) on CPU torch: (v0 + v1 + v2) / 3
+    float4 c4;
+    c4.x = dsn_div(dsn_sum3(v0[0], v1[0], v2[0]), 3.0f);
+    c4.y = dsn_div(dsn_sum3(v0[1], v1[1], v2[1]), 3.0f);
+    c4.z = dsn_div(dsn_sum3(v0[2], v1[2], v2[2]), 3.0f);
+    c4.w = __int_as_float(f);
+    cent[f] = c4;
+}
+
+void dsn_launch_face_setup(const float* verts, const int32_t* faces, int F, DsnFaceRec* recs, float4* cent,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_face_setup, dim3((F + 255) / 256), dim3(256), 0, st, verts, faces, F, recs, cent);
+}
+
+// model/spacenet.py:314-331 batch_rod2quat + :199-205 pose_mlp + :125-129 embedding row, and the
+// fold of the 24 per-frame-constant input columns of stage1.0 into its bias.
+__global__ void __launch_bounds__(256) k_pose_setup(const float* __restrict__ packed, const float* __restrict__ poses,
+                                                     int frame_idx, int zero_code, const float* __restrict__ light_shift,
+                                                     const float* __restrict__ rot, const float* __restrict__ rot_center,
+                                                     DsnFrameState* __restrict__ fs) {
+    __shared__ float q[92];
+    __shared__ float h1[64], h2[64], feat[16], code[8];
+    int t = threadIdx.x;
+    if (t < 23) {
+        const float* r = poses + 3 * (t + 1);
+        float a[3] = {r[0] + 1e-16f, r[1] + 1e-16f, r[2] + 1e-16f};
+        float angle = dsn_norm3(a);
+        float half = dsn_div(angle, 2.0f);
+        float s = sinf(half), c = cosf(half);
+        q[4 * t + 0] = dsn_div(r[0], angle) * s;
+        q[4 * t + 1] = dsn_div(r[1], angle) * s;
+        q[4 * t + 2] = dsn_div(r[2], angle) * s;
+        q[4 * t + 3] = c - 1.0f;
+    }
+    if (t < 8) code[t] = zero_code ? 0.0f : packed[OFF_RAW_EMB + frame_idx * 8 + t];
+    __syncthreads();
+    if (t < 64) {
+        float acc = packed[OFF_RAW_PM0B + t];
+        const float* w = packed + OFF_RAW_PM0W + t * 92;
+        for (int k = 0; k < 92; ++k) acc += w[k] * q[k];
+        h1[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 64) {
+        float acc = packed[OFF_RAW_PM2B + t];
+        const float* w = packed + OFF_RAW_PM2W + t * 64;
+        for (int k = 0; k < 64; ++k) acc += w[k] * h1[k];
+        h2[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 16) {
+        float acc = packed[OFF_RAW_PM4B + t];
+        const float* w = packed + OFF_RAW_PM4W + t * 64;
+        for (int k = 0; k < 64; ++k) acc += w[k] * h2[k];
+        feat[t] = acc;
+        fs->pose_feat[t] = acc;
+    }
+    if (t < 8) fs->code[t] = code[t];
+    __syncthreads();
+    {   // bias0[o] = b[o] + sum_k W0[o][k] code[k] + sum_k W0[o][71+k] pose[k]
+        float acc = packed[OFF_RAW_B0 + t];
+        const float* w = packed + OFF_RAW_W0 + t * 87;
+        for (int k = 0; k < 8; ++k) acc = fmaf(w[k], code[k], acc);
+        for (int k = 0; k < 16; ++k) acc = fmaf(w[71 + k], feat[k], acc);
+        fs->bias0[t] = acc;
+    }
+    if (t == 0) {
+        fs->has_light = light_shift ? 1.0f : 0.0f;
+        for (int c = 0; c < 3; ++c) fs->light_shift[c] = light_shift ? light_shift[c] : 0.0f;
+        fs->has_rot = (rot && rot_center) ? 1.0f : 0.0f;
+        for (int c = 0; c < 4; ++c) fs->rot[c] = (rot && rot_center) ? rot[c] : 0.0f;
+        for (int c = 0; c < 2; ++c) fs->rot_center[c] = (rot && rot_center) ? rot_center[c] : 0.0f;
+    }
+}
+
+void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_idx, int zero_code,
+                           const float* light_shift, const float* rot, const float* rot_center, DsnFrameState* fs,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_pose_setup, dim3(1), dim3(256), 0, st, packed, poses, frame_idx, zero_code, light_shift, rot,
+                       rot_center, fs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler: utils/pts_utils.py:18-58 + :3-16.  One thread per ray for the union-of-spheres
+// interval (vertices broadcast from an LDS tile; (v - o0) and |v - o0|^2 are per-vertex constants
+// because the reference uses the FIRST ray's origin for every ray), then the block writes
+// z_vals / pts with lanes running over samples (coalesced).
+// ---------------------------------------------------------------------------------------------
+#define GG_TILE 2048
+#define GG_THREADS 256
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restrict__ xyz, int V,
+                                                           const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, float* __restrict__ near,
+                                                           float* __restrict__ far, int R, int S,
+                                                           const float* __restrict__ t_vals,
+                                                           const float* __restrict__ jitter, float* __restrict__ z_vals,
+                                                           float* __restrict__ pts) {
+    __shared__ float4 sv[GG_TILE];
+    __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
+    const float gamma2 = (float)(0.05 * 0.05);
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * GG_THREADS + tid;
+    const float o0x = ray_o[0], o0y = ray_o[1], o0z = ray_o[2];
+    float du[3] = {0.f, 0.f, 1.f}, nrm = 1.f;
+    if (r < R) {
+        float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+        nrm = dsn_norm3(d);
+        du[0] = dsn_div(d[0], nrm); du[1] = dsn_div(d[1], nrm); du[2] = dsn_div(d[2], nrm);
+    }
+    float zmin = 99999.f, zmax = -99999.f;
+    bool any = false;
+    for (int base = 0; base < V; base += GG_TILE) {
+        int n = min(GG_TILE, V - base);
+        __syncthreads();
+        for (int j = tid; j < n; j += GG_THREADS) {
+            float dx = xyz[3 * (base + j)] - o0x, dy = xyz[3 * (base + j) + 1] - o0y, dz = xyz[3 * (base + j) + 2] - o0z;
+            sv[j] = make_float4(dx, dy, dz, dsn_sum3(dx * dx, dy * dy, dz * dz));
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) {
+            float4 v = sv[j];
+            float z0 = dsn_sum3(v.x * du[0], v.y * du[1], v.z * du[2]);
+            float tmp = v.w - z0 * z0;
+            if (tmp < gamma2) {
+                float dz = __fsqrt_rn(gamma2 - tmp);
+                zmin = fminf(zmin, z0 - dz);
+                zmax = fmaxf(zmax, z0 + dz);
+                any = true;
+            }
+        }
+    }
+    float n_ = 0.f, f_ = 0.f;
+    if (r < R) {
+        zmin = dsn_div(zmin, nrm);
+        zmax = dsn_div(zmax, nrm);
+        n_ = near[r]; f_ = far[r];
+        if (any && zmin < zmax) { n_ = zmin; f_ = zmax; near[r] = n_; far[r] = f_; }
+    }
+    s_near[tid] = n_; s_far[tid] = f_;
+    __syncthreads();
+    const int rays_here = min(GG_THREADS, R - blockIdx.x * GG_THREADS);
+    const int total = rays_here * S;
+    for (int e = tid; e < total; e += GG_THREADS) {
+        int lr = e / S, i = e - lr * S;
+        float nn = s_near[lr], ff = s_far[lr];
+        float ti = t_vals[i];
+        float z = nn * (1.0f - ti) + ff * ti;
+        int64_t g = (int64_t)(blockIdx.x * GG_THREADS + lr) * S + i;
+        if (jitter) {
+            float lower = z, upper = z;
+            if (i > 0) { float tp = t_vals[i - 1]; lower = 0.5f * (z + (nn * (1.0f - tp) + ff * tp)); }
+            if (i < S - 1) { float tn = t_vals[i + 1]; upper = 0.5f * ((nn * (1.0f - tn) + ff * tn) + z); }
+            z = lower + (upper - lower) * jitter[g];
+        }
+        z_vals[g] = z;
+        if (pts) {
+            int rr = blockIdx.x * GG_THREADS + lr;
+            pts[3 * g + 0] = ray_o[3 * rr + 0] + ray_d[3 * rr + 0] * z;
+            pts[3 * g + 1] = ray_o[3 * rr + 1] + ray_d[3 * rr + 1] * z;
+            pts[3 * g + 2] = ray_o[3 * rr + 2] + ray_d[3 * rr + 2] * z;
+        }
+    }
+}
+
+void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
+                          int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_sample_gg, dim3((R + GG_THREADS - 1) / GG_THREADS), dim3(GG_THREADS), 0, st, xyz, V, ray_o,
+                       ray_d, near, far, R, S, t_vals, jitter, z_vals, pts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact nearest centroid, brute force: centroids broadcast from LDS tiles, squared distance as
+// the fma chain of pytorch3d's kernel, strict '<' in ascending index order (first index wins).
+// ---------------------------------------------------------------------------------------------
+#define NN_TILE 2048
+__device__ __forceinline__ int dsn_nearest_bruteforce(const float4* __restrict__ cent, int F, float px, float py,
+                                                      float pz, float4* s_tile) {
+    float best = INFINITY;
+    int bi = 0;
+    for (int base = 0; base < F; base += NN_TILE) {
+        int n = min(NN_TILE, F - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) s_tile[j] = cent[base + j];
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) {
+            float4 c = s_tile[j];
+            float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+            float d = dx * dx;
+            d = fmaf(dy, dy, d);
+            d = fmaf(dz, dz, d);
+            if (d < best) { best = d; bi = base + j; }
+        }
+    }
+    return bi;
+}
+
+// can_render.py:333-379 w2l_without_lbs.  One thread per sample point.
+#define WARP_THREADS 256
+__global__ void __launch_bounds__(WARP_THREADS) k_warp(const float4* __restrict__ cent_world,
+                                                        const DsnFaceRec* __restrict__ face_world,
+                                                        const DsnFaceRec* __restrict__ face_canon, int F,
+                                                        const float* __restrict__ pts, const float* __restrict__ ray_o,
+                                                        const float* __restrict__ ray_d,
+                                                        const float* __restrict__ z_vals, int64_t N, int S,
+                                                        int32_t* __restrict__ face_idx, float* __restrict__ uv_out,
+                                                        float* __restrict__ h_out, uint8_t* __restrict__ transparent,
+                                                        float* __restrict__ x_c, float* __restrict__ ray_d_can,
+                                                        int32_t* __restrict__ active_list,
+                                                        int32_t* __restrict__ active_count) {
+    __shared__ float4 s_tile[NN_TILE];
+    const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
+    const bool valid = i < N;
+    float p[3] = {0.f, 0.f, 0.f};
+    int64_t ray = 0;
+    if (valid) {
+        ray = i / S;
+        if (pts) { p[0] = pts[3 * i]; p[1] = pts[3 * i + 1]; p[2] = pts[3 * i + 2]; }
+        else {
+            float z = z_vals[i];
+            p[0] = ray_o[3 * ray + 0] + ray_d[3 * ray + 0] * z;
+            p[1] = ray_o[3 * ray + 1] + ray_d[3 * ray + 1] * z;
+            p[2] = ray_o[3 * ray + 2] + ray_d[3 * ray + 2] * z;
+        }
+    }
+    int fi = dsn_nearest_bruteforce(cent_world, F, p[0], p[1], p[2], s_tile);
+    bool active = false;
+    if (valid) {
+        DsnFaceRec fw = dsn_load_face(face_world, fi);
+        DsnFaceRec fc = dsn_load_face(face_canon, fi);
+        float u, v, h, xc[3];
+        dsn_project(p, fw, u, v, h);
+        bool tr = (u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f);
+        dsn_map2face(u, v, h, fc, xc);
+        if (face_idx) face_idx[i] = fi;
+        if (uv_out) { uv_out[2 * i] = u; uv_out[2 * i + 1] = v; }
+        if (h_out) h_out[i] = h;
+        if (transparent) transparent[i] = tr ? 1 : 0;
+        if (x_c) { x_c[3 * i] = xc[0]; x_c[3 * i + 1] = xc[1]; x_c[3 * i + 2] = xc[2]; }
+        if (ray_d_can && ray_d) {
+            float p2[3] = {p[0] + ray_d[3 * ray + 0], p[1] + ray_d[3 * ray + 1], p[2] + ray_d[3 * ray + 2]};
+            float u2, v2, h2, xe[3], df[3], o[3];
+            dsn_project(p2, fw, u2, v2, h2);
+            dsn_map2face(u2, v2, h2, fc, xe);
+            for (int c = 0; c < 3; ++c) df[c] = xe[c] - xc[c];
+            dsn_normalize3(df, o);
+            ray_d_can[3 * i] = o[0]; ray_d_can[3 * i + 1] = o[1]; ray_d_can[3 * i + 2] = o[2];
+        }
+        active = !tr;
+    }
+    if (active_list) {
+        // wave-aggregated append: one atomic per wave
+        unsigned long long m = __ballot(active);
+        int lane = threadIdx.x & 63;
+        int cnt = __popcll(m);
+        int base = 0;
+        if (lane == 0 && cnt) base = atomicAdd(active_count, cnt);
+        base = __shfl(base, 0);
+        if (active) {
+            int off = __popcll(m & ((1ull << lane) - 1ull));
+            active_list[base + off] = (int32_t)i;
+        }
+    }
+}
+
+void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
+                     const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
+                     uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
+                     hipStream_t st) {
+    int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
+    hipLaunchKernelGGL(k_warp, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, s.cent_world, s.face_world,
+                       s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c, ray_d_can,
+                       active_list, active_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// normals: model/spacenet.py:278-298 normal_local2world.  One thread per (listed) point.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WARP_THREADS) k_normal(const float4* __restrict__ cent_canon,
+                                                          const DsnFaceRec* __restrict__ face_world,
+                                                          const DsnFaceRec* __restrict__ face_canon, int F,
+                                                          const float* __restrict__ x_c, const float* __restrict__ grad,
+                                                          int64_t N, const int32_t* __restrict__ active_list,
+                                                          const int32_t* __restrict__ active_count,
+                                                          int32_t* __restrict__ face_idx_canon,
+                                                          float* __restrict__ n_w) {
+    __shared__ float4 s_tile[NN_TILE];
+    int64_t count = active_list ? (int64_t)(*active_count) : N;
+    int64_t slot0 = (int64_t)blockIdx.x * WARP_THREADS;
+    if (slot0 >= count) return;   // uniform per block
+    int64_t slot = slot0 + threadIdx.x;
+    bool valid = slot < count;
+    int64_t i = valid ? (active_list ? (int64_t)active_list[slot] : slot) : 0;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (valid) { p[0] = x_c[3 * i]; p[1] = x_c[3 * i + 1]; p[2] = x_c[3 * i + 2]; }
+    int fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
+    if (!valid) return;
+    DsnFaceRec fc = dsn_load_face(face_canon, fi);
+    DsnFaceRec fw = dsn_load_face(face_world, fi);
+    float u, v, h, s[3], e[3], pe[3], df[3], o[3];
+    dsn_project(p, fc, u, v, h);
+    dsn_map2face(u, v, h, fw, s);
+    for (int c = 0; c < 3; ++c) pe[c] = p[c] + grad[3 * i + c];
+    dsn_project(pe, fc, u, v, h);
+    dsn_map2face(u, v, h, fw, e);
+    for (int c = 0; c < 3; ++c) df[c] = e[c] - s[c];
+    dsn_normalize3(df, o);
+    if (face_idx_canon) face_idx_canon[i] = fi;
+    n_w[3 * i] = o[0]; n_w[3 * i + 1] = o[1]; n_w[3 * i + 2] = o[2];
+}
+
+void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
+                       const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
+                       hipStream_t st) {
+    int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
+    hipLaunchKernelGGL(k_normal, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, s.cent_canon, s.face_world,
+                       s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing: utils/nerf_net_utils.py:5-56 raw2outputs (+ can_render.py:115-120).
+// One wave per ray, lanes run over samples (S = 64 = one wavefront in every shipped config; longer
+// rays go in chunks of 64 with a carried transmittance).  The exclusive transmittance product
+// T_i = prod_{j<i}(1 - alpha_j + 1e-10) is a wavefront-level inclusive multiplicative scan
+// (6 shuffle steps) shifted by one lane; the five per-ray sums are wavefront butterfly reductions.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dsn_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_composite(const float* __restrict__ colour, const float* __restrict__ sigma,
+                                                    const uint8_t* __restrict__ transparent,
+                                                    const float* __restrict__ z_vals, const float* __restrict__ ray_d,
+                                                    const float* __restrict__ noise, int R, int S,
+                                                    float* __restrict__ rgb_map, float* __restrict__ disp_map,
+                                                    float* __restrict__ acc_map, float* __restrict__ weights,
+                                                    float* __restrict__ depth_map) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;   // wave-uniform
+    float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    float carry = 1.0f;   // transmittance entering this chunk
+    float sr = 0.f, sg = 0.f, sb = 0.f, sdep = 0.f, sacc = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + lane;
+        const bool in = i < S;
+        const int64_t g = (int64_t)r * S + i;
+        float z = in ? z_vals[g] : 0.f;
+        float zn = __shfl_down(z, 1);
+        if (lane == 63 && i + 1 < S) zn = z_vals[g + 1];
+        float dist = (i + 1 < S) ? (zn - z) : 1e10f;
+        dist = dist * dn;
+        float s = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        if (in) {
+            s = sigma[g];
+            if (transparent && transparent[g]) s = 0.f;
+            if (noise) s = s + noise[g];
+            s = s > 0.f ? s : 0.f;
+            cr = colour[3 * g]; cg = colour[3 * g + 1]; cb = colour[3 * g + 2];
+        }
+        const float alpha = in ? (1.0f - expf(-s * dist)) : 0.f;
+        const float fac = in ? ((1.0f - alpha) + 1e-10f) : 1.0f;
+        float incl = fac;   // inclusive product scan over the wavefront
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            float t = __shfl_up(incl, off);
+            if (lane >= off) incl = incl * t;
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63);
+        const float w = alpha * T;
+        if (in && weights) weights[g] = w;
+        sr += dsn_wave_sum(w * cr);
+        sg += dsn_wave_sum(w * cg);
+        sb += dsn_wave_sum(w * cb);
+        sdep += dsn_wave_sum(w * z);
+        sacc += dsn_wave_sum(w);
+    }
+    if (lane == 0) {
+        rgb_map[3 * r] = sr; rgb_map[3 * r + 1] = sg; rgb_map[3 * r + 2] = sb;
+        depth_map[r] = sdep;
+        acc_map[r] = sacc;
+        float q = dsn_div(sdep, sacc);          // NaN when acc == 0, like the reference
+        float m = (1e-10f > q) ? 1e-10f : q;    // torch.max propagates NaN
+        if (q != q) m = q;
+        disp_map[r] = dsn_div(1.0f, m);
+    }
+}
+
+void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
+                          const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st) {
+    hipLaunchKernelGGL(k_composite, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
+                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map);
+}

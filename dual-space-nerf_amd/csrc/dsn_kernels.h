@@ -1,0 +1,31 @@
+// dsn_kernels.h - host-side launcher prototypes shared by the .hip translation units and dsn_api.hip
+#pragma once
+#include "dsn_common.h"
+
+void dsn_launch_face_setup(const float* verts, const int32_t* faces, int F, DsnFaceRec* recs, float4* cent,
+                           hipStream_t st);
+void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_idx, int zero_code,
+                           const float* light_shift, const float* rot, const float* rot_center, DsnFrameState* fs,
+                           hipStream_t st);
+void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
+                          int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
+                          hipStream_t st);
+void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
+                     const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
+                     uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
+                     hipStream_t st);
+void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
+                       const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
+                       hipStream_t st);
+void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
+                          const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st);
+// dsn_field.hip
+void dsn_pack_params_host(const float* const* params33_host, float* packed_host);
+void dsn_launch_pack_params(const float* const* params33_dev_array, float* packed, hipStream_t st);
+void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                      const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                      float* grad, hipStream_t st);
+void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
+                      const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
+                      int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);

@@ -1,0 +1,55 @@
+"""Ray-parallel multi-GPU execution of the hot path: one process per GPU, rays partitioned into
+contiguous blocks, rendered pixels combined by ONE all-gather (RCCL over xGMI on MI355X; gloo in the
+CPU tests).  The reference has no distributed code at all; rays are independent
+units, so there is no data-path collective besides this exchange of 6 floats per ray
+(rgb, disp, acc, depth = 24 B/ray: 786 KB per rank for a 512x512 frame on 8 GPUs - latency-bound, so a
+single fused all_gather_into_tensor of the packed [block, 6] tensor is used rather than six small ones).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class RayParallel:
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def block(self, R: int) -> int:
+        return (R + self.world - 1) // self.world
+
+    def shard(self, R: int):
+        """[start, stop) of this rank's contiguous ray block (last blocks may be short or empty)."""
+        b = self.block(R)
+        start = min(R, self.rank * b)
+        return start, min(R, start + b)
+
+    def gather(self, local: torch.Tensor, R: int) -> torch.Tensor:
+        """local [r_local, C] (this rank's block, r_local = stop-start) -> [R, C] on every rank."""
+        if self.world == 1:
+            return local
+        b = self.block(R)
+        C = local.shape[1]
+        pad = torch.zeros(b, C, dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        out = torch.empty(self.world * b, C, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return out[:R]
+
+    def render(self, render_fn, ray_o, ray_d, near, far):
+        """render_fn(ray_o, ray_d, near, far) -> dict(color [r,3], disp_map [r], acc_map [r], depth_map [r])
+        on this rank's block; returns the same dict for all R rays on every rank."""
+        R = ray_o.shape[0]
+        s, e = self.shard(R)
+        if e > s:
+            loc = render_fn(ray_o[s:e].contiguous(), ray_d[s:e].contiguous(), near[s:e].contiguous(),
+                            far[s:e].contiguous())
+            packed = torch.cat([loc["color"], loc["disp_map"][:, None], loc["acc_map"][:, None],
+                                loc["depth_map"][:, None]], dim=1)
+        else:
+            packed = torch.zeros(0, 6, dtype=torch.float32, device=ray_o.device)
+        full = self.gather(packed, R)
+        return {"color": full[:, 0:3], "disp_map": full[:, 3], "acc_map": full[:, 4], "depth_map": full[:, 5]}

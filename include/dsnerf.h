@@ -1,0 +1,122 @@
+/*
+ * dsnerf.h - C ABI of libdsnerf_hip.so: the MI355X (gfx950) implementation of the
+ * Dual-Space-NeRF volume-rendering hot path.
+ *
+ * The reference (zyhbili/Dual-Space-NeRF) has no FFI layer: its boundary is the Python call
+ * surface can_render.Renderer / model.spacenet.DualSpaceNeRF.  Each entry point below replaces
+ * the device work behind one reference function (cited per function, paths relative to the
+ * reference repo) and is what a ctypes binding inside that function would call; see
+ * INTEGRATION.md for the stubs.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; float32 row-major,
+ *     indices int32, masks uint8;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - `scene` is an opaque device blob (dsn_scene_bytes(V,F)); V and F are passed with it on every call
+ *     (the library keeps no host-side state);
+ *   - functions never allocate, never synchronise, never touch the host copy of any tensor:
+ *     the caller owns every buffer (sizes from the *_bytes() helpers) and the ordering is the
+ *     stream's;
+ *   - return 0 on success; non-zero = error, message from dsn_last_error() (thread-local).
+ *     There is no CPU fallback: if no gfx950 device / code object is available the call fails.
+ */
+#ifndef DSNERF_H
+#define DSNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#define DSN_EXPORT __attribute__((visibility("default")))
+extern "C" {
+#endif
+
+#define DSN_ABI_VERSION 1
+#define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
+
+DSN_EXPORT int dsn_abi_version(void);
+DSN_EXPORT const char* dsn_last_error(void);
+
+/* ---- network parameters ------------------------------------------------------------------
+ * params33_host: HOST array of 33 DEVICE pointers in state_dict order (nerf.embedding.weight,
+ * nerf.stage1.{0,2,4,6}.{weight,bias}, nerf.stage2.{0,2,4}.{weight,bias}, nerf.density_net.0.*,
+ * nerf.rgb_net.{1,3}.*, lighting_mlp.lights_encoding.{0,2,4}.*, pose_mlp.{0,2,4}.*), torch
+ * Linear layout [out,in].  Replaces nn.Module parameter storage consumed by
+ * model/spacenet.py:93-148,174-188,223-236; re-run after every optimizer step / load_state_dict. */
+DSN_EXPORT size_t dsn_packed_param_bytes(void);
+DSN_EXPORT int dsn_pack_params(const float* const* params33_host, void* packed, void* stream);
+
+/* layout utility, no device work: writes the packed image of 33 HOST arrays into a HOST buffer of
+ * dsn_packed_param_bytes() bytes (lets tools / tests inspect the MFMA operand layout without a GPU) */
+DSN_EXPORT int dsn_pack_params_host_image(const float* const* params33_host, float* packed_host);
+
+/* ---- body model + per-frame state ----------------------------------------------------------
+ * dsn_set_body : can_render.py:382-406 Renderer.load_body_model (canonical_model["meshes"]).
+ * dsn_set_frame: per-batch state: posed mesh batch["xyz"] (can_render.py:352-355), centroids
+ *   (utils/render_utils.py:94), pose code batch_rod2quat+pose_mlp (model/spacenet.py:223-236,
+ *   314-331), embedding row (model/spacenet.py:125-129; zero_code = `net.nerf.w is not None`),
+ *   light-centre shift / rotation (model/spacenet.py:254-263; NULL = not set).
+ *   light_shift3 = light_center - Th. */
+DSN_EXPORT size_t dsn_scene_bytes(int V, int F);
+DSN_EXPORT int dsn_set_body(void* scene, const float* canon_vertex, const int32_t* faces, int V, int F, void* stream);
+DSN_EXPORT int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
+                  int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
+                  void* stream);
+
+/* ---- stage kernels -----------------------------------------------------------------------*/
+/* utils/pts_utils.py:18-58 geometry_guided_ray_marching + :3-16 uniform_sampling.
+ * near/far [R] are updated in place (reference :52-53).  t_vals [S] = torch.linspace(0,1,S);
+ * jitter [R,S] = the torch.rand draw of :12 (NULL in eval).  pts [R,S,3] may be NULL. */
+DSN_EXPORT int dsn_sample_gg(const void* scene, int V, int F, const float* ray_o, const float* ray_d, float* near, float* far, int R, int S,
+                  const float* t_vals, const float* jitter, float* z_vals, float* pts, void* stream);
+
+/* utils/pts_utils.py:3-16 uniform_sampling alone (cfg.MODEL.sample_points_mode == "uniform",
+ * can_render.py:42-51): same arguments, near/far are not modified. */
+DSN_EXPORT int dsn_sample_uniform(const void* scene, int V, int F, const float* ray_o, const float* ray_d, float* near, float* far,
+                       int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts, void* stream);
+
+/* can_render.py:333-379 Renderer.w2l_without_lbs (+ utils/render_utils.py:84-109,
+ * utils/geo_utils.py:96-113,138-156,181-200).  pts [N,3]; ray_d [N/S,3] per-ray directions
+ * (NULL -> no ray_d_can).  Any output may be NULL.  active_list/active_count (optional): indices of
+ * non-transparent points appended in unspecified order (count must be zeroed by the caller). */
+DSN_EXPORT int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray_d, int64_t N, int S, int32_t* face_idx, float* uv,
+             float* h, uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list,
+             int32_t* active_count, void* stream);
+
+/* model/spacenet.py:93-148 SpaceNet.forward + :301-311 gradient(): sigma [N], essence [N,3],
+ * grad = d sigma / d x_c [N,3].  If active_list != NULL only the listed points (count read from
+ * active_count on the device) are evaluated and written; the rest are left untouched. */
+DSN_EXPORT int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
+              const int32_t* active_count, float* sigma, float* essence, float* grad, void* stream);
+
+/* model/spacenet.py:278-298 normal_local2world + :254-265 + :174-188 LightingMLP.forward.
+ * x_w = world sample points [N,3], ray_d [N/S,3]; outputs face_idx_canon [N], n_w [N,3],
+ * colour [N,3] (any may be NULL except colour). */
+DSN_EXPORT int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
+              const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
+              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, void* stream);
+
+/* can_render.py:115-120 (transparent sigma-zeroing) + utils/nerf_net_utils.py:5-56 raw2outputs.
+ * colour [R,S,3], sigma [R,S], transparent [R,S] (NULL = none), noise [R,S] = randn*raw_noise_std
+ * (NULL in eval).  weights [R,S] may be NULL. */
+DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
+                  const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
+                  float* acc_map, float* weights, float* depth_map, void* stream);
+
+/* ---- fused path: can_render.py:137-168 Renderer.render on R rays --------------------------
+ * flags: DSN_SKIP_TRANSPARENT evaluates the networks only on non-transparent samples (exact in
+ * eval mode: their sigma is forced to 0 and their colour is multiplied by weight 0; must not be
+ * set when noise != NULL).  out_weights / out_z may be NULL. */
+#define DSN_SKIP_TRANSPARENT 1
+DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
+DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                    float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
+                    int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
+                    float* out_weights, float* out_z, void* workspace, void* stream);
+
+/* diagnostics: the first int32 of `workspace` holds the number of samples the last DSN_SKIP_TRANSPARENT
+ * render evaluated (device memory). */
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSNERF_H */

@@ -1,0 +1,178 @@
+"""GPU parity of the fused path and the Python boundary (Renderer / DualSpaceNeRF mirrors)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from helpers import CASES, code_for, light_kw, load, maxdiff, state
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(S):
+    return SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
+                           MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0,
+                                                 raw_noise_std=1.0, TYPE="nerf", FINE_RAY_SAMPLING=-1))
+
+
+def make_renderer(g, name=None):
+    import dsnerf_amd
+    S = int(g["S"])
+    net = dsnerf_amd.DualSpaceNeRF(make_cfg(S))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in state().items()})
+    net.cuda()
+    r = dsnerf_amd.Renderer(net, None, make_cfg(S), torch.from_numpy(g["canonical_vertex"]),
+                            body_data={"f": g["faces"]})
+    if name == "small_novel":
+        r.net.set_light_center(torch.from_numpy(g["light_center"]))
+        r.net.nerf.w = 0
+    if name == "small_rot":
+        r.net.set_rot_center(torch.from_numpy(g["rot_center"]))
+        r.net.set_rot(torch.from_numpy(g["rot"]))
+    return r
+
+
+def make_batch(g):
+    return {
+        "ray_o": torch.from_numpy(g["ray_o"])[None], "ray_d": torch.from_numpy(g["ray_d"])[None],
+        "near": torch.from_numpy(g["near"].copy())[None], "far": torch.from_numpy(g["far"].copy())[None],
+        "xyz": torch.from_numpy(g["xyz"])[None], "poses": torch.from_numpy(g["poses"])[None],
+        "Th": torch.from_numpy(g["Th"]).reshape(1, 1, 3), "frame": torch.tensor([int(g["frame"])]),
+    }
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_render_matches_reference_and_oracle(name):
+    g = load(name)
+    r = make_renderer(g, name)
+    train = name == "small_train"
+    if train:
+        r.train()
+        torch.manual_seed(233)       # main.py:21-26; the mirror draws rand then randn like the reference
+    else:
+        r.eval()
+    out = r.render(make_batch(g))["coarse"]
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.array_equal(out["z_vals"], g["render:z_vals"])
+    # reference float32 Renderer.render on the same batch
+    for k, tol in (("color", 1e-4), ("acc_map", 1e-4), ("weights", 1e-4), ("depth_map", 3e-4)):
+        assert maxdiff(out[k], g["render:" + k]) < tol, (k, maxdiff(out[k], g["render:" + k]))
+    # oracle on the same inputs (same geometry bit for bit; only MLP rounding differs)
+    S = int(g["S"])
+    sd = state()
+    tv = torch.linspace(0.0, 1.0, steps=S).numpy()
+    jit = g["jitter"][0] if "jitter" in g.files else None
+    noise = g["noise"] if "noise" in g.files else None
+    e = O.render(g["ray_o"], g["ray_d"], g["near"], g["far"], S, g["xyz"], g["canonical_vertex"], g["faces"],
+                 O.Params(sd), g["poses"], code_for(g, sd, name), jitter=jit, noise=noise, t_vals=tv, **light_kw(g))
+    assert maxdiff(out["color"], e["color"]) < 1e-4
+    d, dg = out["disp_map"], g["render:disp_map"]
+    assert np.array_equal(np.isnan(d), np.isnan(dg))
+
+
+@pytest.mark.parametrize("name", ["small_eval", "full_eval"])
+def test_skip_transparent_is_exact(name):
+    g = load(name)
+    r = make_renderer(g, name)
+    r.eval()
+    r.skip_transparent = True
+    a = r.render(make_batch(g))["coarse"]
+    a = {k: v.clone() for k, v in a.items()}
+    r.skip_transparent = False
+    b = r.render(make_batch(g))["coarse"]
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_render_view_matches_reference():
+    g = load("small_view")
+    r = make_renderer(g)
+    r.eval()
+    H, W = int(g["H"]), int(g["W"])
+    b = make_batch(g)
+    b["img"] = torch.zeros(1, H, W, 3, dtype=torch.float64)
+    b["mask_at_box"] = torch.from_numpy(g["mask_at_box"])[None]
+    v = r.render_view(b)
+    for k in ("coarse_color", "coarse_acc", "coarse_depth"):
+        assert tuple(v[k].shape) == tuple(g[k].shape) and not v[k].is_cuda
+        assert maxdiff(v[k].numpy(), g[k]) < 1e-4, k
+    outside = ~g["mask_at_box"].reshape(H, W)
+    assert float(v["coarse_color"].numpy()[outside].sum()) == 0.0
+
+
+def test_module_forward_matches_reference():
+    """DualSpaceNeRF.forward(pos[N,6], rays[N,6], frame_idx, batch_info) like can_render.py:113"""
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    b = make_batch(g)
+    b["canonical_model"] = r.canonical_model
+    b["face_idx"] = r.face_idx
+    S = int(g["S"])
+    dirs = np.repeat(g["ray_d"][:, None, :], S, 1).reshape(-1, 3)
+    pos = torch.from_numpy(np.concatenate([g["pts"].reshape(-1, 3), g["x_c"]], 1))
+    rays = torch.from_numpy(np.concatenate([dirs, g["ray_d_can"]], 1))
+    col, den, _ = r.net(pos, rays, torch.full((g["ray_o"].shape[0], S), int(g["frame"])), batch_info=b)
+    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < 1e-4
+    act = ~g["transparent"]
+    assert maxdiff(col.cpu().numpy()[act], g["colour"][act]) < 2e-4
+    den2 = r.net(pos, rays, 0, b, density_only=True)
+    assert torch.equal(den2, den)
+    # query_volume (utils/visualizer.py:47-66's call)
+    q = r.query_volume(torch.from_numpy(g["x_c"])[None], torch.tensor([int(g["frame"])]),
+                       torch.from_numpy(g["transparent"])[None], b)
+    assert q.shape == (1, g["x_c"].shape[0], 1)
+    assert float(q.reshape(-1)[torch.from_numpy(g["transparent"]).to(q.device)].abs().sum()) == 0.0
+
+
+def test_w2l_boundary_methods():
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    b = make_batch(g)
+    near, far = b["near"].clone(), b["far"].clone()
+    pts, z = r.get_sampling_points(b["ray_o"], b["ray_d"], near, far, b["xyz"], mode="GG")
+    assert np.array_equal(z[0].cpu().numpy(), g["z_vals"]) and np.array_equal(near[0].numpy(), g["near_gg"])
+    p6, rays, tm = r.w2l(pts, b["ray_o"], b["ray_d"], b)
+    assert np.array_equal(p6[..., 3:].reshape(-1, 3).cpu().numpy(), g["x_c"])
+    assert np.array_equal(rays[..., 3:].reshape(-1, 3).cpu().numpy(), g["ray_d_can"])
+    assert np.array_equal(tm.reshape(-1).cpu().numpy(), g["transparent"])
+
+
+def test_full_size_properties():
+    """512x512x64 (BASELINE config 2): size-independent properties + oracle on a ray subset."""
+    import dsnerf_amd
+    from dsnerf_amd import synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(512, 512, xyz)
+    S = 64
+    g = {"canonical_vertex": canon, "faces": faces, "S": S}
+    r = make_renderer(g)
+    r.eval()
+    poses = synth.make_poses()
+    batch = {"ray_o": torch.from_numpy(rays["ray_o"])[None], "ray_d": torch.from_numpy(rays["ray_d"])[None],
+             "near": torch.from_numpy(rays["near"].copy())[None], "far": torch.from_numpy(rays["far"].copy())[None],
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(poses)[None],
+             "Th": torch.tensor([0.2, -0.1, 1.0]).reshape(1, 1, 3), "frame": torch.tensor([5])}
+    out = r.render(batch)["coarse"]
+    w, acc, z = out["weights"], out["acc_map"], out["z_vals"]
+    assert torch.isfinite(out["color"]).all() and torch.isfinite(w).all()
+    assert float((w.sum(-1) - acc).abs().max()) < 1e-5                # acc is the sum of weights
+    assert float(acc.max()) <= 1.0 + 1e-5 and float(w.min()) >= 0.0
+    assert bool((z[:, 1:] >= z[:, :-1]).all())                           # samples are ordered
+    dep = out["depth_map"]
+    hit = acc > 0.99
+    assert bool(((dep[hit] >= z[hit, 0] - 1e-4) & (dep[hit] <= z[hit, -1] + 1e-4)).all())
+    # oracle on 48 rays spread over the image
+    sel = np.linspace(0, 512 * 512 - 1, 48).astype(np.int64)
+    sd = state()
+    tv = torch.linspace(0.0, 1.0, steps=S).numpy()
+    # same first-ray origin for the sampler: put ray 0 first (all rays share the camera origin anyway)
+    e = O.render(rays["ray_o"][sel], rays["ray_d"][sel], rays["near"][sel], rays["far"][sel], S, xyz, canon, faces,
+                 O.Params(sd), poses, sd["nerf.embedding.weight"][5], t_vals=tv)
+    got = out["color"][torch.from_numpy(sel).cuda()].cpu().numpy()
+    assert np.array_equal(out["z_vals"][torch.from_numpy(sel).cuda()].cpu().numpy(), e["z_vals"])
+    assert maxdiff(got, e["color"]) < 1e-4

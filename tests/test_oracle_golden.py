@@ -1,0 +1,102 @@
+"""The oracle (oracle/dsn_oracle.c) is PINNED here: every function is checked against the golden
+vectors the real reference produced (tests/golden/make_golden.py).  Geometry stages are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from helpers import CASES, code_for, light_kw, load, maxdiff, per_point_dirs, state
+
+
+@pytest.fixture(scope="module")
+def params():
+    sd = state()
+    return sd, O.Params(sd)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampler_bit_exact(name):
+    g = load(name)
+    S = int(g["S"])
+    tv = torch.linspace(0.0, 1.0, steps=S).numpy()   # utils/pts_utils.py:4 draws it on the host
+    jit = g["jitter"][0] if "jitter" in g.files else None
+    sm = O.sample_gg(g["ray_o"], g["ray_d"], g["near"], g["far"], g["xyz"], S, jit, tv)
+    assert np.array_equal(sm["near"], g["near_gg"]) and np.array_equal(sm["far"], g["far_gg"])
+    assert np.array_equal(sm["z_vals"], g["z_vals"])
+    assert np.array_equal(sm["pts"], g["pts"])
+    # the built-in linspace differs from torch's vectorised one by at most 1 ulp
+    assert maxdiff(O.linspace01(S), tv) <= 1.2e-7
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_warp_bit_exact(name):
+    g = load(name)
+    assert np.array_equal(O.centroids(g["xyz"], g["faces"]), g["centroid_world"])
+    w = O.warp(g["pts"], per_point_dirs(g), g["xyz"], g["canonical_vertex"], g["faces"])
+    assert np.array_equal(w["idx"], g["idx_world"])
+    assert np.array_equal(w["uv"], g["uv"]) and np.array_equal(w["h"], g["h"])
+    assert np.array_equal(w["transparent"], g["transparent"])
+    assert np.array_equal(w["x_c"], g["x_c"])
+    assert np.array_equal(w["ray_d_can"], g["ray_d_can"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_field(name, params):
+    sd, P = params
+    g = load(name)
+    q, pf = O.pose_feat(g["poses"], P)
+    assert np.array_equal(q, g["pose_quat"][0])
+    assert maxdiff(pf, g["pose_feat"][0]) < 5e-7
+    sig, ess, gr = O.field(g["x_c"], P, code_for(g, sd, name), g["pose_feat"][0])
+    assert maxdiff(sig, g["sigma"]) < 5e-5                  # |sigma| <= 10: GEMM-order noise only
+    assert maxdiff(ess, g["essence"]) < 5e-6
+    scale = np.abs(g["grad_sigma"]).max()
+    assert maxdiff(gr, g["grad_sigma"]) < 2e-4 * scale      # ill-conditioned (PE x512, ReLU kinks)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_normal_and_lighting(name, params):
+    sd, P = params
+    g = load(name)
+    idc, nw = O.normal_world(g["x_c"], g["grad_sigma"], g["canonical_vertex"], g["xyz"], g["faces"])
+    assert np.array_equal(idc, g["idx_canon"])
+    assert np.array_equal(nw, g["n_w"])
+    col = O.lighting(g["n_w"], g["pts"], per_point_dirs(g), g["essence"], P, **light_kw(g))
+    assert maxdiff(col, g["colour"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_composite(name):
+    g = load(name)
+    noise = g["noise"] if "noise" in g.files else None
+    cm = O.composite(g["raw"], g["z_vals"], g["ray_d"], noise)
+    for k in ("rgb_map", "acc_map", "weights", "depth_map"):
+        assert maxdiff(cm[k], g[k]) < 2e-6, k
+    fin = np.isfinite(g["disp_map"])
+    assert np.array_equal(np.isnan(cm["disp_map"]), np.isnan(g["disp_map"]))   # NaN where acc == 0
+    assert np.allclose(cm["disp_map"][fin], g["disp_map"][fin], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_render_end_to_end(name, params):
+    """Whole path vs Renderer.render of the reference (trainer.py:70's call)."""
+    sd, P = params
+    g = load(name)
+    S = int(g["S"])
+    tv = torch.linspace(0.0, 1.0, steps=S).numpy()
+    jit = g["jitter"][0] if "jitter" in g.files else None
+    noise = g["noise"] if "noise" in g.files else None
+    e = O.render(g["ray_o"], g["ray_d"], g["near"], g["far"], S, g["xyz"], g["canonical_vertex"], g["faces"], P,
+                 g["poses"], code_for(g, sd, name), jitter=jit, noise=noise, t_vals=tv, **light_kw(g))
+    assert np.array_equal(e["z_vals"], g["render:z_vals"])
+    for k in ("color", "depth_map", "acc_map", "weights"):
+        assert maxdiff(e[k], g["render:" + k]) < 1e-4, k      # north_star tolerance
+        assert maxdiff(e[k], g["render:" + k]) < 5e-6, k      # what is actually achieved
+
+
+def test_reference_noise_floor_documented():
+    """The reference disagrees with ITSELF (float32 vs float64) by far more than 1e-4 end to end on the
+    full body: parity has to be judged stage-wise / against same-precision outputs."""
+    g = load("full_eval")
+    assert maxdiff(g["rgb_map"], g["rgb_map_f64"]) > 1e-3
+    assert maxdiff(g["sigma"], g["sigma_f64"]) > 1e-2

@@ -1,0 +1,70 @@
+"""N>1 path on CPU: world_size-2 gloo run of the ray partition + all-gather (dual-space-nerf_amd/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _fake_render(o, d, n, f):
+    # any deterministic per-ray function: lets the test check placement after the gather
+    s = (o * d).sum(-1) + n - f
+    return {"color": torch.stack([s, 2 * s, 3 * s], -1), "disp_map": s + 1, "acc_map": s + 2, "depth_map": s + 3}
+
+
+def _worker(rank, world, port, R, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("par", os.path.join(root, "dual-space-nerf_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(par)
+    g = torch.Generator().manual_seed(7)
+    o, d = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+    n, f = torch.rand(R, generator=g), torch.rand(R, generator=g) + 1
+    rp = par.RayParallel()
+    s, e = rp.shard(R)
+    out = rp.render(_fake_render, o, d, n, f)
+    ref = _fake_render(o, d, n, f)
+    ok = all(torch.equal(out[k], ref[k]) for k in ref)
+    q.put((rank, s, e, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [10, 7, 1])
+def test_ray_parallel_world2(R):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, R, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, e0, ok0), (r1, s1, e1, ok1) = res
+    assert ok0 and ok1
+    assert s0 == 0 and e0 == s1 and e1 == R      # contiguous, disjoint, covering
+
+
+def test_single_process_is_identity():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("par", os.path.join(root, "dual-space-nerf_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(par)
+    rp = par.RayParallel()
+    assert rp.world == 1 and rp.shard(9) == (0, 9)
+    x = torch.arange(12.0).reshape(4, 3)
+    assert rp.gather(x, 4) is x
