@@ -71,7 +71,7 @@ def main():
     sd = synth.make_state_dict()
     poses = synth.make_poses(seed=5 + rank)
     xyz = synth.pose_body(canon, seed=3 + rank)          # every rank renders its own frame of the batch
-    rays = synth.make_rays(H, W, xyz)
+    rays = synth.make_rays(H, W, xyz, fit_box=True)    # every ray crosses the padded body AABB (= mask_at_box rays)
 
     packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
     scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
@@ -131,7 +131,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{H}x{W} frame x {S} samples/ray per GPU (BASELINE configs[1]; N>1: one frame per GPU, configs[4]), "
-                        f"synthetic closed body V=6890/F=13776, GG sampling, eval mode",
+                        f"synthetic closed body V=6890/F=13776, camera framed so that all rays cross the body AABB (mask_at_box), "
+                        f"GG sampling, eval mode",
             "rays_per_gpu": R, "samples_per_ray": S,
             "transparent_skip": (not args.dense),
             "evaluated_sample_fraction": n_active / float(R * S),

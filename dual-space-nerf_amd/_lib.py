@@ -33,10 +33,11 @@ EXPORTS = [
     "dsn_abi_version", "dsn_last_error", "dsn_packed_param_bytes", "dsn_pack_params",
     "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_shade", "dsn_composite",
-    "dsn_render_workspace_bytes", "dsn_render_rays",
+    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_debug_nn_stats",
 ]
 
 SKIP_TRANSPARENT = 1
+NN_EXHAUSTIVE = 2
 
 
 def lib():
@@ -88,7 +89,7 @@ class PackedParams:
     def __init__(self, device):
         require_gpu()
         self.device = torch.device(device)
-        self.buf = torch.empty(lib().dsn_packed_param_bytes(), dtype=torch.uint8, device=self.device)
+        self.buf = torch.zeros(lib().dsn_packed_param_bytes(), dtype=torch.uint8, device=self.device)
         self._versions = None
         self._keep = None
 
@@ -135,6 +136,14 @@ class Scene:
         return self
 
 
+def nn_stats(scene: Scene):
+    """Diagnostics (synchronising): dict level -> (ncell, ok, total, cap)."""
+    out = (C.c_int32 * 16)()
+    _check(lib().dsn_debug_nn_stats(_ptr(scene.buf), scene.V, scene.F, out, _stream()), "dsn_debug_nn_stats")
+    names = ["world_fine", "world_coarse", "canon_fine", "canon_coarse"]
+    return {n: tuple(out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
+
+
 # ------------------------------------------------------------------------------------------------
 # stage calls (device tensors in, device tensors out)
 # ------------------------------------------------------------------------------------------------
@@ -151,7 +160,7 @@ def sample(scene: Scene, ray_o, ray_d, near, far, S, t_vals, jitter=None, want_p
     return pts, z
 
 
-def warp(scene: Scene, pts, ray_d, S, want_dir=True, want_uvh=False, want_active=False):
+def warp(scene: Scene, pts, ray_d, S, want_dir=True, want_uvh=False, want_active=False, exhaustive=False):
     pts = pts.reshape(-1, 3)
     N = pts.shape[0]
     dev = scene.device
@@ -171,7 +180,7 @@ def warp(scene: Scene, pts, ray_d, S, want_dir=True, want_uvh=False, want_active
         cnt = out["active_count"] = torch.zeros(64, dtype=torch.int32, device=dev)
     _check(lib().dsn_warp(_ptr(scene.buf), scene.V, scene.F, _ptr(pts, torch.float32), _ptr(ray_d), C.c_int64(N), S,
                           _ptr(out["face_idx"]), _ptr(uv), _ptr(h), _ptr(out["transparent"]), _ptr(out["x_c"]),
-                          _ptr(rdc), _ptr(lst), _ptr(cnt), _stream()), "dsn_warp")
+                          _ptr(rdc), _ptr(lst), _ptr(cnt), NN_EXHAUSTIVE if exhaustive else 0, _stream()), "dsn_warp")
     return out
 
 
@@ -188,7 +197,7 @@ def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=
     return sigma, ess, g
 
 
-def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None):
+def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None, exhaustive=False):
     x_c = x_c.reshape(-1, 3)
     N = x_c.shape[0]
     dev = scene.device
@@ -199,7 +208,8 @@ def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S,
     _check(lib().dsn_shade(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32),
                            _ptr(grad.reshape(-1, 3), torch.float32), _ptr(x_w.reshape(-1, 3), torch.float32),
                            _ptr(ray_d, torch.float32), _ptr(essence.reshape(-1, 3), torch.float32), C.c_int64(N), S,
-                           _ptr(lst), _ptr(cnt), _ptr(idx), _ptr(n_w), _ptr(col), _stream()), "dsn_shade")
+                           _ptr(lst), _ptr(cnt), _ptr(idx), _ptr(n_w), _ptr(col), NN_EXHAUSTIVE if exhaustive else 0,
+                           _stream()), "dsn_shade")
     return idx, n_w, col
 
 
@@ -232,7 +242,7 @@ class RenderWorkspace:
 
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
-                jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None):
+                jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -247,6 +257,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         if want_weights:
             out["weights"] = torch.empty(R, S, dtype=torch.float32, device=dev)
     flags = SKIP_TRANSPARENT if (skip_transparent and noise is None) else 0
+    if exhaustive:
+        flags |= NN_EXHAUSTIVE
     buf = ws.get(R, S)
     _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
                                  _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,

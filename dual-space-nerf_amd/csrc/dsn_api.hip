@@ -58,6 +58,8 @@ int dsn_set_body(void* scene, const float* canon_vertex, const int32_t* faces, i
         hipMemcpyAsync(s.faces, faces, sizeof(int32_t) * 3 * (size_t)F, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return dsn_fail("%s", "dsn_set_body: copy failed");
     dsn_launch_face_setup(s.canon, s.faces, F, s.face_canon, s.cent_canon, st);
+    // canonical-space queries are x_c = face frame re-embedding with |h| <= 0.1 and uv in [-4,5]: wide pads
+    dsn_launch_build_nn(s.cent_canon, F, s.nn_canon, 0.25f, 0.7f, st);
     return dsn_check_launch("dsn_set_body");
 }
 
@@ -72,6 +74,8 @@ int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xy
     if (hipMemcpyAsync(s.xyz, xyz, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return dsn_fail("%s", "dsn_set_frame: copy failed");
     dsn_launch_face_setup(s.xyz, s.faces, F, s.face_world, s.cent_world, st);
+    // world-space queries lie inside the (padded) body AABB the rays were clipped to; coarse level beyond
+    dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st);
     dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2,
                           s.frame, st);
     return dsn_check_launch("dsn_set_frame");
@@ -99,14 +103,14 @@ int dsn_sample_uniform(const void* scene, int V, int F, const float* ray_o, cons
 
 int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray_d, int64_t N, int S, int32_t* face_idx, float* uv,
              float* h, uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list,
-             int32_t* active_count, void* stream) {
+             int32_t* active_count, int flags, void* stream) {
     DSN_REQUIRE(scene && pts, "dsn_warp: null argument");
     DSN_REQUIRE(N > 0 && S > 0, "dsn_warp: empty point batch");
     DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_warp: active_list and active_count go together");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_warp: bad V/F");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
     dsn_launch_warp(s, pts, nullptr, ray_d, nullptr, N, S, face_idx, uv, h, transparent, x_c, ray_d_can, active_list,
-                    active_count, (hipStream_t)stream);
+                    active_count, (flags & DSN_NN_EXHAUSTIVE) != 0, (hipStream_t)stream);
     return dsn_check_launch("dsn_warp");
 }
 
@@ -124,14 +128,14 @@ int dsn_field(const void* scene, int V, int F, const void* packed, const float* 
 
 int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
               const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
-              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, void* stream) {
+              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, int flags, void* stream) {
     DSN_REQUIRE(scene && packed && x_c && grad && x_w && ray_d && essence && n_w && colour, "dsn_shade: null argument");
     DSN_REQUIRE(N > 0 && S > 0, "dsn_shade: empty point batch");
     DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_shade: active_list and active_count go together");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_shade: bad V/F");
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    dsn_launch_normal(s, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, st);
+    dsn_launch_normal(s, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, (flags & DSN_NN_EXHAUSTIVE) != 0, st);
     dsn_launch_light((const float*)packed, s.frame, n_w, x_w, nullptr, ray_d, nullptr, essence, N, S, active_list,
                      active_count, colour, st);
     return dsn_check_launch("dsn_shade");
@@ -145,6 +149,22 @@ int dsn_composite(const float* colour, const float* sigma, const uint8_t* transp
     dsn_launch_composite(colour, sigma, transparent, z_vals, ray_d, noise, R, S, rgb_map, disp_map, acc_map, weights,
                          depth_map, (hipStream_t)stream);
     return dsn_check_launch("dsn_composite");
+}
+
+// diagnostics (synchronises the stream): {ncell, ok, total, cap} of world-fine, world-coarse, canon-fine,
+// canon-coarse nearest-face levels -> out16_host
+int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream) {
+    DSN_REQUIRE(scene && out16_host && V > 0 && F > 0, "dsn_debug_nn_stats: bad argument");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    const DsnGrid* gs[4] = {s.nn_world.fine.g, s.nn_world.coarse.g, s.nn_canon.fine.g, s.nn_canon.coarse.g};
+    for (int i = 0; i < 4; ++i) {
+        DsnGrid h;
+        if (hipMemcpyAsync(&h, gs[i], sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+            return dsn_fail("%s", "dsn_debug_nn_stats: copy failed");
+        out16_host[4 * i + 0] = h.ncell; out16_host[4 * i + 1] = h.ok; out16_host[4 * i + 2] = h.total; out16_host[4 * i + 3] = h.cap;
+    }
+    return 0;
 }
 
 // workspace carve for the fused path
@@ -209,9 +229,10 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             hipMemsetAsync(w.colour, 0, sizeof(float) * 3 * N, st) != hipSuccess)
             return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
-    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, st);
+    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
+    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st);
     dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
-    dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, st);
+    dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
     dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st);

@@ -38,6 +38,9 @@ struct DsnFrameState {   // small per-frame vectors
     float bias0[256];    // stage1.0 bias with the 24 constant input columns (code, pose) folded in
 };
 
+__host__ __device__ inline size_t dsn_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+#include "dsn_nn.h"
+
 struct DsnSceneView {
     int V, F;
     float* canon;            // [V,3] copy
@@ -48,9 +51,9 @@ struct DsnSceneView {
     DsnFaceRec* face_world;  // [F]
     DsnFaceRec* face_canon;  // [F]
     DsnFrameState* frame;
+    DsnNNView nn_world;      // exact nearest-centroid lists of the posed mesh (rebuilt per frame)
+    DsnNNView nn_canon;      // ... of the canonical mesh (built once)
 };
-
-__host__ __device__ inline size_t dsn_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 __host__ __device__ inline DsnSceneView dsn_scene_view(void* base, int V, int F) {
     DsnSceneView s;
@@ -66,12 +69,14 @@ __host__ __device__ inline DsnSceneView dsn_scene_view(void* base, int V, int F)
     s.face_world = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
     s.face_canon = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
     s.frame = (DsnFrameState*)p;    p += dsn_align256(sizeof(DsnFrameState));
+    s.nn_world = dsn_nn_view(p, F);
+    s.nn_canon = dsn_nn_view(p, F);
     return s;
 }
 __host__ __device__ inline size_t dsn_scene_size(int V, int F) {
     return 256 + 2 * dsn_align256(sizeof(float) * 3 * (size_t)V) + dsn_align256(sizeof(int32_t) * 3 * (size_t)F) +
            2 * dsn_align256(sizeof(float4) * (size_t)F) + 2 * dsn_align256(sizeof(DsnFaceRec) * (size_t)F) +
-           dsn_align256(sizeof(DsnFrameState));
+           dsn_align256(sizeof(DsnFrameState)) + 2 * dsn_nn_bytes(F);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -83,7 +88,7 @@ __device__ __forceinline__ float dsn_dot3(const float* a, const float* b) {
 }
 // torch.norm(dim=-1) on 3 floats: fma-accumulated sum of squares, then sqrt
 __device__ __forceinline__ float dsn_norm3(const float* a) {
-    return __fsqrt_rn(fmaf(a[2], a[2], fmaf(a[1], a[1], a[0] * a[0])));
+    return sqrtf(fmaf(a[2], a[2], fmaf(a[1], a[1], a[0] * a[0])));
 }
 // torch.cross: fma(a_i, b_j, -(a_j*b_i))
 __device__ __forceinline__ void dsn_cross3(const float* a, const float* b, float* o) {

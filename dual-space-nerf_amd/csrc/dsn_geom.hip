@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
             float z0 = dsn_sum3(v.x * du[0], v.y * du[1], v.z * du[2]);
             float tmp = v.w - z0 * z0;
             if (tmp < gamma2) {
-                float dz = __fsqrt_rn(gamma2 - tmp);
+                float dz = sqrtf(gamma2 - tmp);
                 zmin = fminf(zmin, z0 - dz);
                 zmax = fmaxf(zmax, z0 + dz);
                 any = true;
@@ -218,7 +218,17 @@ __device__ __forceinline__ int dsn_nearest_bruteforce(const float4* __restrict__
 
 // can_render.py:333-379 w2l_without_lbs.  One thread per sample point.
 #define WARP_THREADS 256
-__global__ void __launch_bounds__(WARP_THREADS) k_warp(const float4* __restrict__ cent_world,
+struct DsnNNArgs {   // device pointers of one mesh's two-level lists
+    const DsnGrid* gf; const int32_t* off_f; const float4* list_f;
+    const DsnGrid* gc; const int32_t* off_c; const int32_t* list_c;
+};
+static DsnNNArgs dsn_nn_args(const DsnNNView& v) {
+    DsnNNArgs a = {v.fine.g, v.fine.offsets, (const float4*)v.fine.list, v.coarse.g, v.coarse.offsets, (const int32_t*)v.coarse.list};
+    return a;
+}
+
+template <bool EXHAUSTIVE>
+__global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float4* __restrict__ cent_world,
                                                         const DsnFaceRec* __restrict__ face_world,
                                                         const DsnFaceRec* __restrict__ face_canon, int F,
                                                         const float* __restrict__ pts, const float* __restrict__ ray_o,
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(const float4* __restrict_
                                                         float* __restrict__ x_c, float* __restrict__ ray_d_can,
                                                         int32_t* __restrict__ active_list,
                                                         int32_t* __restrict__ active_count) {
-    __shared__ float4 s_tile[NN_TILE];
+    __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
     const bool valid = i < N;
     float p[3] = {0.f, 0.f, 0.f};
@@ -244,7 +254,9 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(const float4* __restrict_
             p[2] = ray_o[3 * ray + 2] + ray_d[3 * ray + 2] * z;
         }
     }
-    int fi = dsn_nearest_bruteforce(cent_world, F, p[0], p[1], p[2], s_tile);
+    int fi = 0;
+    if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_world, F, p[0], p[1], p[2], s_tile);
+    else if (valid) fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_world, F, p[0], p[1], p[2]);
     bool active = false;
     if (valid) {
         DsnFaceRec fw = dsn_load_face(face_world, fi);
@@ -287,17 +299,24 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(const float4* __restrict_
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     hipStream_t st) {
+                     bool exhaustive, hipStream_t st) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
-    hipLaunchKernelGGL(k_warp, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, s.cent_world, s.face_world,
-                       s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c, ray_d_can,
-                       active_list, active_count);
+    DsnNNArgs nn = dsn_nn_args(s.nn_world);
+    if (exhaustive)
+        hipLaunchKernelGGL(k_warp<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
+                           s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
+                           ray_d_can, active_list, active_count);
+    else
+        hipLaunchKernelGGL(k_warp<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
+                           s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
+                           ray_d_can, active_list, active_count);
 }
 
 // ---------------------------------------------------------------------------------------------
 // normals: model/spacenet.py:278-298 normal_local2world.  One thread per (listed) point.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WARP_THREADS) k_normal(const float4* __restrict__ cent_canon,
+template <bool EXHAUSTIVE>
+__global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const float4* __restrict__ cent_canon,
                                                           const DsnFaceRec* __restrict__ face_world,
                                                           const DsnFaceRec* __restrict__ face_canon, int F,
                                                           const float* __restrict__ x_c, const float* __restrict__ grad,
@@ -305,7 +324,7 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(const float4* __restric
                                                           const int32_t* __restrict__ active_count,
                                                           int32_t* __restrict__ face_idx_canon,
                                                           float* __restrict__ n_w) {
-    __shared__ float4 s_tile[NN_TILE];
+    __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     int64_t count = active_list ? (int64_t)(*active_count) : N;
     int64_t slot0 = (int64_t)blockIdx.x * WARP_THREADS;
     if (slot0 >= count) return;   // uniform per block
@@ -314,7 +333,9 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(const float4* __restric
     int64_t i = valid ? (active_list ? (int64_t)active_list[slot] : slot) : 0;
     float p[3] = {0.f, 0.f, 0.f};
     if (valid) { p[0] = x_c[3 * i]; p[1] = x_c[3 * i + 1]; p[2] = x_c[3 * i + 2]; }
-    int fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
+    int fi = 0;
+    if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
+    else if (valid) fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_canon, F, p[0], p[1], p[2]);
     if (!valid) return;
     DsnFaceRec fc = dsn_load_face(face_canon, fi);
     DsnFaceRec fw = dsn_load_face(face_world, fi);
@@ -332,10 +353,15 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(const float4* __restric
 
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
-                       hipStream_t st) {
+                       bool exhaustive, hipStream_t st) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
-    hipLaunchKernelGGL(k_normal, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, s.cent_canon, s.face_world,
-                       s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
+    DsnNNArgs nn = dsn_nn_args(s.nn_canon);
+    if (exhaustive)
+        hipLaunchKernelGGL(k_normal<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_canon, s.face_world,
+                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
+    else
+        hipLaunchKernelGGL(k_normal<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_canon, s.face_world,
+                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
 }
 
 // ---------------------------------------------------------------------------------------------

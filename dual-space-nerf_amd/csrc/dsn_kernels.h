@@ -13,10 +13,12 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     hipStream_t st);
+                     bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
-                       hipStream_t st);
+                       bool exhaustive, hipStream_t st);
+// dsn_nn.hip
+void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st);
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st);

@@ -1,0 +1,151 @@
+// dsn_nn.h - exact nearest-centroid search structure ("cell candidate lists").
+//
+// The reference finds, for every sample point, the face whose centroid is nearest
+// (utils/render_utils.py:84-99 -> pytorch3d knn_points K=1): 13 776 distance evaluations per point,
+// twice per point.  This structure returns the SAME index (bit-identical argmin, first index on ties)
+// from a short list:
+//
+//   For a box B (a grid cell, grown by a guard band), every point p in B satisfies
+//       dist(p, c_nn(p)) <= dist(p, c_g) <= dmax(B, c_g)        for all faces g,
+//   hence  dmin(B, c_nn(p)) <= U(B) := min_g dmax(B, c_g).
+//   So the list  L(B) = { f : dmin(B, c_f)^2 <= U(B)^2 (1 + 1e-5) }  contains the nearest centroid of
+//   every point of B (the 1e-5 slack dominates all float32 rounding in dmin/dmax/d2; the guard band
+//   dominates the rounding of the point->cell assignment).  L(B) is stored in ascending face order, and
+//   the query scans it with the same fma chain and strict '<' as the brute-force search, so ties resolve
+//   to the lowest index exactly as pytorch3d does.
+//
+// Two levels per mesh: a fine grid (~3F cells) over the centroid AABB + pad1 and a coarse grid over
+// AABB + pad2 for far-away points; points outside both fall back to an exhaustive scan.  Lists are
+// rebuilt on the device for every posed frame (dsn_set_frame) and once for the canonical mesh.
+#pragma once
+// (included from dsn_common.h after dsn_align256 is defined)
+
+struct DsnGrid {            // device-resident descriptor (64 B)
+    float lo[3];
+    float cell;
+    float inv_cell;
+    int nx, ny, nz;
+    int ncell;
+    int ok;                 // 1 when the lists fit the capacity and the level is usable
+    int total;              // number of list entries
+    int cap;                // capacity of the list array (entries)
+    int maxcell;
+    int pad_[3];
+};
+
+#define DSN_GRID_GUARD 1e-4f     // metres added on every side of a cell before bounding
+#define DSN_NN_FINE_MAXCELL 65536
+#define DSN_NN_COARSE_MAXCELL 16384
+
+__host__ __device__ inline int dsn_nn_fine_cap(int F) { long long c = 1600LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
+__host__ __device__ inline int dsn_nn_coarse_cap(int F) { long long c = 1000LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
+
+struct DsnGridView {        // one level
+    DsnGrid* g;
+    int32_t* offsets;       // [maxcell + 1]
+    float* u2;              // [maxcell] scratch: U(B)^2
+    void* list;             // [cap] entries: float4 {x,y,z,index bits} (fine level) or int32 index (coarse level)
+};
+struct DsnNNView { DsnGridView fine, coarse; };
+
+__host__ __device__ inline size_t dsn_grid_bytes(int maxcell, int cap, int entry_bytes) {
+    return dsn_align256(sizeof(DsnGrid)) + dsn_align256(sizeof(int32_t) * ((size_t)maxcell + 1)) +
+           dsn_align256(sizeof(float) * (size_t)maxcell) + dsn_align256((size_t)entry_bytes * (size_t)cap);
+}
+__host__ __device__ inline DsnGridView dsn_grid_view(char*& p, int maxcell, int cap, int entry_bytes) {
+    DsnGridView v;
+    v.g = (DsnGrid*)p;          p += dsn_align256(sizeof(DsnGrid));
+    v.offsets = (int32_t*)p;    p += dsn_align256(sizeof(int32_t) * ((size_t)maxcell + 1));
+    v.u2 = (float*)p;           p += dsn_align256(sizeof(float) * (size_t)maxcell);
+    v.list = (void*)p;          p += dsn_align256((size_t)entry_bytes * (size_t)cap);
+    return v;
+}
+__host__ __device__ inline size_t dsn_nn_bytes(int F) {
+    return dsn_grid_bytes(DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), 16) +
+           dsn_grid_bytes(DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), 4);
+}
+__host__ __device__ inline DsnNNView dsn_nn_view(char*& p, int F) {
+    DsnNNView v;
+    v.fine = dsn_grid_view(p, DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), 16);
+    v.coarse = dsn_grid_view(p, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), 4);
+    return v;
+}
+
+#ifdef __HIPCC__
+// squared distance exactly as the exhaustive search computes it
+__device__ __forceinline__ float dsn_d2(float px, float py, float pz, const float4 c) {
+    float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+    float d = dx * dx;
+    d = fmaf(dy, dy, d);
+    d = fmaf(dz, dz, d);
+    return d;
+}
+
+// cell index of p in grid g, or -1 when p is outside the grid / the level is unusable
+__device__ __forceinline__ int dsn_grid_cell(const DsnGrid& g, float px, float py, float pz) {
+    if (!g.ok) return -1;
+    float fx = (px - g.lo[0]) * g.inv_cell, fy = (py - g.lo[1]) * g.inv_cell, fz = (pz - g.lo[2]) * g.inv_cell;
+    if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f)) return -1;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    if (ix >= g.nx || iy >= g.ny || iz >= g.nz) return -1;
+    return (ix * g.ny + iy) * g.nz + iz;
+}
+
+// exact nearest centroid through the two-level lists; exhaustive scan (global memory) beyond them.
+// Fine lists carry the centroid inline (one 16-byte load per candidate, sequential addresses, lanes in the
+// same cell share them) and are scanned four at a time in list order, which keeps first-index-wins.
+__device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
+                                                 const float4* __restrict__ list_f, const DsnGrid* __restrict__ gc,
+                                                 const int32_t* __restrict__ off_c, const int32_t* __restrict__ list_c,
+                                                 const float4* __restrict__ cent, int F, float px, float py, float pz) {
+    float best = INFINITY;
+    int bi = 0;
+    int c = dsn_grid_cell(*gf, px, py, pz);
+    if (c >= 0) {
+        const int o = off_f[c], n = off_f[c + 1] - o;
+        const float4* e = list_f + o;
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const float4 a = e[i], b = e[i + 1], cc = e[i + 2], d = e[i + 3];
+            const float da = dsn_d2(px, py, pz, a), db = dsn_d2(px, py, pz, b);
+            const float dc = dsn_d2(px, py, pz, cc), dd = dsn_d2(px, py, pz, d);
+            if (da < best) { best = da; bi = __float_as_int(a.w); }
+            if (db < best) { best = db; bi = __float_as_int(b.w); }
+            if (dc < best) { best = dc; bi = __float_as_int(cc.w); }
+            if (dd < best) { best = dd; bi = __float_as_int(d.w); }
+        }
+        for (; i < n; ++i) {
+            const float4 a = e[i];
+            const float da = dsn_d2(px, py, pz, a);
+            if (da < best) { best = da; bi = __float_as_int(a.w); }
+        }
+        return bi;
+    }
+    c = dsn_grid_cell(*gc, px, py, pz);
+    if (c >= 0) {
+        const int o = off_c[c], n = off_c[c + 1] - o;
+        const int32_t* lst = list_c + o;
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const int f0 = lst[i], f1 = lst[i + 1], f2 = lst[i + 2], f3 = lst[i + 3];
+            const float d0 = dsn_d2(px, py, pz, cent[f0]), d1 = dsn_d2(px, py, pz, cent[f1]);
+            const float d2 = dsn_d2(px, py, pz, cent[f2]), d3 = dsn_d2(px, py, pz, cent[f3]);
+            if (d0 < best) { best = d0; bi = f0; }
+            if (d1 < best) { best = d1; bi = f1; }
+            if (d2 < best) { best = d2; bi = f2; }
+            if (d3 < best) { best = d3; bi = f3; }
+        }
+        for (; i < n; ++i) {
+            const int f = lst[i];
+            const float d = dsn_d2(px, py, pz, cent[f]);
+            if (d < best) { best = d; bi = f; }
+        }
+        return bi;
+    }
+    for (int f = 0; f < F; ++f) {
+        const float d = dsn_d2(px, py, pz, cent[f]);
+        if (d < best) { best = d; bi = f; }
+    }
+    return bi;
+}
+#endif

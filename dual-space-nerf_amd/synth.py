@@ -135,7 +135,7 @@ def pose_body(canon: np.ndarray, seed: int = 3, trans=(0.2, -0.1, 1.0)) -> np.nd
 # camera
 # --------------------------------------------------------------------------------------
 def make_rays(H: int, W: int, xyz: np.ndarray, cam_dist: float = 2.6, focal_frac: float = 1.05,
-              pad: float = 0.05, unit_dirs: bool = False):
+              pad: float = 0.05, unit_dirs: bool = False, fit_box: bool = False):
     """Pinhole rays for an H x W image looking at the body's centre from -z at `cam_dist`.
 
     Returns dict(ray_o [R,3], ray_d [R,3], near [R], far [R]) float32, R = H*W.
@@ -154,6 +154,31 @@ def make_rays(H: int, W: int, xyz: np.ndarray, cam_dist: float = 2.6, focal_frac
     Rc2w = Ry @ Rx
     o = ctr - Rc2w @ np.array([0.0, 0.0, cam_dist])
     focal = focal_frac * max(H, W)
+    if fit_box:
+        # The reference renders only rays that cross the body's 3-D bounds (mask_at_box,
+        # dataloader/zju_mocap_dataset.py + utils/rays_utils.py:63-97).  To get H*W such rays, zoom in until
+        # the padded AABB's silhouette covers the whole image: the largest focal length whose corner rays
+        # still hit the box (bisection), i.e. the whole image is "mask_at_box".
+        def all_hit(fc):
+            cs = np.array([[-0.5 * W + 0.5, -0.5 * H + 0.5], [0.5 * W - 0.5, -0.5 * H + 0.5],
+                           [-0.5 * W + 0.5, 0.5 * H - 0.5], [0.5 * W - 0.5, 0.5 * H - 0.5]])
+            # border pixels (the silhouette of a convex box is convex: borders suffice)
+            ts = np.linspace(-0.5, 0.5, 65)
+            bx = np.concatenate([np.stack([ts * W, np.full_like(ts, -0.5 * H + 0.5)], 1), np.stack([ts * W, np.full_like(ts, 0.5 * H - 0.5)], 1),
+                                 np.stack([np.full_like(ts, -0.5 * W + 0.5), ts * H], 1), np.stack([np.full_like(ts, 0.5 * W - 0.5), ts * H], 1), cs])
+            dd = np.concatenate([bx / fc, np.ones((bx.shape[0], 1))], 1) @ Rc2w.T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                a, b = (lo - o) / dd, (hi - o) / dd
+            return bool((np.minimum(a, b).max(-1) < np.maximum(a, b).min(-1)).all())
+        f_lo, f_hi = focal, 64.0 * focal
+        if not all_hit(f_lo):
+            for _ in range(40):
+                mid = 0.5 * (f_lo + f_hi)
+                if all_hit(mid):
+                    f_hi = mid
+                else:
+                    f_lo = mid
+            focal = f_hi * 1.001
     jj, ii = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     dc = np.stack([(jj - 0.5 * W + 0.5) / focal, (ii - 0.5 * H + 0.5) / focal, np.ones_like(jj)], -1)
     d = (dc.reshape(-1, 3) @ Rc2w.T)

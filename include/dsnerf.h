@@ -81,7 +81,7 @@ DSN_EXPORT int dsn_sample_uniform(const void* scene, int V, int F, const float* 
  * non-transparent points appended in unspecified order (count must be zeroed by the caller). */
 DSN_EXPORT int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray_d, int64_t N, int S, int32_t* face_idx, float* uv,
              float* h, uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list,
-             int32_t* active_count, void* stream);
+             int32_t* active_count, int flags, void* stream);
 
 /* model/spacenet.py:93-148 SpaceNet.forward + :301-311 gradient(): sigma [N], essence [N,3],
  * grad = d sigma / d x_c [N,3].  If active_list != NULL only the listed points (count read from
@@ -94,7 +94,7 @@ DSN_EXPORT int dsn_field(const void* scene, int V, int F, const void* packed, co
  * colour [N,3] (any may be NULL except colour). */
 DSN_EXPORT int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
               const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
-              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, void* stream);
+              const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, int flags, void* stream);
 
 /* can_render.py:115-120 (transparent sigma-zeroing) + utils/nerf_net_utils.py:5-56 raw2outputs.
  * colour [R,S,3], sigma [R,S], transparent [R,S] (NULL = none), noise [R,S] = randn*raw_noise_std
@@ -108,11 +108,18 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
  * eval mode: their sigma is forced to 0 and their colour is multiplied by weight 0; must not be
  * set when noise != NULL).  out_weights / out_z may be NULL. */
 #define DSN_SKIP_TRANSPARENT 1
+/* nearest-face search by exhaustive scan instead of the exact cell-candidate lists (same result by
+ * construction; kept as the on-device cross-check of the lists).  Valid for dsn_warp, dsn_shade, dsn_render_rays. */
+#define DSN_NN_EXHAUSTIVE 2
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
                     float* out_weights, float* out_z, void* workspace, void* stream);
+
+/* diagnostics, NOT for the hot path (synchronises `stream`): {ncell, ok, total entries, capacity} of the four
+ * nearest-face list levels (world fine/coarse, canonical fine/coarse) into a HOST array of 16 int32. */
+DSN_EXPORT int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream);
 
 /* diagnostics: the first int32 of `workspace` holds the number of samples the last DSN_SKIP_TRANSPARENT
  * render evaluated (device memory). */

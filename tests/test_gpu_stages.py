@@ -58,12 +58,16 @@ def test_sampler(ctx, name):
     assert np.array_equal(pts.cpu().numpy(), g["pts"])
 
 
+@pytest.mark.parametrize("exhaustive", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_warp(ctx, name):
+def test_warp(ctx, name, exhaustive):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
     sc = scene_for(ctx, g, name)
-    out = ctx["lib"].warp(sc, T(g["pts"], dev), T(g["ray_d"], dev), S, want_dir=True, want_uvh=True, want_active=True)
+    st = ctx["lib"].nn_stats(sc)
+    assert all(v[1] == 1 and v[2] <= v[3] for v in st.values()), st       # every list level is in use
+    out = ctx["lib"].warp(sc, T(g["pts"], dev), T(g["ray_d"], dev), S, want_dir=True, want_uvh=True, want_active=True,
+                          exhaustive=exhaustive)
     assert np.array_equal(out["face_idx"].cpu().numpy(), g["idx_world"])
     assert np.array_equal(out["uv"].cpu().numpy(), g["uv"])
     assert np.array_equal(out["h"].cpu().numpy(), g["h"])
@@ -85,8 +89,15 @@ def test_field(ctx, name):
     # vs the reference's own float32 outputs (north_star: 1e-4 abs on sigma / RGB)
     assert maxdiff(sig, g["sigma"]) < 1e-4
     assert maxdiff(ess, g["essence"]) < 1e-4
-    scale = np.abs(g["grad_sigma"]).max()
-    assert maxdiff(gr, g["grad_sigma"]) < 3e-4 * scale
+    # d sigma/dx is ill-conditioned (encoding x512, ReLU kinks: a pre-activation within rounding of 0 flips a
+    # whole mask and moves the gradient discretely - the reference's own float32/float64 runs disagree the same
+    # way), so it is judged per point, relative, with a small outlier budget instead of a max-abs bound.
+    gn = np.linalg.norm(g["grad_sigma"], axis=-1)
+    rel = np.linalg.norm(gr - g["grad_sigma"], axis=-1) / np.maximum(gn, 1.0)
+    assert np.median(rel) < 2e-6
+    assert np.mean(rel > 1e-4) < 2e-3, float(np.mean(rel > 1e-4))
+    rel64 = np.linalg.norm(g["grad_sigma"] - g["grad_sigma_f64"], axis=-1) / np.maximum(gn, 1.0)
+    assert np.mean(rel > 1e-4) <= np.mean(rel64 > 1e-4) + 2e-3     # no worse than the reference's own spread
     # and no further from the float64 reference than the float32 reference is (x1.5 slack)
     assert maxdiff(sig, g["sigma_f64"]) <= 1.5 * maxdiff(g["sigma"], g["sigma_f64"]) + 1e-5
     # vs the oracle on the same inputs
@@ -115,13 +126,14 @@ def test_field_active_list(ctx, name):
     assert float(a_sig[~m].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("exhaustive", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_shade(ctx, name):
+def test_shade(ctx, name, exhaustive):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
     sc = scene_for(ctx, g, name)
     idx, n_w, col = ctx["lib"].shade(sc, ctx["packed"], T(g["x_c"], dev), T(g["grad_sigma"], dev), T(g["pts"], dev),
-                                     T(g["ray_d"], dev), T(g["essence"], dev), S)
+                                     T(g["ray_d"], dev), T(g["essence"], dev), S, exhaustive=exhaustive)
     assert np.array_equal(idx.cpu().numpy(), g["idx_canon"])
     assert np.array_equal(n_w.cpu().numpy(), g["n_w"])          # same inputs -> bit-exact normals
     assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5
@@ -149,3 +161,26 @@ def test_composite(ctx, name):
     tm = T(g["transparent"].reshape(raw.shape[:2]).astype(np.uint8), dev)
     rgb2, *_ = ctx["lib"].composite(T(col, dev), T(s2, dev), tm, T(g["z_vals"], dev), T(g["ray_d"], dev), noise)
     assert torch.equal(rgb2, rgb)
+
+
+def test_lists_equal_exhaustive_on_random_points(ctx):
+    """exact-list search == exhaustive search, bit for bit, for points anywhere (inside the fine grid,
+    in the coarse shell, and far outside both)"""
+    g = load("full_eval")
+    dev = ctx["dev"]
+    sc = scene_for(ctx, g, "full_eval")
+    rng = np.random.default_rng(5)
+    lo, hi = g["xyz"].min(0), g["xyz"].max(0)
+    near = rng.uniform(lo - 0.1, hi + 0.1, size=(200000, 3))
+    shell = rng.uniform(lo - 0.9, hi + 0.9, size=(60000, 3))
+    far = rng.uniform(lo - 3.0, hi + 3.0, size=(4000, 3))
+    onv = g["xyz"][rng.integers(0, g["xyz"].shape[0], 20000)] + rng.normal(0, 1e-3, (20000, 3))
+    pts = np.concatenate([near, shell, far, onv]).astype(np.float32)
+    a = ctx["lib"].warp(sc, T(pts, dev), None, 1, want_dir=False, want_uvh=True, exhaustive=False)
+    b = ctx["lib"].warp(sc, T(pts, dev), None, 1, want_dir=False, want_uvh=True, exhaustive=True)
+    for k in ("face_idx", "x_c", "uv", "h", "transparent"):
+        assert torch.equal(a[k], b[k]), k
+    # the exhaustive kernel itself against the oracle on a subset
+    sub = pts[::97]
+    idx = O.nearest_face(sub, O.centroids(g["xyz"], g["faces"]))
+    assert np.array_equal(b["face_idx"].cpu().numpy()[::97], idx)
