@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 FLOP_FIELD_PER_SAMPLE = 2.0 * 884608.0       # k_field: forward trunk+heads 458 880 MAC + reverse 425 728 MAC
 FLOP_ALL_PER_SAMPLE = 2.0 * 902272.0         # + lighting MLP 17 664 MAC
 PEAK_F32_MATRIX_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F16_MATRIX_TFLOPS = 2500.0              # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
+SPLIT_PRODUCTS = 3                           # split-fp16: 3 f16 MFMA products per algorithmic product
 
 
 def parse():
@@ -45,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays the CPU oracle is timed on (0 = sized for ~15 s)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
     return ap.parse_args()
 
 
@@ -94,7 +97,7 @@ def main():
         far.copy_(far0)
         scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
         out = _lib.render_rays(scene, packed, ws, ray_o, ray_d, near, far, S, t_vals, None, None,
-                               skip_transparent=not args.dense, want_weights=False, out=out)
+                               skip_transparent=not args.dense, want_weights=False, out=out, fp32=args.fp32)
         if world > 1:
             packed_px[:, 0:3] = out["color"]
             packed_px[:, 3] = out["disp_map"]
@@ -163,7 +166,7 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
     n_eval = R * S if args.dense else int(w["active_count"][0])
     reps = max(3, min(10, args.steps))
     for _i in range(2):
-        _lib.field(scene, packed, w["x_c"], active=active)
+        _lib.field(scene, packed, w["x_c"], active=active, fp32=args.fp32)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _i in range(reps)]
     # pre-allocate outputs once so that only the kernel sits between the events
@@ -178,16 +181,23 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
         a.record()
         rc = _lib.lib().dsn_field(_lib._ptr(scene.buf), scene.V, scene.F, _lib._ptr(packed.buf), _lib._ptr(w["x_c"]),
                                   C.c_int64(N), _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess),
-                                  _lib._ptr(g), _lib._stream())
+                                  _lib._ptr(g), _lib.FIELD_FP32 if args.fp32 else 0, _lib._stream())
         b.record()
         assert rc == 0
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     flops = n_eval * FLOP_FIELD_PER_SAMPLE
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_field", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None, "kernel_ms": ms, "samples_per_launch": n_eval,
-            "flop_per_sample": FLOP_FIELD_PER_SAMPLE}
+    if args.fp32:
+        peak, kern, note = PEAK_F32_MATRIX_TFLOPS, "k_field", "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    else:
+        # the algorithmic FLOPs are executed as 3 f16 MFMA products each: the ceiling for ALGORITHMIC FLOP/s of this
+        # scheme is the dense f16 MFMA peak / 3 (= 5.3x the fp32-matrix peak of 157.3)
+        peak, kern = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "k_field16"
+        note = "split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32-equivalent accuracy; peak = 2500/3"
+    return {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": None, "kernel_ms": ms, "samples_per_launch": n_eval,
+            "flop_per_sample": FLOP_FIELD_PER_SAMPLE, "scheme": note, "x_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
 
 
 def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):

@@ -38,6 +38,7 @@ EXPORTS = [
 
 SKIP_TRANSPARENT = 1
 NN_EXHAUSTIVE = 2
+FIELD_FP32 = 4
 
 
 def lib():
@@ -184,7 +185,7 @@ def warp(scene: Scene, pts, ray_d, S, want_dir=True, want_uvh=False, want_active
     return out
 
 
-def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=True, active=None):
+def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=True, active=None, fp32=False):
     x_c = x_c.reshape(-1, 3)
     N = x_c.shape[0]
     dev = scene.device
@@ -193,7 +194,8 @@ def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=
     g = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_grad else None
     lst, cnt = (None, None) if active is None else active
     _check(lib().dsn_field(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
-                           _ptr(lst), _ptr(cnt), _ptr(sigma), _ptr(ess), _ptr(g), _stream()), "dsn_field")
+                           _ptr(lst), _ptr(cnt), _ptr(sigma), _ptr(ess), _ptr(g), FIELD_FP32 if fp32 else 0, _stream()),
+           "dsn_field")
     return sigma, ess, g
 
 
@@ -242,7 +244,8 @@ class RenderWorkspace:
 
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
-                jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False):
+                jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
+                fp32=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -259,6 +262,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     flags = SKIP_TRANSPARENT if (skip_transparent and noise is None) else 0
     if exhaustive:
         flags |= NN_EXHAUSTIVE
+    if fp32:
+        flags |= FIELD_FP32
     buf = ws.get(R, S)
     _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
                                  _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,

@@ -115,14 +115,19 @@ int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray
 }
 
 int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
-              const int32_t* active_count, float* sigma, float* essence, float* grad, void* stream) {
+              const int32_t* active_count, float* sigma, float* essence, float* grad, int flags, void* stream) {
     DSN_REQUIRE(scene && packed && x_c && sigma, "dsn_field: null argument");
     DSN_REQUIRE(N > 0, "dsn_field: empty point batch");
     DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_field: active_list and active_count go together");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_field: bad V/F");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    dsn_launch_field((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
-                     (hipStream_t)stream);
+    // split-fp16 kernel for the full evaluation; the exact-fp32 kernel serves density-only / colour-only queries
+    if (!(flags & DSN_FIELD_FP32) && essence && grad)
+        dsn_launch_field16((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
+                           (hipStream_t)stream);
+    else
+        dsn_launch_field((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
+                         (hipStream_t)stream);
     return dsn_check_launch("dsn_field");
 }
 
@@ -231,7 +236,10 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     }
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st);
-    dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+    if (flags & DSN_FIELD_FP32)
+        dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+    else
+        dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
     dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,

@@ -98,6 +98,48 @@ __device__ __forceinline__ void dsn_cross3(const float* a, const float* b, float
 }
 __device__ __forceinline__ float dsn_div(float a, float b) { return __fdiv_rn(a, b); }
 
+// Branch-free sincos for the positional encoding (arguments x * 2^j, |x| of order 1 m, j < 10).
+// Two-term Cody-Waite reduction by pi/2 with fma (error ~ |k| * 2e-15, k < 2^16 safe) + the classic
+// minimax polynomials on [-pi/4, pi/4] (~1 ulp); no divergent large-argument path, so 30 inlined calls
+// cost neither exec-mask SGPRs nor scratch (ocml's sincosf carries a Payne-Hanek branch per call).
+__device__ __forceinline__ void dsn_sincos(float x, float& s, float& c) {
+    const float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(kf, -1.57079637050628662109375f, x);
+    r = fmaf(kf, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)kf;
+    const float a = (q & 1) ? cr : sr;
+    const float b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// relu bit patterns without compare masks.  `x > 0 ? .. : ..` costs an SGPR pair per element and LLVM
+// canonicalises every arithmetic spelling of it back to v_cmp + v_cndmask; in the long unrolled network
+// kernels the scheduler then keeps hundreds of such pairs alive and spills them.  Two one-instruction
+// asm ops (opaque to instcombine, still schedulable) pin the VALU-only form.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dsn_nonzero_bit(float v) {       // 1 if v != 0 (v >= 0 by construction)
+    uint32_t b;
+    asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(v)));
+    return b;
+}
+template <int R>
+__device__ __forceinline__ float dsn_keep_if_bit(float a, uint32_t m) {   // a if bit R of m is set, else +0
+    int k;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(k) : "v"(m), "n"(R));
+    return __int_as_float(__float_as_int(a) & k);
+}
+#define DSN_FOR16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+
 // per-face record: identical values to what the reference recomputes per point
 __device__ __forceinline__ void dsn_make_face(const float* v0, const float* v1, const float* v2, DsnFaceRec& r) {
     float n[3];
@@ -195,8 +237,15 @@ enum {
     OFF_RAW_PM2B = OFF_RAW_PM2W + 64 * 64,
     OFF_RAW_PM4W = OFF_RAW_PM2B + 64,
     OFF_RAW_PM4B = OFF_RAW_PM4W + 16 * 64,
-    OFF_END = OFF_RAW_PM4B + 16
+    OFF_END32 = OFF_RAW_PM4B + 16,
+    // ---- split-fp16 images of the same 872-block stream (csrc/dsn_field16.hip): 4 KB per block, stored as
+    // [t(2)][part(hi,lo)][lane(64)][8 halves]; block b of the fp32 stream <-> block b here.
+    OFF16_BASE = (OFF_END32 + 63) & ~63,          // float offset, 256-byte aligned
+    DSN_STREAM_BLOCKS = OFF_LT0 / DSN_BLK,        // 872: stage1.0 ... stage1.0^T in consumption order
+    OFF_END = OFF16_BASE + DSN_STREAM_BLOCKS * DSN_BLK
 };
+#define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
+#define DSN_LO_INV (1.0f / 4096.0f)
 
 // accumulator (C/D) layout of v_mfma_f32_32x32x2_f32: lane l, register r holds
 //   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31

@@ -85,14 +85,11 @@ __constant__ DsnImageX g_images[] = {DSN_IMAGE_TABLE};
 static const DsnImageX h_images[] = {DSN_IMAGE_TABLE};
 #define DSN_NUM_IMAGES ((int)(sizeof(g_images) / sizeof(g_images[0])))
 
-// value of packed element e of image x  (see the header comment for the lane mapping)
-__host__ __device__ inline float dsn_pack_value(const DsnImageX& x, const float* __restrict__ src, int e) {
+// weight the A operand of block (mb, kb) holds for k-slot r (0..15) of `lane` - shared by the fp32 image
+// (r = 4*r4 + j) and the split-fp16 image (r = 8*t + j): see the header comment for the lane mapping
+__host__ __device__ inline float dsn_weight_at(const DsnImageX& x, const float* __restrict__ src, int mb, int kb, int r, int lane) {
     const DsnImage& im = x.im;
-    if (im.kind == IMG_COPY) return src[e];
-    int blk = e / DSN_BLK, w = e % DSN_BLK;
-    int mb = blk / im.KB, kb = blk % im.KB;
-    int r4 = w / 256, lane = (w % 256) / 4, j = w % 4;
-    int r = 4 * r4 + j, half = lane >> 5, row = lane & 31;
+    const int half = lane >> 5, row = lane & 31;
     if (im.kind == IMG_LT0) {
         int k = 2 * r + half;
         return (r < 5 && k < 9) ? src[(32 * mb + row) * im.ld + k] : 0.0f;
@@ -115,12 +112,41 @@ __host__ __device__ inline float dsn_pack_value(const DsnImageX& x, const float*
     return src[o * im.ld + im.col0 + 32 * mb + row];
 }
 
+// value of packed element e of the fp32 image x
+__host__ __device__ inline float dsn_pack_value(const DsnImageX& x, const float* __restrict__ src, int e) {
+    const DsnImage& im = x.im;
+    if (im.kind == IMG_COPY) return src[e];
+    int blk = e / DSN_BLK, w = e % DSN_BLK;
+    int r4 = w / 256, lane = (w % 256) / 4, j = w % 4;
+    return dsn_weight_at(x, src, blk / im.KB, blk % im.KB, 4 * r4 + j, lane);
+}
+
+// halfword hw (0..2047) of the split-fp16 image of stream block (image x, local block blk)
+__host__ __device__ inline _Float16 dsn_pack_value16(const DsnImageX& x, const float* __restrict__ src, int blk, int hw) {
+    const DsnImage& im = x.im;
+    const int t = hw >> 10, part = (hw >> 9) & 1, lane = (hw >> 3) & 63, j = hw & 7;
+    const float v = dsn_weight_at(x, src, blk / im.KB, blk % im.KB, 8 * t + j, lane);
+    const _Float16 hi = (_Float16)v;
+    if (!part) return hi;
+    return (_Float16)((v - (float)hi) * DSN_LO_SCALE);
+}
+
 __global__ void k_pack_params(DsnParamPtrs pp, float* __restrict__ packed) {
     const DsnImageX x = g_images[blockIdx.y];
     const float* src = pp.p[x.im.src];
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < x.im.count; e += gridDim.x * blockDim.x)
         packed[x.im.dst + e] = dsn_pack_value(x, src, e);
 }
+
+// split-fp16 stream: image i (first 15 table entries, stream order) owns blocks [dst/DSN_BLK, (dst+count)/DSN_BLK)
+__global__ void k_pack_params16(DsnParamPtrs pp, _Float16* __restrict__ dst16) {
+    const DsnImageX x = g_images[blockIdx.y];
+    const float* src = pp.p[x.im.src];
+    const int nblk = x.im.count / DSN_BLK, b0 = x.im.dst / DSN_BLK;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nblk * 2048; e += gridDim.x * blockDim.x)
+        dst16[(size_t)(b0 + e / 2048) * 2048 + (e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
+}
+#define DSN_NUM_STREAM_IMAGES 15
 
 // host twin of k_pack_params (same dsn_pack_value): lets tests check the MFMA operand layout on a CPU
 void dsn_pack_params_host(const float* const* params33_host, float* packed_host) {
@@ -129,12 +155,21 @@ void dsn_pack_params_host(const float* const* params33_host, float* packed_host)
         const float* src = params33_host[x.im.src];
         for (int e = 0; e < x.im.count; ++e) packed_host[x.im.dst + e] = dsn_pack_value(x, src, e);
     }
+    _Float16* d16 = reinterpret_cast<_Float16*>(packed_host + OFF16_BASE);
+    for (int i = 0; i < DSN_NUM_STREAM_IMAGES; ++i) {
+        const DsnImageX x = h_images[i];
+        const float* src = params33_host[x.im.src];
+        const int nblk = x.im.count / DSN_BLK, b0 = x.im.dst / DSN_BLK;
+        for (int e = 0; e < nblk * 2048; ++e) d16[(size_t)(b0 + e / 2048) * 2048 + (e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
+    }
 }
 
 void dsn_launch_pack_params(const float* const* params33, float* packed, hipStream_t st) {
     DsnParamPtrs pp;
     for (int i = 0; i < DSN_NUM_PARAMS_INTERNAL; ++i) pp.p[i] = params33[i];
     hipLaunchKernelGGL(k_pack_params, dim3(64, DSN_NUM_IMAGES), dim3(256), 0, st, pp, packed);
+    hipLaunchKernelGGL(k_pack_params16, dim3(64, DSN_NUM_STREAM_IMAGES), dim3(256), 0, st, pp,
+                       reinterpret_cast<_Float16*>(packed + OFF16_BASE));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,396 @@
+// dsn_field16.hip - k_field16: the canonical field + d sigma/dx on the gfx950 matrix cores at 16x the
+// fp32-MFMA issue rate, with fp32-equivalent accuracy ("split-fp16", 3 products).
+//
+// Numerics.  Every operand v (activation or weight) is split  v = hi + lo * 2^-12  with
+//   hi = fp16(v),  lo = fp16((v - hi) * 2^12)      (22 significand bits kept)
+// and  W.x  is evaluated as   (W_hi x_hi)  +  2^-12 (W_hi x_lo + W_lo x_hi)   with
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate; products of fp16 are exact in fp32).  The dropped
+// W_lo x_lo term is 2^-24 relative - the size of one fp32 rounding.  Measured against the float64
+// reference this is as accurate as the reference's own float32 run (tests/test_gpu_field16.py;
+// sigma 6e-6 abs).  Plain bf16 / fp16 inputs miss the 1e-4 bar by 10x, bf16 2-way split by 1.4x.
+// Range: the reverse pass runs on g * 2^-6 (exact rescale at the end) so that |g| up to 4e6 stays
+// inside fp16; forward activations must stay below 65504 (they are O(10) for NeRF trunks).
+//
+// Structure.  Same transposed formulation and register chaining as k_field (dsn_field.hip): one
+// wavefront owns 32 points, the accumulator layout of the 32x32 MFMA is re-used as the next
+// B operand - here after an in-register fp32 -> (hi, lo) fp16 pack, 8 k-values per lane per step.
+// 3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles: 167 424 matrix cycles per 32 points
+// instead of 884 736.  At that rate the weight stream (3.57 MB per 128 points per CU) can no longer be
+// fetched per wave from L2, so the 4 waves of a workgroup share it: the stream is cut into 4 KB
+// blocks, a 16-slot LDS ring (64 KB) is filled 8 blocks ahead with global_load_lds_dwordx4 (no VGPR
+// staging; each wave moves one 1 KB quarter of every block), one barrier per 8 blocks.
+#include "dsn_common.h"
+#include "dsn_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// build-time variant switches (probed with scripts/probe_field16_variants.sh; defaults = best measured)
+#ifndef F16_SINCOS_OCML
+#define F16_SINCOS_OCML 0     // 1: ocml sincosf (divergent large-argument path), 0: branch-free dsn_sincos
+#endif
+#ifndef F16_RELU_ASM
+#define F16_RELU_ASM 0        // 1: asm-pinned VALU-only relu/mask idioms, 0: plain C (LLVM picks cmp+cndmask)
+#endif
+#ifndef F16_FENCE
+#define F16_FENCE 0           // sched_barrier after every block
+#endif
+#ifndef F16_PREFETCH
+#define F16_PREFETCH 0        // explicit one-block-ahead LDS operand reads
+#endif
+
+#define F16_THREADS 256
+#define F16_RING_SLOTS 16
+#define F16_CHUNK 8
+#define F16_NCHUNK (DSN_STREAM_BLOCKS / F16_CHUNK)   // 109
+#define F16_GSCALE 0.015625f                         // reverse pass runs on g / 64
+#define F16_GUNSCALE 64.0f
+
+struct W16 {                 // weight stream state of one wave
+    const char* g;           // this lane's source: stream base + wave * 1024 + lane * 16
+    char* ring;              // LDS ring base
+    int wave;
+    half8 h0, l0, h1, l1;    // the CURRENT block's operands: (hi, lo) for k-step 0 and 1
+};
+
+// issue the loads of chunk c (8 blocks) into its ring slots: this wave moves quarter `wave` of every block
+__device__ __forceinline__ void w16_stage(const W16& w, int c) {
+#pragma unroll
+    for (int i = 0; i < F16_CHUNK; ++i) {
+        const int b = c * F16_CHUNK + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w.g + (size_t)b * 4096),
+                                         (__attribute__((address_space(3))) void*)(w.ring + (b & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024),
+                                         16, 0, 0);
+    }
+}
+// chunk boundary in front of block b (b % 8 == 0): after the barrier chunk b/8 has landed for everyone and chunk
+// b/8 - 1 has been read by everyone (its last block is already in registers) -> its slots take chunk b/8 + 1
+__device__ __forceinline__ void w16_boundary(const W16& w, int b) {
+    __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) first: this wave's quarters of chunk b/8 are in LDS
+    const int c = b / F16_CHUNK;
+    if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
+}
+__device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
+    const char* s = w.ring + (b & (F16_RING_SLOTS - 1)) * 4096 + lane * 16;
+    h0 = *reinterpret_cast<const half8*>(s);
+    l0 = *reinterpret_cast<const half8*>(s + 1024);
+    h1 = *reinterpret_cast<const half8*>(s + 2048);
+    l1 = *reinterpret_cast<const half8*>(s + 3072);
+}
+__device__ __forceinline__ void w16_begin(W16& w, int lane) {
+    w16_stage(w, 0);
+    w16_boundary(w, 0);
+    w16_read(w, 0, lane, w.h0, w.l0, w.h1, w.l1);
+}
+
+// (accM, accC) += W[32 rows][32*KB k] * (xh, xl): consumes KB blocks starting at stream block `blk`.
+// One-block-ahead software pipeline: the LDS reads of block b+1 are issued before the 6 MFMAs of block b.
+template <int KB>
+__device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], const half8 (&xl)[KB][2],
+                                        f32x16& accM, f32x16& accC) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#if F16_PREFETCH
+        half8 n0 = w.h0, m0 = w.l0, n1 = w.h1, m1 = w.l1;
+        if (blk + 1 < DSN_STREAM_BLOCKS) {
+            if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16_boundary(w, blk + 1);
+            w16_read(w, blk + 1, lane, n0, m0, n1, m1);
+        }
+#else
+        if (blk > 0) {
+            if ((blk & (F16_CHUNK - 1)) == 0) w16_boundary(w, blk);
+            w16_read(w, blk, lane, w.h0, w.l0, w.h1, w.l1);
+        }
+#endif
+        accM = MFMA16(w.h0, xh[kb][0], accM);
+        accC = MFMA16(w.h0, xl[kb][0], accC);
+        accC = MFMA16(w.l0, xh[kb][0], accC);
+        accM = MFMA16(w.h1, xh[kb][1], accM);
+        accC = MFMA16(w.h1, xl[kb][1], accC);
+        accC = MFMA16(w.l1, xh[kb][1], accC);
+#if F16_PREFETCH
+        w.h0 = n0; w.l0 = m0; w.h1 = n1; w.l1 = m1;
+#endif
+        ++blk;
+#if F16_FENCE
+        __builtin_amdgcn_sched_barrier(0);   // keep the pipeline depth at one block (bounds the operand registers)
+#endif
+    }
+}
+
+__device__ __forceinline__ f32x16 rows16(const float* __restrict__ v, int m, int half) {
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(v + 32 * m + 8 * q + 4 * half);
+        o[4 * q + 0] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+// fp32 block (accumulator layout) -> the two k-steps of the next B operand, split hi / lo
+__device__ __forceinline__ void split16(const f32x16& v, half8 (&h)[2], half8 (&l)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const _Float16 hi = (_Float16)v[r];
+        const _Float16 lo = (_Float16)((v[r] - (float)hi) * DSN_LO_SCALE);
+        h[r >> 3][r & 7] = hi;
+        l[r >> 3][r & 7] = lo;
+    }
+}
+__device__ __forceinline__ f32x16 fold16(const f32x16& m, const f32x16& c) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaf(c[r], DSN_LO_INV, m[r]);
+    return v;
+}
+// relu + its bit pattern / mask application
+#if F16_RELU_ASM
+__device__ __forceinline__ uint32_t relu_bits16(f32x16& a) {
+    uint32_t m = 0;
+#define DSN_RB(R) { const float v = fmaxf(a[R], 0.0f); m = (dsn_nonzero_bit(v) << R) | m; a[R] = v; }
+    DSN_FOR16(DSN_RB)
+#undef DSN_RB
+    return m;
+}
+__device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
+#define DSN_MK(R) a[R] = dsn_keep_if_bit<R>(a[R], m);
+    DSN_FOR16(DSN_MK)
+#undef DSN_MK
+}
+#else
+__device__ __forceinline__ uint32_t relu_bits16(f32x16& a) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool pos = a[r] > 0.0f;
+        m |= pos ? (1u << r) : 0u;
+        a[r] = pos ? a[r] : 0.0f;
+    }
+    return m;
+}
+__device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = ((m >> r) & 1u) ? a[r] : 0.0f;
+}
+#endif
+
+// 256 -> 256 forward layer
+__device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const float* __restrict__ bias,
+                                            const half8 (&xh)[8][2], const half8 (&xl)[8][2], half8 (&yh)[8][2],
+                                            half8 (&yl)[8][2], uint32_t (&mk)[4]) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = rows16(bias, m, half), aC = zero16();
+        dense16<8>(w, blk, lane, xh, xl, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        const uint32_t bits = relu_bits16(v);
+        if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
+        split16(v, yh[m], yl[m]);
+    }
+}
+// 256 -> 256 reverse layer
+__device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const half8 (&xh)[8][2],
+                                            const half8 (&xl)[8][2], half8 (&yh)[8][2], half8 (&yl)[8][2],
+                                            const uint32_t (&mk)[4]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8>(w, blk, lane, xh, xl, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        split16(v, yh[m], yl[m]);
+    }
+}
+
+__global__ void __launch_bounds__(F16_THREADS, 1)
+k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
+          int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
+          float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    if ((int64_t)blockIdx.x * 128 >= count) return;   // block-uniform: the barriers below need all 4 waves
+    int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool valid = slot < count;
+    if (!valid) slot = count - 1;
+    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
+    const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 1024 + lane * 16;
+    w.ring = ring;
+    w.wave = wave;
+    w16_begin(w, lane);
+    int blk = 0;
+
+    // positional encoding (fp32, accurate sincos) -> split k-steps; same slot map as k_field
+    half8 ph[2][2], pl[2][2];
+    {
+        f32x16 pe[2];
+#pragma unroll
+        for (int t = 0; t < 30; ++t) {
+            float s, c;
+#if F16_SINCOS_OCML
+            sincosf(xa[t % 3] * (float)(1 << (t / 3)), &s, &c);
+#else
+            dsn_sincos(xa[t % 3] * (float)(1 << (t / 3)), s, c);
+#endif
+            pe[t >> 4][t & 15] = half ? c : s;
+        }
+        pe[1][14] = half ? xa[1] : xa[0];
+        pe[1][15] = half ? 0.0f : xa[2];
+        split16(pe[0], ph[0], pl[0]);
+        split16(pe[1], ph[1], pl[1]);
+    }
+
+    uint32_t mk[7][4];
+    half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
+
+    // stage1.0
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = rows16(fs->bias0, m, half), aC = zero16();
+        dense16<2>(w, blk, lane, ph, pl, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        const uint32_t bits = relu_bits16(v);
+        if (m & 1) mk[0][m >> 1] |= bits << 16; else mk[0][m >> 1] = bits;
+        split16(v, ah[m], al[m]);
+    }
+    layer16_fwd(w, blk, lane, packed + OFF_B1 + 0 * 256, ah, al, bh, bl, mk[1]);
+    layer16_fwd(w, blk, lane, packed + OFF_B1 + 1 * 256, bh, bl, ah, al, mk[2]);
+    layer16_fwd(w, blk, lane, packed + OFF_B1 + 2 * 256, ah, al, bh, bl, mk[3]);
+    // stage2.0 : [h, pe] -> 256
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = rows16(packed + OFF_B1 + 3 * 256, m, half), aC = zero16();
+        dense16<8>(w, blk, lane, bh, bl, aM, aC);
+        dense16<2>(w, blk, lane, ph, pl, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        const uint32_t bits = relu_bits16(v);
+        if (m & 1) mk[4][m >> 1] |= bits << 16; else mk[4][m >> 1] = bits;
+        split16(v, ah[m], al[m]);
+    }
+    layer16_fwd(w, blk, lane, packed + OFF_B1 + 4 * 256, ah, al, bh, bl, mk[5]);
+    // stage2.4 with the density head and the seed of the reverse pass fused into its epilogue
+    float sg_part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = rows16(packed + OFF_B1 + 5 * 256, m, half), aC = zero16();
+        dense16<8>(w, blk, lane, bh, bl, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        const uint32_t bits = relu_bits16(v);
+        if (m & 1) mk[6][m >> 1] |= bits << 16; else mk[6][m >> 1] = bits;
+        const f32x16 wd = rows16(packed + OFF_WDEN, m, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
+        split16(v, ah[m], al[m]);
+    }
+    sg_part += __shfl_xor(sg_part, 32);
+    if (valid && half == 0) sigma[pt] = sg_part + packed[OFF_SCAL + 0];
+    // rgb_net: 256 -> 128 -> relu -> 3 (second layer as per-lane dots in the epilogue)
+    {
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x16 aM = rows16(packed + OFF_BRGB1, m, half), aC = zero16();
+            dense16<8>(w, blk, lane, ah, al, aM, aC);
+            const f32x16 v = fold16(aM, aC);
+            const f32x16 w0 = rows16(packed + OFF_WRGB3 + 0 * 128, m, half);
+            const f32x16 w1 = rows16(packed + OFF_WRGB3 + 1 * 128, m, half);
+            const f32x16 w2 = rows16(packed + OFF_WRGB3 + 2 * 128, m, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = fmaxf(v[r], 0.0f);
+                e0 = fmaf(w0[r], x, e0); e1 = fmaf(w1[r], x, e1); e2 = fmaf(w2[r], x, e2);
+            }
+        }
+        e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32); e2 += __shfl_xor(e2, 32);
+        if (valid && half == 0) {
+            essence[3 * pt + 0] = e0 + packed[OFF_SCAL + 1];
+            essence[3 * pt + 1] = e1 + packed[OFF_SCAL + 2];
+            essence[3 * pt + 2] = e2 + packed[OFF_SCAL + 3];
+        }
+    }
+
+    // ---- reverse pass on g / 64: seed = W_den masked by relu(stage2.4)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 g = rows16(packed + OFF_WDEN, m, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] *= F16_GSCALE;
+        mask16(g, (mk[6][m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        split16(g, ah[m], al[m]);
+    }
+    layer16_bwd(w, blk, lane, ah, al, bh, bl, mk[5]);
+    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[4]);
+    // stage2.0^T : 256 -> [256 h | 64 pe]
+    f32x16 dpe[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        f32x16 v = fold16(aM, aC);
+        mask16(v, (mk[3][m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        split16(v, bh[m], bl[m]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        dpe[b] = fold16(aM, aC);
+    }
+    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[2]);
+    layer16_bwd(w, blk, lane, ah, al, bh, bl, mk[1]);
+    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[0]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        const f32x16 v = fold16(aM, aC);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpe[b][r] += v[r];
+    }
+
+    // encoding backward (each lane re-derives its own sin / cos: both are needed for the derivative)
+    {
+        float g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 30; ++t) {
+            const int j = t / 3, a = t % 3;
+            float s, c;
+#if F16_SINCOS_OCML
+            sincosf(xa[a] * (float)(1 << j), &s, &c);
+#else
+            dsn_sincos(xa[a] * (float)(1 << j), s, c);
+#endif
+            const float d = dpe[t >> 4][t & 15];
+            const float term = (d * (half ? s : c)) * (float)(1 << j);
+            g[a] += half ? -term : term;
+        }
+        const float i30 = dpe[1][14], i31 = dpe[1][15];
+        if (half) g[1] += i30; else { g[0] += i30; g[2] += i31; }
+        g[0] += __shfl_xor(g[0], 32); g[1] += __shfl_xor(g[1], 32); g[2] += __shfl_xor(g[2], 32);
+        if (valid && half == 0) {
+            grad[3 * pt] = g[0] * F16_GUNSCALE; grad[3 * pt + 1] = g[1] * F16_GUNSCALE; grad[3 * pt + 2] = g[2] * F16_GUNSCALE;
+        }
+    }
+}
+
+void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                        const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                        float* grad, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_field16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, active_list,
+                       active_count, sigma, essence, grad);
+}

@@ -28,6 +28,9 @@ void dsn_launch_pack_params(const float* const* params33_dev_array, float* packe
 void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                       const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                       float* grad, hipStream_t st);
+void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                        const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                        float* grad, hipStream_t st);
 void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                       const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                       int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);

@@ -87,7 +87,7 @@ DSN_EXPORT int dsn_warp(const void* scene, int V, int F, const float* pts, const
  * grad = d sigma / d x_c [N,3].  If active_list != NULL only the listed points (count read from
  * active_count on the device) are evaluated and written; the rest are left untouched. */
 DSN_EXPORT int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
-              const int32_t* active_count, float* sigma, float* essence, float* grad, void* stream);
+              const int32_t* active_count, float* sigma, float* essence, float* grad, int flags, void* stream);
 
 /* model/spacenet.py:278-298 normal_local2world + :254-265 + :174-188 LightingMLP.forward.
  * x_w = world sample points [N,3], ray_d [N/S,3]; outputs face_idx_canon [N], n_w [N,3],
@@ -111,6 +111,10 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
 /* nearest-face search by exhaustive scan instead of the exact cell-candidate lists (same result by
  * construction; kept as the on-device cross-check of the lists).  Valid for dsn_warp, dsn_shade, dsn_render_rays. */
 #define DSN_NN_EXHAUSTIVE 2
+/* evaluate the field with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain) instead of the
+ * default split-fp16 scheme (3 x v_mfma_f32_32x32x16_f16 on hi/lo operand halves: fp32-equivalent accuracy at
+ * 5.3x fewer matrix cycles).  Valid for dsn_field and dsn_render_rays. */
+#define DSN_FIELD_FP32 4
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,

@@ -121,7 +121,8 @@ def test_module_forward_matches_reference():
     # colour goes through normalize(grad sigma): per point, with the same small outlier budget as the gradient
     assert np.median(dc) < 1e-6 and np.mean(dc > 1e-4) < 5e-3, (np.median(dc), np.mean(dc > 1e-4), dc.max())
     den2 = r.net(pos, rays, int(g["frame"]), b, density_only=True)
-    assert torch.equal(den2, den)
+    # density-only queries run the exact-fp32 kernel, the full forward the split-fp16 one: equal to rounding
+    assert float((den2 - den).abs().max()) < 3e-5
     # query_volume (utils/visualizer.py:47-66's call)
     q = r.query_volume(torch.from_numpy(g["x_c"])[None], torch.tensor([int(g["frame"])]),
                        torch.from_numpy(g["transparent"])[None], b)

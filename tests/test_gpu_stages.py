@@ -79,12 +79,15 @@ def test_warp(ctx, name, exhaustive):
     assert np.array_equal(lst, np.nonzero(~g["transparent"])[0])
 
 
+@pytest.mark.parametrize("fp32", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_field(ctx, name):
+def test_field(ctx, name, fp32):
+    """fp32=False: default split-fp16 MFMA kernel (k_field16); fp32=True: exact-fp32 MFMA kernel (k_field).
+    Both must meet the same bounds against the reference."""
     g = load(name)
     dev = ctx["dev"]
     sc = scene_for(ctx, g, name)
-    sig, ess, gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev))
+    sig, ess, gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=fp32)
     sig, ess, gr = sig.cpu().numpy(), ess.cpu().numpy(), gr.cpu().numpy()
     # vs the reference's own float32 outputs (north_star: 1e-4 abs on sigma / RGB)
     assert maxdiff(sig, g["sigma"]) < 1e-4
@@ -105,8 +108,9 @@ def test_field(ctx, name):
     assert maxdiff(sig, osig) < 1e-4 and maxdiff(ess, oess) < 1e-5
 
 
+@pytest.mark.parametrize("fp32", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_field_active_list(ctx, name):
+def test_field_active_list(ctx, name, fp32):
     """compacted evaluation == dense evaluation on the listed points, untouched elsewhere"""
     g = load(name)
     dev = ctx["dev"]
@@ -118,8 +122,8 @@ def test_field_active_list(ctx, name):
     lst[:len(act)] = T(act, dev)
     cnt = torch.zeros(64, dtype=torch.int32, device=dev)
     cnt[0] = len(act)
-    d_sig, d_ess, d_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev))
-    a_sig, a_ess, a_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), active=(lst, cnt))
+    d_sig, d_ess, d_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=fp32)
+    a_sig, a_ess, a_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), active=(lst, cnt), fp32=fp32)
     m = torch.zeros_like(d_sig, dtype=torch.bool)
     m[T(act.astype(np.int64), dev)] = True
     assert torch.equal(a_sig[m], d_sig[m]) and torch.equal(a_ess[m], d_ess[m]) and torch.equal(a_gr[m], d_gr[m])
@@ -184,3 +188,17 @@ def test_lists_equal_exhaustive_on_random_points(ctx):
     sub = pts[::97]
     idx = O.nearest_face(sub, O.centroids(g["xyz"], g["faces"]))
     assert np.array_equal(b["face_idx"].cpu().numpy()[::97], idx)
+
+
+def test_split_fp16_matches_fp32_kernel(ctx):
+    """the two field kernels agree far inside the parity tolerance on every active point of the full body"""
+    g = load("full_eval")
+    dev = ctx["dev"]
+    sc = scene_for(ctx, g, "full_eval")
+    a = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=False)
+    b = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=True)
+    assert float((a[0] - b[0]).abs().max()) < 3e-5
+    assert float((a[1] - b[1]).abs().max()) < 3e-6
+    gn = b[2].norm(dim=-1).clamp_min(1.0)
+    rel = (a[2] - b[2]).norm(dim=-1) / gn
+    assert float(rel.median()) < 2e-6 and float((rel > 1e-4).float().mean()) < 2e-3
