@@ -36,8 +36,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_FENCE
 #define F16_FENCE 0           // sched_barrier after every block
 #endif
+#ifndef F16_SGB
+#define F16_SGB 1             // sched_group_barrier interleave (1 MFMA : 4 VALU) inside every block + fence per block
+#endif
 #ifndef F16_PREFETCH
-#define F16_PREFETCH 0        // explicit one-block-ahead LDS operand reads
+#define F16_PREFETCH 1        // explicit one-block-ahead LDS operand reads
 #endif
 
 #define F16_THREADS 256
@@ -50,24 +53,33 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 struct W16 {                 // weight stream state of one wave
     const char* g;           // this lane's source: stream base + wave * 1024 + lane * 16
     char* ring;              // LDS ring base
+    unsigned ring_off;       // its LDS byte address (for M0)
     int wave;
     half8 h0, l0, h1, l1;    // the CURRENT block's operands: (hi, lo) for k-step 0 and 1
 };
 
+// LDS-DMA of 1 KB (64 lanes x 16 B) issued through inline asm: the compiler-visible builtin makes hipcc put
+// s_waitcnt vmcnt(0) in front of the next ds_read (it cannot prove the ring slots differ), which serialises the
+// prefetch.  M0 = wave-uniform LDS byte address of the destination; saved / restored around the statement
+// (cdna_hip_programming.md 5.7).  Completion is waited for by w16_boundary's own vmcnt(0) + barrier.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 // issue the loads of chunk c (8 blocks) into its ring slots: this wave moves quarter `wave` of every block
 __device__ __forceinline__ void w16_stage(const W16& w, int c) {
 #pragma unroll
     for (int i = 0; i < F16_CHUNK; ++i) {
         const int b = c * F16_CHUNK + i;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w.g + (size_t)b * 4096),
-                                         (__attribute__((address_space(3))) void*)(w.ring + (b & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024),
-                                         16, 0, 0);
+        glds16(w.g + (size_t)b * 4096, w.ring_off + (b & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024);
     }
 }
 // chunk boundary in front of block b (b % 8 == 0): after the barrier chunk b/8 has landed for everyone and chunk
 // b/8 - 1 has been read by everyone (its last block is already in registers) -> its slots take chunk b/8 + 1
 __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
-    __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) first: this wave's quarters of chunk b/8 are in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of chunk b/8 have landed in LDS
+    __syncthreads();
     const int c = b / F16_CHUNK;
     if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
 }
@@ -86,9 +98,11 @@ __device__ __forceinline__ void w16_begin(W16& w, int lane) {
 
 // (accM, accC) += W[32 rows][32*KB k] * (xh, xl): consumes KB blocks starting at stream block `blk`.
 // One-block-ahead software pipeline: the LDS reads of block b+1 are issued before the 6 MFMAs of block b.
-template <int KB>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int KB, class Hook = NoHook>
 __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], const half8 (&xl)[KB][2],
-                                        f32x16& accM, f32x16& accC) {
+                                        f32x16& accM, f32x16& accC, Hook&& hook = NoHook()) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #if F16_PREFETCH
@@ -109,10 +123,21 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
         accM = MFMA16(w.h1, xh[kb][1], accM);
         accC = MFMA16(w.h1, xl[kb][1], accC);
         accC = MFMA16(w.l1, xh[kb][1], accC);
+        hook(kb);   // independent VALU work (the previous output block's epilogue slice) issues under these MFMAs
 #if F16_PREFETCH
         w.h0 = n0; w.l0 = m0; w.h1 = n1; w.l1 = m1;
 #endif
         ++blk;
+#if F16_SGB
+        // pin the issue order inside this block: MFMA, 4 VALU (epilogue slice of the previous output block), MFMA, ...
+        // (hipcc otherwise clusters all MFMAs of a chunk and leaves the VALU work as an unoverlapped tail)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #if F16_FENCE
         __builtin_amdgcn_sched_barrier(0);   // keep the pipeline depth at one block (bounds the operand registers)
 #endif
@@ -181,40 +206,83 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 }
 #endif
 
-// 256 -> 256 forward layer
+// Deferred epilogue, two accumulator registers at a time.  With one wave per SIMD nothing else can cover the VALU
+// work of an epilogue (fold, relu / mask, hi-lo split, pack: ~12 instructions per element), so the epilogue of output
+// block m-1 is cut into 8 slices of two elements and slice kb is issued right behind the MFMAs of block (m, kb):
+// the matrix pipe stays busy while the VALU retires the previous block.
+template <bool FWD>
+__device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
+                                          half8 (&yh)[2], half8 (&yl)[2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * kb + e;
+        float v = fmaf(pC[r], DSN_LO_INV, pM[r]);
+        if (FWD) {
+            const bool pos = v > 0.0f;
+            bits |= pos ? (1u << r) : 0u;
+            v = pos ? v : 0.0f;
+        } else {
+            v = ((mword >> r) & 1u) ? v : 0.0f;
+        }
+        const _Float16 hi = (_Float16)v;
+        yh[r >> 3][r & 7] = hi;
+        yl[r >> 3][r & 7] = (_Float16)((v - (float)hi) * DSN_LO_SCALE);
+    }
+}
+
+// 256 -> 256 forward layer (software-pipelined epilogues)
 __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const float* __restrict__ bias,
                                             const half8 (&xh)[8][2], const half8 (&xl)[8][2], half8 (&yh)[8][2],
                                             half8 (&yl)[8][2], uint32_t (&mk)[4]) {
     const int half = lane >> 5;
+    f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(bias, m, half), aC = zero16();
-        dense16<8>(w, blk, lane, xh, xl, aM, aC);
-        f32x16 v = fold16(aM, aC);
-        const uint32_t bits = relu_bits16(v);
-        if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        split16(v, yh[m], yl[m]);
+        uint32_t bits = 0;
+        if (m == 0) dense16<8>(w, blk, lane, xh, xl, aM, aC);
+        else dense16<8>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1]); });
+        if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= bits << 16; else mk[(m - 1) >> 1] = bits; }
+        pM = aM; pC = aC;
+    }
+    {   // last block: nothing left to hide it under
+        uint32_t bits = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true>(pM, pC, kb, 0u, bits, yh[7], yl[7]);
+        mk[3] |= bits << 16;
     }
 }
 // 256 -> 256 reverse layer
 __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const half8 (&xh)[8][2],
                                             const half8 (&xl)[8][2], half8 (&yh)[8][2], half8 (&yl)[8][2],
                                             const uint32_t (&mk)[4]) {
+    f32x16 pM = zero16(), pC = zero16();
+    uint32_t dummy = 0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
-        dense16<8>(w, blk, lane, xh, xl, aM, aC);
-        f32x16 v = fold16(aM, aC);
-        mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
-        split16(v, yh[m], yl[m]);
+        const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
+        if (m == 0) dense16<8>(w, blk, lane, xh, xl, aM, aC);
+        else dense16<8>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1]); });
+        pM = aM; pC = aC;
     }
+    const uint32_t mw = (mk[3] >> 16) & 0xffffu;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false>(pM, pC, kb, mw, dummy, yh[7], yl[7]);
 }
 
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
           int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
           float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
+    // LDS map: weight ring 64 KB | relu masks 7 layers x 4 words x 256 threads = 28 KB | PE operands 8 x half8 x 256 = 32 KB
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
+    __shared__ uint32_t s_mask[7][4][F16_THREADS];
+    // every small vector the epilogues need (no compiler-visible global load may sit in the steady state: its
+    // vmcnt wait would drain the LDS-DMA queue): [bias0 256 | OFF_B1.. 2304 (6 biases, rgb bias, W_den, W_rgb3) | scalars 8]
+    __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
+    __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
+    const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -226,9 +294,18 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
 
+    for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
+        s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
+    const float* const v_bias0 = s_vec;
+    const float* const v_b1 = s_vec + 256;                                  // + l * 256
+    const float* const v_brgb1 = s_vec + 256 + (OFF_BRGB1 - OFF_B1);
+    const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
+    const float* const v_wrgb3 = s_vec + 256 + (OFF_WRGB3 - OFF_B1);
+    const float* const v_scal = s_vec + 2560;
     W16 w;
     w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 1024 + lane * 16;
     w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
     w16_begin(w, lane);
     int blk = 0;
@@ -251,63 +328,76 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         pe[1][15] = half ? 0.0f : xa[2];
         split16(pe[0], ph[0], pl[0]);
         split16(pe[1], ph[1], pl[1]);
+        s_pe[0][tid] = ph[0][0]; s_pe[1][tid] = ph[0][1]; s_pe[2][tid] = ph[1][0]; s_pe[3][tid] = ph[1][1];
+        s_pe[4][tid] = pl[0][0]; s_pe[5][tid] = pl[0][1]; s_pe[6][tid] = pl[1][0]; s_pe[7][tid] = pl[1][1];
     }
 
-    uint32_t mk[7][4];
+    // relu masks live in LDS between the forward and the reverse pass (28 VGPRs otherwise); lane-private slots,
+    // so no barrier is needed around them
+#define MK_STORE(L, mk) { s_mask[L][0][tid] = mk[0]; s_mask[L][1][tid] = mk[1]; s_mask[L][2][tid] = mk[2]; s_mask[L][3][tid] = mk[3]; }
+#define MK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
+    uint32_t mk[4];
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
 
     // stage1.0
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        f32x16 aM = rows16(fs->bias0, m, half), aC = zero16();
+        f32x16 aM = rows16(v_bias0, m, half), aC = zero16();
         dense16<2>(w, blk, lane, ph, pl, aM, aC);
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
-        if (m & 1) mk[0][m >> 1] |= bits << 16; else mk[0][m >> 1] = bits;
+        if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         split16(v, ah[m], al[m]);
     }
-    layer16_fwd(w, blk, lane, packed + OFF_B1 + 0 * 256, ah, al, bh, bl, mk[1]);
-    layer16_fwd(w, blk, lane, packed + OFF_B1 + 1 * 256, bh, bl, ah, al, mk[2]);
-    layer16_fwd(w, blk, lane, packed + OFF_B1 + 2 * 256, ah, al, bh, bl, mk[3]);
+    MK_STORE(0, mk)
+    layer16_fwd(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk); MK_STORE(1, mk)
+    layer16_fwd(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk); MK_STORE(2, mk)
+    layer16_fwd(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk); MK_STORE(3, mk)
     // stage2.0 : [h, pe] -> 256
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        f32x16 aM = rows16(packed + OFF_B1 + 3 * 256, m, half), aC = zero16();
+        f32x16 aM = rows16(v_b1 + 3 * 256, m, half), aC = zero16();
         dense16<8>(w, blk, lane, bh, bl, aM, aC);
-        dense16<2>(w, blk, lane, ph, pl, aM, aC);
+        {   // encoding operands come back from LDS just for these two blocks
+            half8 qh[2][2], ql[2][2];
+            qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
+            ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
+            dense16<2>(w, blk, lane, qh, ql, aM, aC);
+        }
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
-        if (m & 1) mk[4][m >> 1] |= bits << 16; else mk[4][m >> 1] = bits;
+        if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         split16(v, ah[m], al[m]);
     }
-    layer16_fwd(w, blk, lane, packed + OFF_B1 + 4 * 256, ah, al, bh, bl, mk[5]);
+    MK_STORE(4, mk)
+    layer16_fwd(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk); MK_STORE(5, mk)
     // stage2.4 with the density head and the seed of the reverse pass fused into its epilogue
     float sg_part = 0.0f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        f32x16 aM = rows16(packed + OFF_B1 + 5 * 256, m, half), aC = zero16();
+        f32x16 aM = rows16(v_b1 + 5 * 256, m, half), aC = zero16();
         dense16<8>(w, blk, lane, bh, bl, aM, aC);
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
-        if (m & 1) mk[6][m >> 1] |= bits << 16; else mk[6][m >> 1] = bits;
-        const f32x16 wd = rows16(packed + OFF_WDEN, m, half);
+        if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
+        const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
         split16(v, ah[m], al[m]);
     }
     sg_part += __shfl_xor(sg_part, 32);
-    if (valid && half == 0) sigma[pt] = sg_part + packed[OFF_SCAL + 0];
+    if (valid && half == 0) sigma[pt] = sg_part + v_scal[0];
     // rgb_net: 256 -> 128 -> relu -> 3 (second layer as per-lane dots in the epilogue)
     {
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            f32x16 aM = rows16(packed + OFF_BRGB1, m, half), aC = zero16();
+            f32x16 aM = rows16(v_brgb1, m, half), aC = zero16();
             dense16<8>(w, blk, lane, ah, al, aM, aC);
             const f32x16 v = fold16(aM, aC);
-            const f32x16 w0 = rows16(packed + OFF_WRGB3 + 0 * 128, m, half);
-            const f32x16 w1 = rows16(packed + OFF_WRGB3 + 1 * 128, m, half);
-            const f32x16 w2 = rows16(packed + OFF_WRGB3 + 2 * 128, m, half);
+            const f32x16 w0 = rows16(v_wrgb3 + 0 * 128, m, half);
+            const f32x16 w1 = rows16(v_wrgb3 + 1 * 128, m, half);
+            const f32x16 w2 = rows16(v_wrgb3 + 2 * 128, m, half);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = fmaxf(v[r], 0.0f);
@@ -316,23 +406,24 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         }
         e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32); e2 += __shfl_xor(e2, 32);
         if (valid && half == 0) {
-            essence[3 * pt + 0] = e0 + packed[OFF_SCAL + 1];
-            essence[3 * pt + 1] = e1 + packed[OFF_SCAL + 2];
-            essence[3 * pt + 2] = e2 + packed[OFF_SCAL + 3];
+            essence[3 * pt + 0] = e0 + v_scal[1];
+            essence[3 * pt + 1] = e1 + v_scal[2];
+            essence[3 * pt + 2] = e2 + v_scal[3];
         }
     }
 
     // ---- reverse pass on g / 64: seed = W_den masked by relu(stage2.4)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        f32x16 g = rows16(packed + OFF_WDEN, m, half);
+        f32x16 g = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] *= F16_GSCALE;
-        mask16(g, (mk[6][m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        mask16(g, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
         split16(g, ah[m], al[m]);
     }
-    layer16_bwd(w, blk, lane, ah, al, bh, bl, mk[5]);
-    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[4]);
+    MK_LOAD(5, mk) layer16_bwd(w, blk, lane, ah, al, bh, bl, mk);
+    MK_LOAD(4, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
+    MK_LOAD(3, mk)
     // stage2.0^T : 256 -> [256 h | 64 pe]
     f32x16 dpe[2];
 #pragma unroll
@@ -340,7 +431,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 aM = zero16(), aC = zero16();
         dense16<8>(w, blk, lane, ah, al, aM, aC);
         f32x16 v = fold16(aM, aC);
-        mask16(v, (mk[3][m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
         split16(v, bh[m], bl[m]);
     }
 #pragma unroll
@@ -349,9 +440,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         dense16<8>(w, blk, lane, ah, al, aM, aC);
         dpe[b] = fold16(aM, aC);
     }
-    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[2]);
-    layer16_bwd(w, blk, lane, ah, al, bh, bl, mk[1]);
-    layer16_bwd(w, blk, lane, bh, bl, ah, al, mk[0]);
+    MK_LOAD(2, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
+    MK_LOAD(1, mk) layer16_bwd(w, blk, lane, ah, al, bh, bl, mk);
+    MK_LOAD(0, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x16 aM = zero16(), aC = zero16();
