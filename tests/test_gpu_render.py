@@ -189,3 +189,51 @@ def test_full_size_properties():
     got = out["color"][torch.from_numpy(sel).cuda()].cpu().numpy()
     assert np.array_equal(out["z_vals"][torch.from_numpy(sel).cuda()].cpu().numpy(), e["z_vals"])
     assert maxdiff(got, e["color"]) < 1e-4
+
+
+@pytest.mark.parametrize("R,S", [(37, 128), (1, 64), (130, 32), (65, 200)])
+def test_ragged_shapes_match_oracle(R, S):
+    """ragged ray counts (not multiples of the 256-thread / 128-point tiles), S = 128 (BASELINE config 4) and an S that is
+    not a multiple of the wavefront width, against the oracle"""
+    import dsnerf_amd
+    from dsnerf_amd import synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(96, 96, xyz, fit_box=True)
+    sel = np.linspace(0, 96 * 96 - 1, R).astype(np.int64)
+    g = {"canonical_vertex": canon, "faces": faces, "S": S}
+    r = make_renderer(g)
+    r.eval()
+    poses = synth.make_poses()
+    batch = {"ray_o": torch.from_numpy(rays["ray_o"][sel])[None], "ray_d": torch.from_numpy(rays["ray_d"][sel])[None],
+             "near": torch.from_numpy(rays["near"][sel].copy())[None], "far": torch.from_numpy(rays["far"][sel].copy())[None],
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(poses)[None],
+             "Th": torch.tensor([0.2, -0.1, 1.0]).reshape(1, 1, 3), "frame": torch.tensor([5])}
+    out = {k: v.cpu().numpy() for k, v in r.render(batch)["coarse"].items()}
+    sd = state()
+    e = O.render(rays["ray_o"][sel], rays["ray_d"][sel], rays["near"][sel], rays["far"][sel], S, xyz, canon, faces,
+                 O.Params(sd), poses, sd["nerf.embedding.weight"][5], t_vals=torch.linspace(0.0, 1.0, steps=S).numpy())
+    assert np.array_equal(out["z_vals"], e["z_vals"])
+    assert maxdiff(out["color"], e["color"]) < 1e-4
+    assert maxdiff(out["acc_map"], e["acc_map"]) < 1e-4 and maxdiff(out["weights"], e["weights"]) < 1e-4
+
+
+def test_all_transparent_frame():
+    """rays that never come near the body: empty active list, networks not evaluated, zero image, NaN disparity"""
+    import dsnerf_amd
+    from dsnerf_amd import synth
+    canon, faces = synth.make_small_body()
+    xyz = synth.pose_body(canon)
+    g = {"canonical_vertex": canon, "faces": faces, "S": 16}
+    r = make_renderer(g)
+    r.eval()
+    R = 70
+    o = np.tile(np.array([[5.0, 5.0, 5.0]], np.float32), (R, 1))
+    d = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (R, 1))
+    batch = {"ray_o": torch.from_numpy(o)[None], "ray_d": torch.from_numpy(d)[None],
+             "near": torch.full((1, R), 1.0), "far": torch.full((1, R), 2.0),
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(synth.make_poses())[None],
+             "Th": torch.zeros(1, 1, 3), "frame": torch.tensor([0])}
+    out = r.render(batch)["coarse"]
+    assert float(out["color"].abs().max()) == 0.0 and float(out["acc_map"].abs().max()) == 0.0
+    assert bool(torch.isnan(out["disp_map"]).all())
