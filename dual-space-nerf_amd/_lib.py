@@ -33,7 +33,7 @@ EXPORTS = [
     "dsn_abi_version", "dsn_last_error", "dsn_packed_param_bytes", "dsn_pack_params",
     "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_shade", "dsn_composite",
-    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_debug_nn_stats",
+    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -272,3 +272,22 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                  _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
            "dsn_render_rays")
     return out
+
+
+def camera_rays(K, R, T, bounds, H, W, device=None):
+    """Whole-image rays + box near/far on the device (utils/rays_utils.py:16-30, :63-97, :176-184).
+    K, R [3,3], T [3] or [3,1], bounds [2,3]: anything convertible to float64 tensors.  Returns
+    (ray_o [H*W,3], ray_d [H*W,3], near [H*W], far [H*W], mask_at_box [H*W] bool), all on the device, uncompacted."""
+    require_gpu()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    f64 = lambda a: torch.as_tensor(a, dtype=torch.float64).reshape(-1).to(dev).contiguous()
+    K, R, T, bounds = f64(K), f64(R), f64(T), f64(bounds)
+    n = H * W
+    ray_o = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ray_d = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    near = torch.empty(n, dtype=torch.float32, device=dev)
+    far = torch.empty(n, dtype=torch.float32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    _check(lib().dsn_camera_rays(_ptr(K), _ptr(R), _ptr(T), _ptr(bounds), H, W, _ptr(ray_o), _ptr(ray_d), _ptr(near),
+                                 _ptr(far), _ptr(mask), _stream()), "dsn_camera_rays")
+    return ray_o, ray_d, near, far, mask.bool()

@@ -172,6 +172,15 @@ int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, voi
     return 0;
 }
 
+// utils/rays_utils.py:16-30 get_rays + :63-97 get_near_far, whole-image path (:176-184)
+int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
+                    float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream) {
+    DSN_REQUIRE(K3x3 && R3x3 && T3 && bounds2x3 && ray_o && ray_d && near && far && mask_at_box, "dsn_camera_rays: null argument");
+    DSN_REQUIRE(H > 0 && W > 0, "dsn_camera_rays: empty image");
+    dsn_launch_camera_rays(K3x3, R3x3, T3, bounds2x3, H, W, ray_o, ray_d, near, far, mask_at_box, (hipStream_t)stream);
+    return dsn_check_launch("dsn_camera_rays");
+}
+
 // workspace carve for the fused path
 struct DsnWorkspace {
     int32_t* count;       // [64] (first word = number of active samples)

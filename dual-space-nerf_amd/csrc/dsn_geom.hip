@@ -445,3 +445,71 @@ void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t
     hipLaunchKernelGGL(k_composite, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
                        noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map);
 }
+
+// ---------------------------------------------------------------------------------------------
+// "next" row f-2: camera rays + AABB near/far on the device (whole-image path of
+// utils/rays_utils.py:16-30 get_rays, :63-97 get_near_far as used by my_sample_ray(nrays<=0), :176-184).
+// The reference does this in float64 numpy on the CPU and casts to float32: rays are produced in double,
+// ROUNDED to float32 (:177-178), and the slab intersections are evaluated in double FROM THE ROUNDED rays (:179);
+// the same order is kept here so that results are the reference's to the last float32 bit (up to BLAS summation order
+// in the 1e-16 range).  One thread per pixel; K^-1 by the adjugate.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_camera_rays(const double* __restrict__ K, const double* __restrict__ Rm,
+                                                      const double* __restrict__ T, const double* __restrict__ bounds,
+                                                      int H, int W, float* __restrict__ ray_o, float* __restrict__ ray_d,
+                                                      float* __restrict__ near, float* __restrict__ far,
+                                                      uint8_t* __restrict__ mask_at_box) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const double k00 = K[0], k01 = K[1], k02 = K[2], k10 = K[3], k11 = K[4], k12 = K[5], k20 = K[6], k21 = K[7], k22 = K[8];
+    const double det = k00 * (k11 * k22 - k12 * k21) - k01 * (k10 * k22 - k12 * k20) + k02 * (k10 * k21 - k11 * k20);
+    const double id = 1.0 / det;
+    const double Ki[9] = {(k11 * k22 - k12 * k21) * id, (k02 * k21 - k01 * k22) * id, (k01 * k12 - k02 * k11) * id,
+                          (k12 * k20 - k10 * k22) * id, (k00 * k22 - k02 * k20) * id, (k02 * k10 - k00 * k12) * id,
+                          (k10 * k21 - k11 * k20) * id, (k01 * k20 - k00 * k21) * id, (k00 * k11 - k01 * k10) * id};
+    // rays_o = -R^T T
+    double o[3];
+    for (int c = 0; c < 3; ++c) o[c] = -(Rm[0 * 3 + c] * T[0] + Rm[1 * 3 + c] * T[1] + Rm[2 * 3 + c] * T[2]);
+    const double i = (double)(float)(p % W), j = (double)(float)(p / W);
+    double pc[3], pw[3];
+    for (int c = 0; c < 3; ++c) pc[c] = i * Ki[c * 3 + 0] + j * Ki[c * 3 + 1] + Ki[c * 3 + 2];   // xy1 . Kinv^T
+    for (int c = 0; c < 3; ++c)
+        pw[c] = (pc[0] - T[0]) * Rm[0 * 3 + c] + (pc[1] - T[1]) * Rm[1 * 3 + c] + (pc[2] - T[2]) * Rm[2 * 3 + c];   // (pc - T) . R
+    float of[3], df[3];
+    for (int c = 0; c < 3; ++c) { of[c] = (float)o[c]; df[c] = (float)(pw[c] - o[c]); }
+    for (int c = 0; c < 3; ++c) { ray_o[3 * p + c] = of[c]; ray_d[3 * p + c] = df[c]; }
+    // get_near_far on the float32-rounded rays, in double
+    const double ro[3] = {(double)of[0], (double)of[1], (double)of[2]}, rd[3] = {(double)df[0], (double)df[1], (double)df[2]};
+    double b[2][3];
+    for (int c = 0; c < 3; ++c) { b[0][c] = bounds[c] + (-0.01); b[1][c] = bounds[3 + c] + 0.01; }
+    const double eps = 1e-6;
+    int hits = 0;
+    double dsel[2] = {0.0, 0.0};
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c) {   // plane order of the reference's reshape(-1, 6): min xyz, then max xyz
+            const double dint = (b[s][c] - ro[c]) / rd[c];
+            const double px = dint * rd[0] + ro[0], py = dint * rd[1] + ro[1], pz = dint * rd[2] + ro[2];
+            const bool in = (px >= b[0][0] - eps) && (px <= b[1][0] + eps) && (py >= b[0][1] - eps) && (py <= b[1][1] + eps) &&
+                            (pz >= b[0][2] - eps) && (pz <= b[1][2] + eps);
+            if (in) {
+                if (hits < 2) {
+                    const double ex = px - ro[0], ey = py - ro[1], ez = pz - ro[2];
+                    dsel[hits] = sqrt(ex * ex + ey * ey + ez * ez);
+                }
+                ++hits;
+            }
+        }
+    const bool m = hits == 2;   // "intersect exactly twice" (:86)
+    // np.linalg.norm on the float32 rays stays in float32 (:92): sqrt((x*x + y*y) + z*z), unfused
+    const double nr = (double)sqrtf((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);
+    const double d0 = dsel[0] / nr, d1 = dsel[1] / nr;
+    mask_at_box[p] = m ? 1 : 0;
+    near[p] = m ? (float)fmin(d0, d1) : 0.0f;
+    far[p] = m ? (float)fmax(d0, d1) : 0.0f;
+}
+
+void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
+                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st) {
+    hipLaunchKernelGGL(k_camera_rays, dim3((H * W + 255) / 256), dim3(256), 0, st, K, R, T, bounds, H, W, ray_o, ray_d,
+                       near, far, mask);
+}

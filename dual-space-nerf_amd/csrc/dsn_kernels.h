@@ -22,6 +22,8 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st);
+void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
+                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
 // dsn_field.hip
 void dsn_pack_params_host(const float* const* params33_host, float* packed_host);
 void dsn_launch_pack_params(const float* const* params33_dev_array, float* packed, hipStream_t st);

@@ -103,6 +103,14 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
                   const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                   float* acc_map, float* weights, float* depth_map, void* stream);
 
+/* ---- "next" row: the step in front of the path -------------------------------
+ * utils/rays_utils.py:16-30 get_rays + :63-97 get_near_far, as composed by my_sample_ray(nrays<=0) (:176-184):
+ * K, R [3,3], T [3], bounds [2,3] (min xyz; max xyz) are float64 DEVICE arrays (the reference's numpy dtype).
+ * Outputs for all H*W pixels (row-major): ray_o, ray_d [H*W,3], near, far [H*W] (0 where the ray does not cross the
+ * box exactly twice), mask_at_box [H*W].  The caller compacts with the mask like the reference does (:181-183). */
+DSN_EXPORT int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
+                    float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream);
+
 /* ---- fused path: can_render.py:137-168 Renderer.render on R rays --------------------------
  * flags: DSN_SKIP_TRANSPARENT evaluates the networks only on non-transparent samples (exact in
  * eval mode: their sigma is forced to 0 and their colour is multiplied by weight 0; must not be

@@ -187,3 +187,35 @@ def render(ray_o, ray_d, near, far, S, xyz, canon, faces, params: Params, poses,
                      C.c_int(xyz.shape[0]), C.c_int(faces.shape[0]), params.ptrs, _p(poses), _p(code8), _p(r), _p(rc),
                      _p(ls), _p(tv), _p(j), _p(n), _p(rgb), _p(disp), _p(acc), _p(w), _p(dep), _p(z), _p(raw))
     return dict(color=rgb, disp_map=disp, acc_map=acc, weights=w, depth_map=dep, z_vals=z, raw=raw, near=near, far=far)
+
+
+def camera_rays_np(K, R, T, bounds, H, W):
+    """numpy (float64) restatement of the reference's whole-image ray set-up: utils/rays_utils.py:16-30 get_rays, the
+    float32 cast of my_sample_ray (:177-178) and :63-97 get_near_far evaluated on the rounded rays.  Pinned by
+    tests/golden/camera_rays.npz (made from the reference's own functions).  Returns UNcompacted arrays + mask."""
+    K, R, T = np.asarray(K, np.float64), np.asarray(R, np.float64), np.asarray(T, np.float64).reshape(3)
+    o = -(R.T @ T)
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    xy1 = np.stack([ii, jj, np.ones_like(ii)], -1).reshape(-1, 3).astype(np.float64)
+    pw = (xy1 @ np.linalg.inv(K).T - T) @ R
+    ray_d = (pw - o).astype(np.float32)
+    ray_o = np.broadcast_to(o, pw.shape).astype(np.float32)
+    b = np.asarray(bounds, np.float64) + np.array([-0.01, 0.01])[:, None]
+    ro, rd = ray_o.astype(np.float64), ray_d.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dint = ((b[None] - ro[:, None]) / rd[:, None]).reshape(-1, 6)
+        pts = dint[..., None] * rd[:, None] + ro[:, None]
+    eps = 1e-6
+    inside = np.ones(pts.shape[:2], bool)
+    for c in range(3):
+        inside &= (pts[..., c] >= b[0, c] - eps) & (pts[..., c] <= b[1, c] + eps)
+    mask = inside.sum(-1) == 2
+    near = np.zeros(len(ro), np.float32)
+    far = np.zeros(len(ro), np.float32)
+    sel = pts[mask][inside[mask]].reshape(-1, 2, 3)
+    nr = np.linalg.norm(ray_d[mask], axis=1)      # float32 norm: the reference passes float32 rays (:92), numpy keeps the dtype
+    d0 = np.linalg.norm(sel[:, 0] - ro[mask], axis=1) / nr
+    d1 = np.linalg.norm(sel[:, 1] - ro[mask], axis=1) / nr
+    near[mask] = np.minimum(d0, d1).astype(np.float32)
+    far[mask] = np.maximum(d0, d1).astype(np.float32)
+    return ray_o, ray_d, near, far, mask

@@ -202,3 +202,23 @@ def test_split_fp16_matches_fp32_kernel(ctx):
     gn = b[2].norm(dim=-1).clamp_min(1.0)
     rel = (a[2] - b[2]).norm(dim=-1) / gn
     assert float(rel.median()) < 2e-6 and float((rel > 1e-4).float().mean()) < 2e-3
+
+
+def test_camera_rays(ctx):
+    """device ray set-up (dsn_camera_rays) vs the reference's get_rays / get_near_far golden and the oracle"""
+    import os
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "camera_rays.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd, near, far, mask = ctx["lib"].camera_rays(g["K"], g["R"], g["T"], g["bounds"], H, W)
+    m = mask.cpu().numpy()
+    assert np.array_equal(m, g["mask_at_box"])
+    assert maxdiff(ro.cpu().numpy(), g["ray_o"]) <= 2.4e-7 and maxdiff(rd.cpu().numpy(), g["ray_d"]) <= 1.2e-7   # <= 1 ulp (inverse / summation order in float64)
+    assert np.mean(rd.cpu().numpy() != g["ray_d"]) < 0.01
+    assert maxdiff(near.cpu().numpy()[m], g["near"]) <= 2.4e-7 and maxdiff(far.cpu().numpy()[m], g["far"]) <= 4.8e-7
+    # at the frame size of the metric: same function against the oracle
+    K = np.array([[537.0, 0, 255.5], [0, 537.0, 255.5], [0, 0, 1.0]])
+    o = O.camera_rays_np(K, g["R"], g["T"], g["bounds"], 512, 512)
+    d = ctx["lib"].camera_rays(K, g["R"], g["T"], g["bounds"], 512, 512)
+    assert np.array_equal(d[4].cpu().numpy(), o[4])
+    assert maxdiff(d[1].cpu().numpy(), o[1]) <= 1.2e-7 and maxdiff(d[2].cpu().numpy(), o[2]) <= 4.8e-7

@@ -100,3 +100,12 @@ def test_reference_noise_floor_documented():
     g = load("full_eval")
     assert maxdiff(g["rgb_map"], g["rgb_map_f64"]) > 1e-3
     assert maxdiff(g["sigma"], g["sigma_f64"]) > 1e-2
+
+
+def test_camera_rays_restatement():
+    """get_rays + get_near_far (whole-image path) - numpy restatement vs the reference's own output"""
+    g = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "camera_rays.npz"))
+    ro, rd, near, far, mask = O.camera_rays_np(g["K"], g["R"], g["T"], g["bounds"], int(g["H"]), int(g["W"]))
+    assert np.array_equal(mask, g["mask_at_box"]) and 0 < mask.sum() < mask.size
+    assert np.array_equal(ro, g["ray_o"]) and np.array_equal(rd, g["ray_d"])
+    assert np.array_equal(near[mask], g["near"]) and np.array_equal(far[mask], g["far"])
