@@ -39,6 +39,7 @@ EXPORTS = [
 SKIP_TRANSPARENT = 1
 NN_EXHAUSTIVE = 2
 FIELD_FP32 = 4
+SAMPLE_UNIFORM = 8
 
 
 def lib():
@@ -199,7 +200,7 @@ def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=
     return sigma, ess, g
 
 
-def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None, exhaustive=False):
+def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None, exhaustive=False, fp32=False):
     x_c = x_c.reshape(-1, 3)
     N = x_c.shape[0]
     dev = scene.device
@@ -210,7 +211,7 @@ def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S,
     _check(lib().dsn_shade(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32),
                            _ptr(grad.reshape(-1, 3), torch.float32), _ptr(x_w.reshape(-1, 3), torch.float32),
                            _ptr(ray_d, torch.float32), _ptr(essence.reshape(-1, 3), torch.float32), C.c_int64(N), S,
-                           _ptr(lst), _ptr(cnt), _ptr(idx), _ptr(n_w), _ptr(col), NN_EXHAUSTIVE if exhaustive else 0,
+                           _ptr(lst), _ptr(cnt), _ptr(idx), _ptr(n_w), _ptr(col), (NN_EXHAUSTIVE if exhaustive else 0) | (FIELD_FP32 if fp32 else 0),
                            _stream()), "dsn_shade")
     return idx, n_w, col
 
@@ -245,7 +246,7 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False):
+                fp32=False, uniform=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -264,6 +265,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= NN_EXHAUSTIVE
     if fp32:
         flags |= FIELD_FP32
+    if uniform:
+        flags |= SAMPLE_UNIFORM
     buf = ws.get(R, S)
     _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
                                  _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,

@@ -195,10 +195,11 @@ class Renderer:
         self._set_frame(batch)
         self._frame_xyz_ptr = batch["xyz"].data_ptr()
         jitter, noise = self._draws(R, S)
-        if self.sample_points_mode != "GG":
-            raise NotImplementedError("fused path implements the shipped configs' sample_points_mode='GG'")
+        if self.sample_points_mode not in ("GG", "uniform"):
+            raise Exception("error")   # the reference fails on unknown modes too (get_sampling_points returns nothing)
         out = _lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o, d, near, far, S, self._t_vals(S),
-                               jitter, noise, skip_transparent=self.skip_transparent and not self.net.training)
+                               jitter, noise, skip_transparent=self.skip_transparent and not self.net.training,
+                               uniform=(self.sample_points_mode == "uniform"))
         if batch["near"].is_cuda:   # in-place semantics of the reference when the batch already lives on the device
             batch["near"][0].copy_(near)
             batch["far"][0].copy_(far)
@@ -222,7 +223,8 @@ class Renderer:
             outs.append(_lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o[i:j].contiguous(),
                                          d[i:j].contiguous(), n[i:j].contiguous(), f[i:j].contiguous(), S,
                                          self._t_vals(S), jitter, noise,
-                                         skip_transparent=self.skip_transparent and not self.net.training))
+                                         skip_transparent=self.skip_transparent and not self.net.training,
+                                         uniform=(self.sample_points_mode == "uniform")))
         coarse = {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
         return coarse, {}
 

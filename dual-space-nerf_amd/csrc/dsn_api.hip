@@ -141,8 +141,12 @@ int dsn_shade(const void* scene, int V, int F, const void* packed, const float* 
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
     dsn_launch_normal(s, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, (flags & DSN_NN_EXHAUSTIVE) != 0, st);
-    dsn_launch_light((const float*)packed, s.frame, n_w, x_w, nullptr, ray_d, nullptr, essence, N, S, active_list,
-                     active_count, colour, st);
+    if (flags & DSN_FIELD_FP32)
+        dsn_launch_light((const float*)packed, s.frame, n_w, x_w, nullptr, ray_d, nullptr, essence, N, S, active_list,
+                         active_count, colour, st);
+    else
+        dsn_launch_light16((const float*)packed, s.frame, n_w, x_w, nullptr, ray_d, nullptr, essence, N, S, active_list,
+                           active_count, colour, st);
     return dsn_check_launch("dsn_shade");
 }
 
@@ -233,7 +237,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     DsnWorkspace w = dsn_carve(workspace, R, S);
     const int64_t N = (int64_t)R * S;
     float* z = out_z ? out_z : w.z;
-    dsn_launch_sample_gg(s.xyz, V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     int32_t* list = skip ? w.active : nullptr;
     int32_t* cnt = skip ? w.count : nullptr;
     if (skip) {
@@ -250,7 +254,10 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     else
         dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
-    dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
+    if (flags & DSN_FIELD_FP32)
+        dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
+    else
+        dsn_launch_light16((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st);
     return dsn_check_launch("dsn_render_rays");

@@ -241,8 +241,9 @@ enum {
     // ---- split-fp16 images of the same 872-block stream (csrc/dsn_field16.hip): 4 KB per block, stored as
     // [t(2)][part(hi,lo)][lane(64)][8 halves]; block b of the fp32 stream <-> block b here.
     OFF16_BASE = (OFF_END32 + 63) & ~63,          // float offset, 256-byte aligned
-    DSN_STREAM_BLOCKS = OFF_LT0 / DSN_BLK,        // 872: stage1.0 ... stage1.0^T in consumption order
-    OFF_END = OFF16_BASE + DSN_STREAM_BLOCKS * DSN_BLK
+    DSN_STREAM_BLOCKS = OFF_LT0 / DSN_BLK,        // 872: stage1.0 ... stage1.0^T in consumption order (k_field16)
+    DSN_STREAM_BLOCKS_ALL = OFF_B1 / DSN_BLK,     // 892: + lights_encoding.0 (4) and .2 (16) for k_light16
+    OFF_END = OFF16_BASE + DSN_STREAM_BLOCKS_ALL * DSN_BLK
 };
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
 #define DSN_LO_INV (1.0f / 4096.0f)

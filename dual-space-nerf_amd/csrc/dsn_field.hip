@@ -146,7 +146,7 @@ __global__ void k_pack_params16(DsnParamPtrs pp, _Float16* __restrict__ dst16) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nblk * 2048; e += gridDim.x * blockDim.x)
         dst16[(size_t)(b0 + e / 2048) * 2048 + (e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
 }
-#define DSN_NUM_STREAM_IMAGES 15
+#define DSN_NUM_STREAM_IMAGES 17
 
 // host twin of k_pack_params (same dsn_pack_value): lets tests check the MFMA operand layout on a CPU
 void dsn_pack_params_host(const float* const* params33_host, float* packed_host) {

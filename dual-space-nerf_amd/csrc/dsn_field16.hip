@@ -485,3 +485,113 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
     hipLaunchKernelGGL(k_field16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, active_list,
                        active_count, sigma, essence, grad);
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_light16 : model/spacenet.py:254-265 + :174-188 LightingMLP with the same split-fp16 products.
+// 9 -> 128 -> 128 -> 1 per point; the 20 weight blocks (80 KB) are L1/L2-resident, so every wave reads its
+// operands straight from memory (no LDS ring: the matrix work per point is 50x smaller than the trunk's).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void light_block(const char* __restrict__ blkp, int lane, const half8 (&xh)[2], const half8 (&xl)[2],
+                                            f32x16& aM, f32x16& aC, bool second_step) {
+    const half8 h0 = *reinterpret_cast<const half8*>(blkp + lane * 16);
+    const half8 l0 = *reinterpret_cast<const half8*>(blkp + 1024 + lane * 16);
+    aM = MFMA16(h0, xh[0], aM);
+    aC = MFMA16(h0, xl[0], aC);
+    aC = MFMA16(l0, xh[0], aC);
+    if (second_step) {
+        const half8 h1 = *reinterpret_cast<const half8*>(blkp + 2048 + lane * 16);
+        const half8 l1 = *reinterpret_cast<const half8*>(blkp + 3072 + lane * 16);
+        aM = MFMA16(h1, xh[1], aM);
+        aC = MFMA16(h1, xl[1], aC);
+        aC = MFMA16(l1, xh[1], aC);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
+          const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+          const float* __restrict__ z_vals, const float* __restrict__ essence, int64_t N, int S,
+          const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
+          float* __restrict__ colour) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (slot0 >= count) return;
+    int64_t slot = slot0 + (lane & 31);
+    const bool valid = slot < count;
+    if (!valid) slot = count - 1;
+    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
+    const int64_t ray = pt / S;
+
+    float in9[10];
+    in9[0] = n_w[3 * pt]; in9[1] = n_w[3 * pt + 1]; in9[2] = n_w[3 * pt + 2];
+    float xw[3];
+    const float d[3] = {ray_d[3 * ray], ray_d[3 * ray + 1], ray_d[3 * ray + 2]};
+    if (x_w_pts) { xw[0] = x_w_pts[3 * pt]; xw[1] = x_w_pts[3 * pt + 1]; xw[2] = x_w_pts[3 * pt + 2]; }
+    else {
+        const float z = z_vals[pt];
+        xw[0] = ray_o[3 * ray] + d[0] * z; xw[1] = ray_o[3 * ray + 1] + d[1] * z; xw[2] = ray_o[3 * ray + 2] + d[2] * z;
+    }
+    if (fs->has_rot != 0.0f) {
+        const float ax = xw[0] - fs->rot_center[0], ay = xw[1] - fs->rot_center[1];
+        const float nx = (ax * fs->rot[0] + ay * fs->rot[2]) + fs->rot_center[0];
+        const float ny = (ax * fs->rot[1] + ay * fs->rot[3]) + fs->rot_center[1];
+        xw[0] = nx; xw[1] = ny;
+    }
+    if (fs->has_light != 0.0f) { xw[0] += fs->light_shift[0]; xw[1] += fs->light_shift[1]; xw[2] += fs->light_shift[2]; }
+    in9[3] = xw[0]; in9[4] = xw[1]; in9[5] = xw[2];
+    const float vn = dsn_norm3(d);
+    in9[6] = dsn_div(d[0], vn); in9[7] = dsn_div(d[1], vn); in9[8] = dsn_div(d[2], vn);
+    in9[9] = 0.0f;
+
+    const char* w16 = reinterpret_cast<const char*>(packed + OFF16_BASE);
+    // input operand: k-slot j of step 0 holds feature 2j + half (j < 5), zero beyond
+    half8 xh[2], xl[2];
+    {
+        f32x16 v = zero16();
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[j] = half ? in9[2 * j + 1] : in9[2 * j];
+        split16(v, xh, xl);
+    }
+    half8 h1h[4][2], h1l[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x16 aM = rows16(packed + OFF_BLT0, m, half), aC = zero16();
+        light_block(w16 + (size_t)(OFF_LT0 / DSN_BLK + m) * 4096, lane, xh, xl, aM, aC, false);
+        f32x16 v = fold16(aM, aC);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+        split16(v, h1h[m], h1l[m]);
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x16 aM = rows16(packed + OFF_BLT1, m, half), aC = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+            light_block(w16 + (size_t)(OFF_LT1 / DSN_BLK + m * 4 + kb) * 4096, lane, h1h[kb], h1l[kb], aM, aC, true);
+        const f32x16 v = fold16(aM, aC);
+        const f32x16 w2 = rows16(packed + OFF_WLT2, m, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(w2[r], fmaxf(v[r], 0.0f), part);
+    }
+    part += __shfl_xor(part, 32);
+    const float o = part + packed[OFF_SCAL + 4];
+    const float wgt = (o > 0.0f ? o : expm1f(o)) + 1.0f;   // ELU(alpha=1) + 1
+    if (valid && half == 0) {
+        colour[3 * pt + 0] = wgt * essence[3 * pt + 0];
+        colour[3 * pt + 1] = wgt * essence[3 * pt + 1];
+        colour[3 * pt + 2] = wgt * essence[3 * pt + 2];
+    }
+}
+
+void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
+                        const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
+                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_light16, dim3((unsigned)blocks), dim3(256), 0, st, packed, fs, n_w, x_w, ray_o, ray_d, z_vals,
+                       essence, N, S, active_list, active_count, colour);
+}

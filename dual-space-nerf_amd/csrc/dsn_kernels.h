@@ -22,6 +22,9 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st);
+void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
+                        const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
+                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);
 void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
                             float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
 // dsn_field.hip

@@ -123,6 +123,9 @@ DSN_EXPORT int dsn_camera_rays(const double* K3x3, const double* R3x3, const dou
  * default split-fp16 scheme (3 x v_mfma_f32_32x32x16_f16 on hi/lo operand halves: fp32-equivalent accuracy at
  * 5.3x fewer matrix cycles).  Valid for dsn_field and dsn_render_rays. */
 #define DSN_FIELD_FP32 4
+/* cfg.MODEL.sample_points_mode == "uniform" (can_render.py:42-51): plain uniform_sampling between the given near/far
+ * instead of the geometry-guided interval.  Valid for dsn_render_rays. */
+#define DSN_SAMPLE_UNIFORM 8
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,

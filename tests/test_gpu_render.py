@@ -237,3 +237,18 @@ def test_all_transparent_frame():
     out = r.render(batch)["coarse"]
     assert float(out["color"].abs().max()) == 0.0 and float(out["acc_map"].abs().max()) == 0.0
     assert bool(torch.isnan(out["disp_map"]).all())
+
+
+def test_uniform_sampling_mode():
+    """cfg.MODEL.sample_points_mode = 'uniform' (can_render.py:42-51): z_vals are the plain lerp of the given near/far"""
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    r.sample_points_mode = "uniform"
+    b = make_batch(g)
+    out = r.render(b)["coarse"]
+    S = int(g["S"])
+    tv = torch.linspace(0.0, 1.0, steps=S)
+    z = b["near"][0][:, None] * (1.0 - tv) + b["far"][0][:, None] * tv
+    assert torch.equal(out["z_vals"].cpu(), z)
+    assert torch.isfinite(out["color"]).all()

@@ -130,14 +130,14 @@ def test_field_active_list(ctx, name, fp32):
     assert float(a_sig[~m].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("exhaustive", [False, True])
+@pytest.mark.parametrize("exhaustive,fp32", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("name", CASES)
-def test_shade(ctx, name, exhaustive):
+def test_shade(ctx, name, exhaustive, fp32):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
     sc = scene_for(ctx, g, name)
     idx, n_w, col = ctx["lib"].shade(sc, ctx["packed"], T(g["x_c"], dev), T(g["grad_sigma"], dev), T(g["pts"], dev),
-                                     T(g["ray_d"], dev), T(g["essence"], dev), S, exhaustive=exhaustive)
+                                     T(g["ray_d"], dev), T(g["essence"], dev), S, exhaustive=exhaustive, fp32=fp32)
     assert np.array_equal(idx.cpu().numpy(), g["idx_canon"])
     assert np.array_equal(n_w.cpu().numpy(), g["n_w"])          # same inputs -> bit-exact normals
     assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5
