@@ -124,6 +124,7 @@ def main():
         dt = float(tt.item())
 
     n_active = int(ws.buf[:4].view(torch.int32)[0]) if not args.dense else R * S
+    n_pos = int(ws.buf[64:68].view(torch.int32)[0]) if (not args.dense and not args.fp32) else n_active
     ms_step = 1e3 * dt / args.steps
     value = world * R * args.steps / dt
 
@@ -139,6 +140,7 @@ def main():
             "rays_per_gpu": R, "samples_per_ray": S,
             "transparent_skip": (not args.dense),
             "evaluated_sample_fraction": n_active / float(R * S),
+            "shaded_sample_fraction": n_pos / float(R * S),
             "ms_per_frame": ms_step,
             "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if world > 1 else "none",
         },

@@ -197,6 +197,8 @@ struct DsnWorkspace {
     float* grad;          // [N,3]
     float* n_w;           // [N,3]
     float* colour;        // [N,3]
+    int32_t* pos;         // [N]   samples with sigma > 0 (eval-mode split of the field kernel)
+    void* masks;          // [N] x 224 B relu-mask records
     size_t bytes;
 };
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
@@ -213,6 +215,8 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.grad = (float*)p;           p += dsn_align256(12 * N);
     w.n_w = (float*)p;            p += dsn_align256(12 * N);
     w.colour = (float*)p;         p += dsn_align256(12 * N);
+    w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
+    w.masks = (void*)p;           p += dsn_align256(224 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -251,7 +255,15 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st);
     if (flags & DSN_FIELD_FP32)
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
-    else
+    else if (skip) {
+        // eval mode: forward for every non-transparent sample, then d sigma/dx, normals and lighting only where sigma > 0
+        // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
+        int32_t* pcnt = w.count + 16;
+        dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st);
+        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st);
+        list = w.pos;
+        cnt = pcnt;
+    } else
         dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
     if (flags & DSN_FIELD_FP32)

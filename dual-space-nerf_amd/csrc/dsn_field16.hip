@@ -90,10 +90,10 @@ __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h
     h1 = *reinterpret_cast<const half8*>(s + 2048);
     l1 = *reinterpret_cast<const half8*>(s + 3072);
 }
-__device__ __forceinline__ void w16_begin(W16& w, int lane) {
-    w16_stage(w, 0);
-    w16_boundary(w, 0);
-    w16_read(w, 0, lane, w.h0, w.l0, w.h1, w.l1);
+__device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
+    w16_stage(w, first_blk / F16_CHUNK);
+    w16_boundary(w, first_blk);
+    w16_read(w, first_blk, lane, w.h0, w.l0, w.h1, w.l1);
 }
 
 // (accM, accC) += W[32 rows][32*KB k] * (xh, xl): consumes KB blocks starting at stream block `blk`.
@@ -271,10 +271,23 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
     for (int kb = 0; kb < 8; ++kb) epi_slice<false>(pM, pC, kb, mw, dummy, yh[7], yl[7]);
 }
 
+// MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
+// MODE 1 (FWD) : forward only; the relu masks go to `masks` (224 B per sample, indexed by sample) and the samples
+//                with sigma > 0 are appended to pos_list / pos_count.
+// MODE 2 (BWD) : reverse pass only, for the samples of the given list, from the stored masks.
+// The split exists for eval-mode rendering: a sample with sigma <= 0 has alpha = 1 - exp(-relu(sigma) dist) = 0
+// exactly, its weight is 0 and its colour - hence d sigma/dx, the normal and the lighting MLP - is never used
+// (utils/nerf_net_utils.py:18-39).  On the benchmark frame that is 71 % of the evaluated samples.
+#define F16_FULL 0
+#define F16_FWD 1
+#define F16_BWD 2
+#define F16_FIRST_BWD_BLOCK (OFF_L6T / DSN_BLK)   // 448
+template <int MODE>
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
           int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-          float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
+          float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad,
+          uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count) {
     // LDS map: weight ring 64 KB | relu masks 7 layers x 4 words x 256 threads = 28 KB | PE operands 8 x half8 x 256 = 32 KB
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
@@ -307,9 +320,19 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
-    w16_begin(w, lane);
-    int blk = 0;
+    w16_begin(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
+    int blk = MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0;
 
+    // relu masks live in LDS between the forward and the reverse pass (28 VGPRs otherwise); lane-private slots,
+    // so no barrier is needed around them
+#define MK_STORE(L, mk) { s_mask[L][0][tid] = mk[0]; s_mask[L][1][tid] = mk[1]; s_mask[L][2][tid] = mk[2]; s_mask[L][3][tid] = mk[3]; }
+#define MK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
+    uint32_t mk[4];
+    half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
+    // per-sample mask record: [half][layer] uint4, 224 B contiguous per sample
+    uint4* const mrec = masks ? masks + ((size_t)pt * 2 + half) * 7 : nullptr;
+
+  if (MODE != F16_BWD) {
     // positional encoding (fp32, accurate sincos) -> split k-steps; same slot map as k_field
     half8 ph[2][2], pl[2][2];
     {
@@ -331,13 +354,6 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         s_pe[0][tid] = ph[0][0]; s_pe[1][tid] = ph[0][1]; s_pe[2][tid] = ph[1][0]; s_pe[3][tid] = ph[1][1];
         s_pe[4][tid] = pl[0][0]; s_pe[5][tid] = pl[0][1]; s_pe[6][tid] = pl[1][0]; s_pe[7][tid] = pl[1][1];
     }
-
-    // relu masks live in LDS between the forward and the reverse pass (28 VGPRs otherwise); lane-private slots,
-    // so no barrier is needed around them
-#define MK_STORE(L, mk) { s_mask[L][0][tid] = mk[0]; s_mask[L][1][tid] = mk[1]; s_mask[L][2][tid] = mk[2]; s_mask[L][3][tid] = mk[3]; }
-#define MK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
-    uint32_t mk[4];
-    half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
 
     // stage1.0
 #pragma unroll
@@ -386,7 +402,24 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         split16(v, ah[m], al[m]);
     }
     sg_part += __shfl_xor(sg_part, 32);
-    if (valid && half == 0) sigma[pt] = sg_part + v_scal[0];
+    const float sg = sg_part + v_scal[0];
+    if (valid && half == 0) sigma[pt] = sg;
+    if (MODE == F16_FWD) {
+        // masks of all 7 layers -> the sample's record; samples with positive density -> the reverse-pass list
+        MK_STORE(6, mk)
+        if (valid) {
+#pragma unroll
+            for (int L = 0; L < 7; ++L)
+                mrec[L] = make_uint4(s_mask[L][0][tid], s_mask[L][1][tid], s_mask[L][2][tid], s_mask[L][3][tid]);
+        }
+        const bool pos = valid && half == 0 && sg > 0.0f;
+        const unsigned long long bm = __ballot(pos);
+        const int cnt = __popcll(bm);
+        int base = 0;
+        if (lane == 0 && cnt) base = atomicAdd(pos_count, cnt);
+        base = __shfl(base, 0);
+        if (pos) pos_list[base + __popcll(bm & ((1ull << lane) - 1ull))] = (int32_t)pt;
+    }
     // rgb_net: 256 -> 128 -> relu -> 3 (second layer as per-lane dots in the epilogue)
     {
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;
@@ -411,6 +444,17 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
             essence[3 * pt + 2] = e2 + v_scal[3];
         }
     }
+
+    if (MODE == F16_FWD) return;
+  } else {
+    // MODE == BWD: masks come back from the sample's record
+#pragma unroll
+    for (int L = 0; L < 7; ++L) {
+        const uint4 q = mrec[L];
+        s_mask[L][0][tid] = q.x; s_mask[L][1][tid] = q.y; s_mask[L][2][tid] = q.z; s_mask[L][3][tid] = q.w;
+    }
+    MK_LOAD(6, mk)
+  }
 
     // ---- reverse pass on g / 64: seed = W_den masked by relu(stage2.4)
 #pragma unroll
@@ -482,8 +526,28 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
                         float* grad, hipStream_t st) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_field16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad);
+    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+                       active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
+}
+// eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
+void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                            const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+                       active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count);
+}
+// ... reverse pass on the sigma > 0 samples only
+void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                            const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
+                            hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+                       pos_list, pos_count, (float*)nullptr, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

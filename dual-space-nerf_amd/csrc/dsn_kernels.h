@@ -22,6 +22,12 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st);
+void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                            const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st);
+void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                            const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
+                            hipStream_t st);
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                         int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);

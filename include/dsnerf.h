@@ -136,8 +136,9 @@ DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* pack
  * nearest-face list levels (world fine/coarse, canonical fine/coarse) into a HOST array of 16 int32. */
 DSN_EXPORT int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream);
 
-/* diagnostics: the first int32 of `workspace` holds the number of samples the last DSN_SKIP_TRANSPARENT
- * render evaluated (device memory). */
+/* diagnostics: after a DSN_SKIP_TRANSPARENT render, int32 word 0 of `workspace` holds the number of non-transparent
+ * samples (field forward evaluated) and word 16 the number of those with sigma > 0 (d sigma/dx, normal and lighting
+ * evaluated) - device memory. */
 #ifdef __cplusplus
 }
 #endif

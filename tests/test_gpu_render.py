@@ -252,3 +252,17 @@ def test_uniform_sampling_mode():
     z = b["near"][0][:, None] * (1.0 - tv) + b["far"][0][:, None] * tv
     assert torch.equal(out["z_vals"].cpu(), z)
     assert torch.isfinite(out["color"]).all()
+
+
+def test_train_forward_loss_parity():
+    """BASELINE config 3 (forward part): train-mode render (jitter + noise from the CPU generator, seed 233, dense
+    evaluation) reproduces the reference's MSE loss (trainer.py:70-72, utils/loss.py:17) on the captured batch"""
+    g = load("small_train")
+    r = make_renderer(g, "small_train")
+    r.train()
+    torch.manual_seed(233)
+    out = r.render(make_batch(g))["coarse"]
+    loss = torch.nn.functional.mse_loss(out["color"].cpu(), torch.from_numpy(g["target_rgb"]))
+    ref = float(g["render:loss"])
+    assert abs(float(loss) - ref) < 1e-6 * max(1.0, abs(ref)), (float(loss), ref)
+    assert maxdiff(out["color"].cpu().numpy(), g["render:color"]) < 1e-4
