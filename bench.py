@@ -9,9 +9,10 @@ torch.distributed.run, one rank per GPU) every rank renders its own frame of the
 exchanged with one RCCL all-gather inside the timed region: weak scaling, value = all rays / max time.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     - k_field (the dominant kernel), timed live with HIP events on the launch stream in a
+  roofline     - k_field16<forward> (the dominant kernel), timed live with HIP events on the launch stream in a
                  separate stage-by-stage pass over the same frame; algorithmic FLOPs = evaluated samples
-                 x 1.769216 MFLOP (2 x 884 608 MAC: trunk + heads forward + analytic d sigma/dx).
+                 x 0.91776 MFLOP (2 x 458 880 MAC: trunk + heads); the reverse kernel (analytic d sigma/dx,
+                 2 x 425 728 MAC per sigma > 0 sample) is reported beside it.
   cpu_baseline - the C oracle (oracle/dsn_oracle.c, a port of the reference algorithm) timed on the host
                  cores on a bounded sample of the same frame (rank 0, N=1 only).
 """
@@ -30,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_FIELD_PER_SAMPLE = 2.0 * 884608.0       # k_field: forward trunk+heads 458 880 MAC + reverse 425 728 MAC
+FLOP_FIELD_FWD_PER_SAMPLE = 2.0 * 458880.0   # k_field16<forward>: trunk + density/essence heads
+FLOP_FIELD_REV_PER_SAMPLE = 2.0 * 425728.0   # k_field16<reverse>: analytic d sigma/dx
 FLOP_ALL_PER_SAMPLE = 2.0 * 902272.0         # + lighting MLP 17 664 MAC
 PEAK_F32_MATRIX_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_F16_MATRIX_TFLOPS = 2500.0              # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
@@ -142,6 +145,9 @@ def main():
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
             "ms_per_frame": ms_step,
+            # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
+            # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
+            "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
             "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if world > 1 else "none",
         },
     }
@@ -158,48 +164,84 @@ def main():
 
 
 def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
-    """Stage-by-stage pass over the same frame; k_field timed with HIP events on the launch stream
-    (torch's current stream IS the stream every dsn_* call is enqueued on)."""
+    """Stage-by-stage pass over the same frame; the field kernels are timed with HIP events on the launch stream
+    (torch's current stream IS the stream every dsn_* call is enqueued on).  The dominant kernel of the frame is
+    k_field16<forward> (all non-transparent samples); k_field16<reverse> runs on the sigma > 0 subset."""
+    import ctypes as C
     R = ray_o.shape[0]
+    N = R * S
+    dev = scene.device
+    L = _lib.lib()
     near, far = near0.clone(), far0.clone()
     pts, z = _lib.sample(scene, ray_o, ray_d, near, far, S, t_vals, None, want_pts=True)
     w = _lib.warp(scene, pts, ray_d, S, want_dir=False, want_active=not args.dense)
-    active = None if args.dense else (w["active_list"], w["active_count"])
-    n_eval = R * S if args.dense else int(w["active_count"][0])
+    lst, cnt = (None, None) if args.dense else (w["active_list"], w["active_count"])
+    n_eval = N if args.dense else int(w["active_count"][0])
     reps = max(3, min(10, args.steps))
-    for _i in range(2):
-        _lib.field(scene, packed, w["x_c"], active=active, fp32=args.fp32)
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _i in range(reps)]
-    # pre-allocate outputs once so that only the kernel sits between the events
-    import ctypes as C
-    N = R * S
-    dev = scene.device
     sig = torch.zeros(N, device=dev)
     ess = torch.zeros(N, 3, device=dev)
     g = torch.zeros(N, 3, device=dev)
-    lst, cnt = (None, None) if active is None else active
-    for a, b in evs:
-        a.record()
-        rc = _lib.lib().dsn_field(_lib._ptr(scene.buf), scene.V, scene.F, _lib._ptr(packed.buf), _lib._ptr(w["x_c"]),
-                                  C.c_int64(N), _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess),
-                                  _lib._ptr(g), _lib.FIELD_FP32 if args.fp32 else 0, _lib._stream())
-        b.record()
-        assert rc == 0
-    torch.cuda.synchronize()
-    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    flops = n_eval * FLOP_FIELD_PER_SAMPLE
-    ach = flops / (ms * 1e-3) / 1e12
+    a0 = (_lib._ptr(scene.buf), scene.V, scene.F, _lib._ptr(packed.buf), _lib._ptr(w["x_c"]), C.c_int64(N))
+
+    def timed(fn, pre=None):
+        ms = []
+        for i in range(reps + 2):                      # 2 untimed warm-up launches
+            if pre is not None:
+                pre()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn()
+            b.record()
+            assert rc == 0, L.dsn_last_error()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ms.append(a.elapsed_time(b))
+        return float(np.mean(ms))
+
+    split = not (args.fp32 or args.dense)
+    if split:
+        rec = torch.empty(L.dsn_field_record_bytes(C.c_int64(N)), dtype=torch.uint8, device=dev)
+        pos = torch.zeros(N, dtype=torch.int32, device=dev)
+        pcnt = torch.zeros(64, dtype=torch.int32, device=dev)
+        ms = timed(lambda: L.dsn_field_forward(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess),
+                                               _lib._ptr(rec), _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream()),
+                   pre=lambda: pcnt.zero_())
+        n_pos = int(pcnt[0])
+        ms_rev = timed(lambda: L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g),
+                                                   _lib._stream()))
+        flop_per, kern = FLOP_FIELD_FWD_PER_SAMPLE, "k_field16<forward>"
+    else:
+        ms = timed(lambda: L.dsn_field(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess), _lib._ptr(g),
+                                       _lib.FIELD_FP32 if args.fp32 else 0, _lib._stream()))
+        flop_per, kern = FLOP_FIELD_PER_SAMPLE, ("k_field" if args.fp32 else "k_field16<full>")
+    ach = n_eval * flop_per / (ms * 1e-3) / 1e12
     if args.fp32:
-        peak, kern, note = PEAK_F32_MATRIX_TFLOPS, "k_field", "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+        peak, note = PEAK_F32_MATRIX_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     else:
         # the algorithmic FLOPs are executed as 3 f16 MFMA products each: the ceiling for ALGORITHMIC FLOP/s of this
         # scheme is the dense f16 MFMA peak / 3 (= 5.3x the fp32-matrix peak of 157.3)
-        peak, kern = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "k_field16"
+        peak = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS
         note = "split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32-equivalent accuracy; peak = 2500/3"
-    return {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": None, "kernel_ms": ms, "samples_per_launch": n_eval,
-            "flop_per_sample": FLOP_FIELD_PER_SAMPLE, "scheme": note, "x_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
+    out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+           "frac": ach / peak, "traffic": measured_traffic(kern, args), "kernel_ms": ms, "samples_per_launch": n_eval,
+           "flop_per_sample": flop_per, "scheme": note, "x_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
+    if split:
+        ach_r = n_pos * FLOP_FIELD_REV_PER_SAMPLE / (ms_rev * 1e-3) / 1e12
+        out["reverse_kernel"] = {"kernel": "k_field16<reverse>", "kernel_ms": ms_rev, "samples_per_launch": n_pos,
+                                 "flop_per_sample": FLOP_FIELD_REV_PER_SAMPLE, "achieved": ach_r, "frac": ach_r / peak}
+    return out
+
+
+def measured_traffic(kern, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc.json, written by scripts/pmc_summary.py: (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction
+    of MI355X_MICROARCH.md); null when the counters were not collected for this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(kern)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
 def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):

@@ -32,7 +32,8 @@ PARAM_ORDER = [
 EXPORTS = [
     "dsn_abi_version", "dsn_last_error", "dsn_packed_param_bytes", "dsn_pack_params",
     "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
-    "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_shade", "dsn_composite",
+    "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
+    "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
@@ -52,7 +53,7 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no fallback path.")
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
-        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes"):
+        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes"):
             getattr(L, n).restype = C.c_size_t
         _lib = L
     return _lib
@@ -198,6 +199,32 @@ def field(scene: Scene, packed: PackedParams, x_c, want_essence=True, want_grad=
                            _ptr(lst), _ptr(cnt), _ptr(sigma), _ptr(ess), _ptr(g), FIELD_FP32 if fp32 else 0, _stream()),
            "dsn_field")
     return sigma, ess, g
+
+
+def field_forward(scene: Scene, packed: PackedParams, x_c, active=None):
+    """sigma, essence for the listed points + the list of points with sigma > 0 (see dsn_field_forward)."""
+    x_c = x_c.reshape(-1, 3)
+    N = x_c.shape[0]
+    dev = scene.device
+    sigma = torch.zeros(N, dtype=torch.float32, device=dev)
+    ess = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+    rec = torch.empty(lib().dsn_field_record_bytes(C.c_int64(N)), dtype=torch.uint8, device=dev)
+    pos = torch.zeros(N, dtype=torch.int32, device=dev)
+    pcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    lst, cnt = (None, None) if active is None else active
+    _check(lib().dsn_field_forward(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
+                                   _ptr(lst), _ptr(cnt), _ptr(sigma), _ptr(ess), _ptr(rec), _ptr(pos), _ptr(pcnt), _stream()),
+           "dsn_field_forward")
+    return sigma, ess, rec, (pos, pcnt)
+
+
+def field_reverse(scene: Scene, packed: PackedParams, x_c, rec, pos):
+    x_c = x_c.reshape(-1, 3)
+    N = x_c.shape[0]
+    g = torch.zeros(N, 3, dtype=torch.float32, device=scene.device)
+    _check(lib().dsn_field_reverse(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
+                                   _ptr(pos[0]), _ptr(pos[1]), _ptr(rec), _ptr(g), _stream()), "dsn_field_reverse")
+    return g
 
 
 def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None, exhaustive=False, fp32=False):

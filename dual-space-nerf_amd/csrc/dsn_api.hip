@@ -131,6 +131,31 @@ int dsn_field(const void* scene, int V, int F, const void* packed, const float* 
     return dsn_check_launch("dsn_field");
 }
 
+size_t dsn_field_record_bytes(int64_t N) { return N > 0 ? dsn_align256(224 * (size_t)N) : 0; }
+
+int dsn_field_forward(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
+                      const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence, void* records,
+                      int32_t* pos_list, int32_t* pos_count, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && sigma && essence && records && pos_list && pos_count, "dsn_field_forward: null argument");
+    DSN_REQUIRE(N > 0, "dsn_field_forward: empty point batch");
+    DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_field_forward: active_list and active_count go together");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_field_forward: bad V/F");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_field16_fwd((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, records, pos_list,
+                           pos_count, (hipStream_t)stream);
+    return dsn_check_launch("dsn_field_forward");
+}
+
+int dsn_field_reverse(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* pos_list,
+                      const int32_t* pos_count, const void* records, float* grad, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && pos_list && pos_count && records && grad, "dsn_field_reverse: null argument");
+    DSN_REQUIRE(N > 0, "dsn_field_reverse: empty point batch");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_field_reverse: bad V/F");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_field16_bwd((const float*)packed, s.frame, x_c, N, pos_list, pos_count, grad, records, (hipStream_t)stream);
+    return dsn_check_launch("dsn_field_reverse");
+}
+
 int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
               const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
               const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, int flags, void* stream) {

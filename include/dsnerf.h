@@ -89,6 +89,19 @@ DSN_EXPORT int dsn_warp(const void* scene, int V, int F, const float* pts, const
 DSN_EXPORT int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
               const int32_t* active_count, float* sigma, float* essence, float* grad, int flags, void* stream);
 
+/* The same evaluation in two launches, for eval-mode rendering (what dsn_render_rays does under
+ * DSN_SKIP_TRANSPARENT): dsn_field_forward writes sigma/essence for the listed points, keeps every point's ReLU
+ * pattern in `records` (dsn_field_record_bytes(N) bytes) and appends the points with sigma > 0 to pos_list
+ * (pos_count zeroed by the caller); dsn_field_reverse then writes grad = d sigma / d x_c for the points of
+ * pos_list only - the others have alpha = 0 exactly (utils/nerf_net_utils.py:24-27: relu(sigma)), so their
+ * normal and colour never reach a pixel.  Results are bit-identical to dsn_field's on the points both write. */
+DSN_EXPORT size_t dsn_field_record_bytes(int64_t N);
+DSN_EXPORT int dsn_field_forward(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
+                      const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                      void* records, int32_t* pos_list, int32_t* pos_count, void* stream);
+DSN_EXPORT int dsn_field_reverse(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
+                      const int32_t* pos_list, const int32_t* pos_count, const void* records, float* grad, void* stream);
+
 /* model/spacenet.py:278-298 normal_local2world + :254-265 + :174-188 LightingMLP.forward.
  * x_w = world sample points [N,3], ray_d [N/S,3]; outputs face_idx_canon [N], n_w [N,3],
  * colour [N,3] (any may be NULL except colour). */

@@ -130,6 +130,43 @@ def test_field_active_list(ctx, name, fp32):
     assert float(a_sig[~m].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("use_list", [False, True])
+@pytest.mark.parametrize("name", CASES)
+def test_field_forward_reverse_equals_single_launch(ctx, name, use_list):
+    """dsn_field_forward + dsn_field_reverse (the eval-mode split) == dsn_field, bit for bit: sigma/essence on every
+    evaluated point, grad on exactly the points with sigma > 0; everything else untouched."""
+    g = load(name)
+    dev = ctx["dev"]
+    sc = scene_for(ctx, g, name)
+    x = T(g["x_c"], dev)
+    N = g["x_c"].shape[0]
+    active, m = None, torch.ones(N, dtype=torch.bool, device=dev)
+    if use_list:
+        act = np.nonzero(~g["transparent"])[0].astype(np.int32)
+        np.random.default_rng(1).shuffle(act)
+        lst = torch.zeros(N, dtype=torch.int32, device=dev)
+        lst[:len(act)] = T(act, dev)
+        cnt = torch.zeros(64, dtype=torch.int32, device=dev)
+        cnt[0] = len(act)
+        active = (lst, cnt)
+        m = torch.zeros(N, dtype=torch.bool, device=dev)
+        m[T(act.astype(np.int64), dev)] = True
+    d_sig, d_ess, d_gr = ctx["lib"].field(sc, ctx["packed"], x)
+    sig, ess, rec, pos = ctx["lib"].field_forward(sc, ctx["packed"], x, active=active)
+    gr = ctx["lib"].field_reverse(sc, ctx["packed"], x, rec, pos)
+    assert torch.equal(sig[m], d_sig[m]) and torch.equal(ess[m], d_ess[m])
+    assert float(sig[~m].abs().sum()) == 0.0
+    want = m & (d_sig > 0)
+    n_pos = int(pos[1][0])
+    assert n_pos == int(want.sum())
+    got = torch.zeros(N, dtype=torch.bool, device=dev)
+    got[pos[0][:n_pos].long()] = True
+    assert torch.equal(got, want)
+    assert torch.equal(gr[want], d_gr[want])
+    assert float(gr[~want].abs().sum()) == 0.0
+    assert 0 < n_pos < N          # the fixture exercises both branches
+
+
 @pytest.mark.parametrize("exhaustive,fp32", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("name", CASES)
 def test_shade(ctx, name, exhaustive, fp32):
