@@ -34,7 +34,7 @@ EXPORTS = [
     "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
-    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -53,7 +53,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no fallback path.")
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
-        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes"):
+        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
+                  "dsn_grad_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
         _lib = L
     return _lib
@@ -302,6 +303,47 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                  _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
            "dsn_render_rays")
     return out
+
+
+class GradWorkspace:
+    """Scratch of the training backward (grown on demand; 16 KB per sample)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.buf = None
+
+    def get(self, R, S):
+        need = lib().dsn_grad_workspace_bytes(int(R), int(S))
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = None
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, d_rgb, d_disp=None,
+                     d_acc=None, d_depth=None, d_weights=None, ws: GradWorkspace = None):
+    """Parameter gradients of render_rays' outputs (dsn_render_rays_grad; trainer.py:70-81 loss.backward()).
+    params: the 33 tensors in PARAM_ORDER (name -> tensor dict or list).  Returns a list of 33 gradient tensors
+    (float32, on the device, shaped like the parameters).  The scene's frame must be set with the same parameters."""
+    dev = scene.device
+    if isinstance(params, dict):
+        params = [params[k] for k in PARAM_ORDER]
+    prm = [_f32(p.detach(), dev) for p in params]
+    grads = [torch.empty_like(p) for p in prm]
+    pp = (C.c_void_p * 33)(*[p.data_ptr() for p in prm])
+    gp = (C.c_void_p * 33)(*[g.data_ptr() for g in grads])
+    R, S = z_vals.shape
+    ws = ws or GradWorkspace(dev)
+    buf = ws.get(R, S)
+    poses = _f32(poses.reshape(24, 3), dev)
+    f = lambda a: None if a is None else _f32(a, dev)
+    args = [f(ray_o), f(ray_d), f(z_vals), f(noise), f(d_rgb), f(d_disp), f(d_acc), f(d_depth), f(d_weights)]
+    _check(lib().dsn_render_rays_grad(_ptr(scene.buf), scene.V, scene.F, pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
+                                      _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), int(R), int(S),
+                                      _ptr(args[4]), _ptr(args[5]), _ptr(args[6]), _ptr(args[7]), _ptr(args[8]), gp,
+                                      _ptr(buf), _stream()), "dsn_render_rays_grad")
+    scene._keep_grad = (prm, args, poses)
+    return grads
 
 
 def camera_rays(K, R, T, bounds, H, W, device=None):

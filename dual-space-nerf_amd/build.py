@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dsn_api.hip", "dsn_geom.hip", "dsn_nn.hip", "dsn_field.hip", "dsn_field16.hip"]
+SOURCES = ["dsn_api.hip", "dsn_geom.hip", "dsn_nn.hip", "dsn_field.hip", "dsn_field16.hip", "dsn_train.hip"]
 HEADERS = ["dsn_common.h", "dsn_nn.h", "dsn_kernels.h", os.path.join("..", "..", "include", "dsnerf.h")]
 LIB = os.path.join(HERE, "libdsnerf_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
@@ -45,7 +45,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
+        # rocBLAS serves the plain fp32 GEMMs of the training backward (csrc/dsn_train.hip)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L" + rocm_lib, "-lrocblas",
+                                                                              "-Wl,-rpath," + rocm_lib, "-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -11,7 +11,8 @@ What differs from the reference, on purpose (DESIGN.md "boundary"):
     an empty_cache + 6 device->host copies each, can_render.py:172-245); one device->host copy at the end;
   * in eval mode the networks are evaluated only on non-transparent samples (their sigma is zeroed and
     their colour has weight 0 in the reference, can_render.py:115-120) - outputs are identical;
-  * `render()` is forward-only this round (no autograd graph).
+  * `render()` in train mode returns tensors attached to ONE autograd node whose backward is
+    dsn_render_rays_grad (analytic parameter gradients, csrc/dsn_train.hip) instead of an op-by-op graph.
 """
 from __future__ import annotations
 
@@ -31,6 +32,44 @@ def load_bodydata(model_type="smpl", gender="neutral", model_path=""):
     assert os.path.exists(model_path), "Path {} does not exist!".format(model_path)
     with open(model_path, "rb") as f:
         return pickle.load(f, encoding="latin1")
+
+
+_OUT_KEYS = ("color", "disp_map", "acc_map", "depth_map", "weights", "z_vals")
+
+
+class _RenderRays(torch.autograd.Function):
+    """render_rays as one differentiable node: forward = dsn_render_rays, backward = dsn_render_rays_grad
+    (what loss.backward() does in trainer.py:70-81).  Inputs that are not parameters carry no gradient, as in the
+    reference (rays, near/far, xyz, poses are data)."""
+
+    @staticmethod
+    def forward(ctx, renderer, call, *params):
+        o, d, near, far, S, jitter, noise, uniform, frame_args = call
+        out = _lib.render_rays(renderer.scene, renderer.net.packed(renderer.device), renderer._ws, o, d, near, far, S,
+                               renderer._t_vals(S), jitter, noise, skip_transparent=False, uniform=uniform)
+        ctx.renderer, ctx.call, ctx.params = renderer, (o, d, noise, frame_args), params
+        ctx.z_vals = out["z_vals"]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out["z_vals"])
+        return tuple(out[k] for k in _OUT_KEYS)
+
+    @staticmethod
+    def backward(ctx, g_color, g_disp, g_acc, g_depth, g_weights, g_z):
+        r = ctx.renderer
+        o, d, noise, frame_args = ctx.call
+        xyz, poses, frame, zero_code, ls, rot, rc = frame_args
+        params = [p.detach() for p in ctx.params]
+        sd = dict(zip(_lib.PARAM_ORDER, params))
+        packed = r.net.packed(r.device)
+        r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc)   # another frame may have been rendered since
+        if g_color is None:
+            g_color = torch.zeros(o.shape[0], 3, device=r.device)
+        if not hasattr(r, "_grad_ws"):
+            r._grad_ws = _lib.GradWorkspace(r.device)
+        grads = _lib.render_rays_grad(r.scene, sd, poses, frame, zero_code, o, d, ctx.z_vals, noise, g_color, g_disp, g_acc,
+                                      g_depth, g_weights, ws=r._grad_ws)
+        grads = [g.to(device=p.device, dtype=p.dtype).reshape(p.shape) for g, p in zip(grads, ctx.params)]
+        return (None, None) + tuple(grads)
 
 
 class Renderer:
@@ -197,9 +236,18 @@ class Renderer:
         jitter, noise = self._draws(R, S)
         if self.sample_points_mode not in ("GG", "uniform"):
             raise Exception("error")   # the reference fails on unknown modes too (get_sampling_points returns nothing)
-        out = _lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o, d, near, far, S, self._t_vals(S),
-                               jitter, noise, skip_transparent=self.skip_transparent and not self.net.training,
-                               uniform=(self.sample_points_mode == "uniform"))
+        uniform = self.sample_points_mode == "uniform"
+        sd = dict(self.net.named_parameters())
+        if self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in sd.values()):
+            frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
+            frame_args = (batch["xyz"][0], batch["poses"][0], frame) + tuple(self.net.frame_args(batch))
+            outs = _RenderRays.apply(self, (o, d, near, far, S, jitter, noise, uniform, frame_args),
+                                     *[sd[k] for k in _lib.PARAM_ORDER])
+            out = dict(zip(_OUT_KEYS, outs))
+        else:
+            out = _lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o, d, near, far, S, self._t_vals(S),
+                                   jitter, noise, skip_transparent=self.skip_transparent and not self.net.training,
+                                   uniform=uniform)
         if batch["near"].is_cuda:   # in-place semantics of the reference when the batch already lives on the device
             batch["near"][0].copy_(near)
             batch["far"][0].copy_(far)

@@ -45,3 +45,10 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
 void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                       const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                       int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);
+
+// dsn_train.hip: parameter gradients of Renderer.render (layer-wise, rocBLAS GEMMs + element-wise kernels)
+size_t dsn_train_workspace_size(int64_t N);
+const char* dsn_train_run(const DsnSceneView& s, const float* const* params33, const float* poses, int frame_idx, int zero_code,
+                          const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
+                          const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
+                          const float* d_weights, float* const* grads33, void* workspace, hipStream_t st);

@@ -1,0 +1,635 @@
+// dsn_train.hip - parameter gradients of Renderer.render (trainer.py:70-81 loss.backward()).
+//
+// What autograd does in the reference, restated analytically.  With per-sample cotangents dL/dsigma, dL/dessence,
+// dL/dn_w coming back from compositing (utils/nerf_net_utils.py:5-56), the colour product and the lighting MLP
+// (model/spacenet.py:174-188, :254-265), the parameters of the canonical field receive
+//
+//   dW_l = sum_n  (m_l * ahat_l)[n] (x) h_{l-1}[n]   +   (m_l * a_l)[n] (x) hdot_{l-1}[n]
+//
+//   h_l     forward activations (model/spacenet.py:93-148), m_l their ReLU patterns
+//   a_l     adjoint of sigma (the reverse pass that also yields g = d sigma/dx, model/spacenet.py:301-311)
+//   ahat_l  adjoint of  dL/dsigma * sigma + dL/dessence . essence
+//   hdot_l  forward TANGENT along u = dL/dg:  u . grad_x sigma is the directional derivative of sigma along u, a
+//           network that is linear in every W_l with the same patterns m_l, so its weight gradient is the outer
+//           product of the sigma-adjoint from above and the tangent from below.  This is the double-backward term
+//           through  grad sigma -> n_w -> lighting  (model/spacenet.py:251-265) without a second autograd graph.
+//   u       = J^T dL/dn_w, J = d n_w / d g: projection onto the canonical nearest face and re-embedding on the posed
+//           face are affine in the point (utils/geo_utils.py:96-113,138-156,181-200), then F.normalize.
+//
+// First implementation of this row: layer-by-layer, activations of one training batch resident in HBM (16 KB per
+// sample - 8.6 GB for the 8192 x 64 batch of BASELINE configs[2], sized for 288 GB), the dense contractions are
+// plain fp32 GEMMs handed to rocBLAS (forward, reverse, tangent, adjoint and the two weight-gradient products per
+// layer), everything else is the kernels below.  Fusing these passes like k_field16 is the follow-up.
+#include "dsn_common.h"
+#include "dsn_kernels.h"
+#include <rocblas/rocblas.h>
+
+#include <mutex>
+
+namespace {
+
+enum { P_EMB = 0, P_S1_0W, P_S1_0B, P_S1_2W, P_S1_2B, P_S1_4W, P_S1_4B, P_S1_6W, P_S1_6B, P_S2_0W, P_S2_0B, P_S2_2W,
+       P_S2_2B, P_S2_4W, P_S2_4B, P_DEN_W, P_DEN_B, P_RGB1_W, P_RGB1_B, P_RGB3_W, P_RGB3_B, P_L0_W, P_L0_B, P_L2_W,
+       P_L2_B, P_L4_W, P_L4_B, P_PM0_W, P_PM0_B, P_PM2_W, P_PM2_B, P_PM4_W, P_PM4_B };
+
+const int kParamCount[33] = {500 * 8, 256 * 87, 256, 256 * 256, 256, 256 * 256, 256, 256 * 256, 256, 256 * 319, 256,
+                             256 * 256, 256, 256 * 256, 256, 256, 1, 128 * 256, 128, 3 * 128, 3, 128 * 9, 128,
+                             128 * 128, 128, 128, 1, 64 * 92, 64, 64 * 64, 64, 16 * 64, 16};
+
+// trunk layer l: weight / bias parameter index, input width (leading dimension of W), column of the h-part
+const int kTrunkW[7] = {P_S1_0W, P_S1_2W, P_S1_4W, P_S1_6W, P_S2_0W, P_S2_2W, P_S2_4W};
+const int kTrunkB[7] = {P_S1_0B, P_S1_2B, P_S1_4B, P_S1_6B, P_S2_0B, P_S2_2B, P_S2_4B};
+const int kTrunkLd[7] = {87, 256, 256, 256, 319, 256, 256};
+#define PE_LD 64          // positional encoding rows: 63 values + one zero pad
+#define PE_K 63
+#define W0_PE_COL 8       // stage1.0 input = [code 8 | pe 63 | pose 16]  (model/spacenet.py:125-131)
+#define W0_POSE_COL 71
+#define W4_PE_COL 256     // stage2.0 input = [h 256 | pe 63]              (model/spacenet.py:133-135)
+
+rocblas_handle g_handle = nullptr;
+std::mutex g_handle_mutex;
+
+rocblas_handle blas(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_handle_mutex);
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success) { g_handle = nullptr; return nullptr; }
+        rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
+    }
+    if (rocblas_set_stream(g_handle, st) != rocblas_status_success) return nullptr;
+    return g_handle;
+}
+
+// row-major views: X [N,in] (ldx), W [out,in] (ldw, torch Linear layout), Y [N,out] (ldy)
+bool lin_fwd(rocblas_handle h, int N, int in, int out, const float* X, int ldx, const float* W, int ldw, float* Y, int ldy,
+             float beta) {
+    const float one = 1.0f;
+    return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, out, N, in, &one, W, ldw, X, ldx, &beta, Y,
+                         ldy) == rocblas_status_success;
+}
+// dX [N,in] = dY [N,out] W
+bool lin_bwd(rocblas_handle h, int N, int in, int out, const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx,
+             float beta) {
+    const float one = 1.0f;
+    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, in, N, out, &one, W, ldw, dY, ldy, &beta, dX,
+                         ldx) == rocblas_status_success;
+}
+// dW [out,in] += dY^T X
+bool lin_wgrad(rocblas_handle h, int N, int in, int out, const float* X, int ldx, const float* dY, int ldy, float* dW,
+               int ldw) {
+    const float one = 1.0f;
+    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, in, out, N, &one, X, ldx, dY, ldy, &one, dW,
+                         ldw) == rocblas_status_success;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// element-wise kernels
+// ------------------------------------------------------------------------------------------------------------
+#define T_THREADS 256
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + T_THREADS - 1) / T_THREADS)); }
+
+// model/dimension_kernel.py:34-35,56-75: [x, sin(2^j x), cos(2^j x)]_{j<10}; column 63 is a zero pad
+__global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_c, int64_t N, float* __restrict__ pe) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= N * PE_LD) return;
+    const int64_t n = t >> 6;
+    const int c = (int)(t & 63);
+    float v = 0.0f;
+    if (c < 3) v = x_c[3 * n + c];
+    else if (c < PE_K) {
+        const int j = (c - 3) / 6, r = (c - 3) % 6, a = r % 3;
+        const float arg = x_c[3 * n + a] * (float)(1 << j);
+        v = r < 3 ? sinf(arg) : cosf(arg);
+    }
+    pe[t] = v;
+}
+
+// tangent of the encoding along u: [u, 2^j cos(2^j x) u, -2^j sin(2^j x) u]
+__global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restrict__ x_c, const float* __restrict__ u,
+                                                             int64_t N, float* __restrict__ tpe) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= N * PE_LD) return;
+    const int64_t n = t >> 6;
+    const int c = (int)(t & 63);
+    float v = 0.0f;
+    if (c < 3) v = u[3 * n + c];
+    else if (c < PE_K) {
+        const int j = (c - 3) / 6, r = (c - 3) % 6, a = r % 3;
+        const float f = (float)(1 << j);
+        const float arg = x_c[3 * n + a] * f;
+        v = (r < 3 ? cosf(arg) : -sinf(arg)) * f * u[3 * n + a];
+    }
+    tpe[t] = v;
+}
+
+// g = J_pe^T dpe  (model/spacenet.py:301-311 through the encoding)
+__global__ void __launch_bounds__(T_THREADS) k_t_pe_reverse(const float* __restrict__ x_c, const float* __restrict__ dpe,
+                                                             int64_t N, float* __restrict__ g) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= N * 3) return;
+    const int64_t n = t / 3;
+    const int a = (int)(t % 3);
+    const float x = x_c[t];
+    const float* d = dpe + n * PE_LD;
+    float acc = d[a];
+    for (int j = 0; j < 10; ++j) {
+        const float f = (float)(1 << j);
+        const float arg = x * f;
+        acc += f * (cosf(arg) * d[3 + 6 * j + a] - sinf(arg) * d[6 + 6 * j + a]);
+    }
+    g[t] = acc;
+}
+
+__global__ void __launch_bounds__(T_THREADS) k_t_bias_relu(float* __restrict__ z, const float* __restrict__ bias, int C,
+                                                            int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= total) return;
+    const float v = z[t] + bias[t % C];
+    z[t] = v > 0.0f ? v : 0.0f;
+}
+
+// a = (h > 0) ? a : 0
+__global__ void __launch_bounds__(T_THREADS) k_t_mask(float* __restrict__ a, const float* __restrict__ h, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= total) return;
+    if (!(h[t] > 0.0f)) a[t] = 0.0f;
+}
+
+// out[n,c] = (h[n,c] > 0) ? base[n,c] (optional) + scale[n] (optional, else 1) * w[c] : 0
+__global__ void __launch_bounds__(T_THREADS) k_t_seed(const float* __restrict__ h, const float* __restrict__ w,
+                                                       const float* __restrict__ scale, const float* base, int C,
+                                                       int64_t total, float* out) {   // base may alias out
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= total) return;
+    const int64_t n = t / C;
+    const int c = (int)(t % C);
+    float v = (scale ? scale[n] : 1.0f) * w[c];
+    if (base) v += base[t];
+    out[t] = h[t] > 0.0f ? v : 0.0f;
+}
+
+__device__ __forceinline__ float t_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// out[n, k] = bias[k] + h[n,:] . w[k,:]   (K <= 3 output rows; one wave per sample)
+__global__ void __launch_bounds__(T_THREADS) k_t_rowdot(const float* __restrict__ h, int C, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int K, int64_t N,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int k = 0; k < K; ++k) {
+        float acc = 0.0f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(h[n * C + c], w[k * C + c], acc);
+        acc = t_wave_sum(acc);
+        if (lane == 0) out[n * K + k] = acc + bias[k];
+    }
+}
+
+// column sums of a [N,C] matrix (C <= 256), accumulated into out[C]
+__global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict__ a, int C, int64_t N, int rows_per_block,
+                                                         float* __restrict__ out) {
+    __shared__ float s[T_THREADS];
+    const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    const int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    int64_t end = base + rows_per_block;
+    if (end > N) end = N;
+    float acc = 0.0f;
+    if (r0 < rs)
+        for (int64_t n = base + r0; n < end; n += rs) acc += a[n * C + c];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    if (r0 == 0) {
+        for (int k = 1; k < rs; ++k) acc += s[k * C + c];
+        atomicAdd(out + c, acc);
+    }
+}
+
+// lighting input rows [n_w, x_w (rotated / shifted, model/spacenet.py:254-263), d/|d|]
+__global__ void __launch_bounds__(T_THREADS) k_t_light_in(const float* __restrict__ n_w, const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, const float* __restrict__ z_vals,
+                                                           const DsnFrameState* __restrict__ fs, int64_t N, int S,
+                                                           float* __restrict__ xl) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const int64_t ray = n / S;
+    const float d[3] = {ray_d[3 * ray], ray_d[3 * ray + 1], ray_d[3 * ray + 2]};
+    const float z = z_vals[n];
+    float xw[3] = {ray_o[3 * ray] + d[0] * z, ray_o[3 * ray + 1] + d[1] * z, ray_o[3 * ray + 2] + d[2] * z};
+    if (fs->has_rot != 0.0f) {
+        const float ax = xw[0] - fs->rot_center[0], ay = xw[1] - fs->rot_center[1];
+        const float nx = (ax * fs->rot[0] + ay * fs->rot[2]) + fs->rot_center[0];
+        const float ny = (ax * fs->rot[1] + ay * fs->rot[3]) + fs->rot_center[1];
+        xw[0] = nx; xw[1] = ny;
+    }
+    if (fs->has_light != 0.0f) { xw[0] += fs->light_shift[0]; xw[1] += fs->light_shift[1]; xw[2] += fs->light_shift[2]; }
+    const float vn = dsn_norm3(d);
+    float* o = xl + 9 * n;
+    o[0] = n_w[3 * n]; o[1] = n_w[3 * n + 1]; o[2] = n_w[3 * n + 2];
+    o[3] = xw[0]; o[4] = xw[1]; o[5] = xw[2];
+    o[6] = dsn_div(d[0], vn); o[7] = dsn_div(d[1], vn); o[8] = dsn_div(d[2], vn);
+}
+
+// colour = (ELU(pre) + 1) * essence  (model/spacenet.py:186-188, :265)
+__global__ void __launch_bounds__(T_THREADS) k_t_colour(const float* __restrict__ pre, const float* __restrict__ ess, int64_t N,
+                                                         float* __restrict__ wl, float* __restrict__ col) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const float p = pre[n];
+    const float w = (p > 0.0f ? p : expm1f(p)) + 1.0f;
+    wl[n] = w;
+    for (int c = 0; c < 3; ++c) col[3 * n + c] = w * ess[3 * n + c];
+}
+
+// utils/nerf_net_utils.py:5-56 forward + its adjoint, one thread per ray (training batches are a few thousand rays).
+// Cotangents: d_rgb [R,3] (required), d_disp / d_acc / d_depth [R], d_weights [R,S] (optional).
+__global__ void __launch_bounds__(T_THREADS) k_t_composite_adjoint(
+    const float* __restrict__ colour, const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+    const float* __restrict__ z_vals, const float* __restrict__ ray_d, const float* __restrict__ noise, int R, int S,
+    const float* __restrict__ d_rgb, const float* __restrict__ d_disp, const float* __restrict__ d_acc,
+    const float* __restrict__ d_depth, const float* __restrict__ d_weights, float* __restrict__ scratch_t,
+    float* __restrict__ d_colour, float* __restrict__ d_sigma) {
+    const int r = blockIdx.x * T_THREADS + threadIdx.x;
+    if (r >= R) return;
+    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    const int64_t b = (int64_t)r * S;
+    // forward: transmittance per sample (kept in scratch_t), depth and acc for the disparity chain
+    float T = 1.0f, depth = 0.0f, acc = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        float s = sigma[b + i];
+        if (transparent[b + i]) s = 0.0f;
+        if (noise) s += noise[b + i];
+        s = s > 0.0f ? s : 0.0f;
+        const float dist = (i + 1 < S ? z_vals[b + i + 1] - z_vals[b + i] : 1e10f) * dn;
+        const float alpha = 1.0f - expf(-s * dist);
+        scratch_t[b + i] = T;
+        const float w = alpha * T;
+        depth += w * z_vals[b + i];
+        acc += w;
+        T *= (1.0f - alpha) + 1e-10f;
+    }
+    float gd = d_depth ? d_depth[r] : 0.0f, ga = d_acc ? d_acc[r] : 0.0f;
+    if (d_disp) {   // disp = 1 / max(1e-10, depth / acc)
+        const float q = depth / acc;
+        if (q > 1e-10f) { gd += d_disp[r] * (-1.0f / (q * q * acc)); ga += d_disp[r] * (1.0f / (q * acc)); }
+    }
+    const float gr[3] = {d_rgb[3 * r], d_rgb[3 * r + 1], d_rgb[3 * r + 2]};
+    float suffix = 0.0f;   // sum_{k>i} Gw_k w_k
+    for (int i = S - 1; i >= 0; --i) {
+        float raw = sigma[b + i];
+        const bool tr = transparent[b + i] != 0;
+        if (tr) raw = 0.0f;
+        if (noise) raw += noise[b + i];
+        const float s = raw > 0.0f ? raw : 0.0f;
+        const float dist = (i + 1 < S ? z_vals[b + i + 1] - z_vals[b + i] : 1e10f) * dn;
+        const float e = expf(-s * dist);
+        const float alpha = 1.0f - e;
+        const float Ti = scratch_t[b + i];
+        const float w = alpha * Ti;
+        const float* c = colour + 3 * (b + i);
+        float gw = (gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2]) + gd * z_vals[b + i] + ga;
+        if (d_weights) gw += d_weights[b + i];
+        const float dalpha = gw * Ti - suffix / ((1.0f - alpha) + 1e-10f);
+        suffix += gw * w;
+        d_sigma[b + i] = (!tr && raw > 0.0f) ? dalpha * dist * e : 0.0f;
+        for (int k = 0; k < 3; ++k) d_colour[3 * (b + i) + k] = w * gr[k];
+    }
+}
+
+// colour = wl * essence, wl = ELU(pre) + 1:  d_essence, d_pre
+__global__ void __launch_bounds__(T_THREADS) k_t_colour_adjoint(const float* __restrict__ d_colour, const float* __restrict__ ess,
+                                                                 const float* __restrict__ wl, const float* __restrict__ pre,
+                                                                 int64_t N, float* __restrict__ d_ess, float* __restrict__ d_pre) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    float dw = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        const float dc = d_colour[3 * n + c];
+        d_ess[3 * n + c] = wl[n] * dc;
+        dw += ess[3 * n + c] * dc;
+    }
+    d_pre[n] = dw * (pre[n] > 0.0f ? 1.0f : wl[n]);   // ELU' = exp(pre) = wl for pre <= 0
+}
+
+// d_rr[n,c] = (rr > 0) ? sum_k d_ess[n,k] W[k,c] : 0      (rgb_net.3 transposed, model/spacenet.py:72-79)
+__global__ void __launch_bounds__(T_THREADS) k_t_rgb_hidden_adjoint(const float* __restrict__ d_ess, const float* __restrict__ w3,
+                                                                     const float* __restrict__ rr, int64_t total,
+                                                                     float* __restrict__ d_rr) {
+    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (t >= total) return;
+    const int64_t n = t >> 7;
+    const int c = (int)(t & 127);
+    const float v = d_ess[3 * n] * w3[c] + d_ess[3 * n + 1] * w3[128 + c] + d_ess[3 * n + 2] * w3[256 + c];
+    d_rr[t] = rr[t] > 0.0f ? v : 0.0f;
+}
+
+// u = (d n_w / d g)^T d_n_w   (model/spacenet.py:278-298; the two projections share the canonical face)
+__global__ void __launch_bounds__(T_THREADS) k_t_normal_adjoint(const DsnFaceRec* __restrict__ face_world,
+                                                                 const DsnFaceRec* __restrict__ face_canon,
+                                                                 const float* __restrict__ x_c, const float* __restrict__ g,
+                                                                 const int32_t* __restrict__ idx_c, const float* __restrict__ d_xl,
+                                                                 int64_t N, float* __restrict__ u) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const DsnFaceRec fc = dsn_load_face(face_canon, idx_c[n]);
+    const DsnFaceRec fw = dsn_load_face(face_world, idx_c[n]);
+    float p[3], pe[3], s[3], e[3], df[3], uu, vv, hh;
+    for (int c = 0; c < 3; ++c) { p[c] = x_c[3 * n + c]; pe[c] = p[c] + g[3 * n + c]; }
+    dsn_project(p, fc, uu, vv, hh);
+    dsn_map2face(uu, vv, hh, fw, s);
+    dsn_project(pe, fc, uu, vv, hh);
+    dsn_map2face(uu, vv, hh, fw, e);
+    for (int c = 0; c < 3; ++c) df[c] = e[c] - s[c];
+    const float nrm = dsn_norm3(df);
+    const float dn[3] = {d_xl[9 * n], d_xl[9 * n + 1], d_xl[9 * n + 2]};
+    float dd[3];
+    if (nrm >= 1e-12f) {
+        const float nh[3] = {df[0] / nrm, df[1] / nrm, df[2] / nrm};
+        const float dot = nh[0] * dn[0] + nh[1] * dn[1] + nh[2] * dn[2];
+        for (int c = 0; c < 3; ++c) dd[c] = (dn[c] - nh[c] * dot) / nrm;
+    } else {
+        for (int c = 0; c < 3; ++c) dd[c] = dn[c] / 1e-12f;
+    }
+    // delta = v20' (a.g) + v10' (b.g) + n' (n.g),  a = inv (d11 v20 - d01 v10),  b = inv (d00 v10 - d01 v20)
+    const float ka = dsn_dot3(fw.v20, dd), kb = dsn_dot3(fw.v10, dd), kn = dsn_dot3(fw.n, dd);
+    for (int c = 0; c < 3; ++c) {
+        const float a = fc.inv * (fc.d11 * fc.v20[c] - fc.d01 * fc.v10[c]);
+        const float b = fc.inv * (fc.d00 * fc.v10[c] - fc.d01 * fc.v20[c]);
+        u[3 * n + c] = a * ka + b * kb + fc.n[c] * kn;
+    }
+}
+
+// stage1.0: gradient of the 24 frame-constant input columns, the embedding row and the pose code, from the column
+// sums csum = sum_n ahat_0[n] (= d bias of stage1.0)
+__global__ void __launch_bounds__(256) k_t_first_layer_consts(const float* __restrict__ csum, const float* __restrict__ w0,
+                                                               const DsnFrameState* __restrict__ fs, int frame_idx,
+                                                               int zero_code, float* __restrict__ d_w0,
+                                                               float* __restrict__ d_emb, float* __restrict__ d_pose) {
+    const int t = threadIdx.x;   // output feature
+    const float c = csum[t];
+    for (int k = 0; k < 8; ++k) d_w0[t * 87 + k] += c * fs->code[k];
+    for (int k = 0; k < 16; ++k) d_w0[t * 87 + W0_POSE_COL + k] += c * fs->pose_feat[k];
+    __shared__ float s[256];
+    for (int k = 0; k < 24; ++k) {
+        const int col = k < 8 ? k : W0_POSE_COL + (k - 8);
+        s[t] = c * w0[t * 87 + col];
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (t < off) s[t] += s[t + off];
+            __syncthreads();
+        }
+        if (t == 0) {
+            if (k < 8) { if (!zero_code) d_emb[frame_idx * 8 + k] += s[0]; }
+            else d_pose[k - 8] = s[0];
+        }
+        __syncthreads();
+    }
+}
+
+// pose_mlp backward (model/spacenet.py:199-205, :314-331): one row, recomputed forward
+__global__ void __launch_bounds__(256) k_t_pose_mlp_adjoint(const float* __restrict__ w0, const float* __restrict__ b0,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const float* __restrict__ w4, const float* __restrict__ poses,
+                                                             const float* __restrict__ d_pose, float* __restrict__ gw0,
+                                                             float* __restrict__ gb0, float* __restrict__ gw2,
+                                                             float* __restrict__ gb2, float* __restrict__ gw4,
+                                                             float* __restrict__ gb4) {
+    __shared__ float q[92], h1[64], h2[64], dh1[64], dh2[64], dp[16];
+    const int t = threadIdx.x;
+    if (t < 23) {
+        const float* r = poses + 3 * (t + 1);
+        float a[3] = {r[0] + 1e-16f, r[1] + 1e-16f, r[2] + 1e-16f};
+        const float angle = dsn_norm3(a);
+        const float half = dsn_div(angle, 2.0f);
+        const float s = sinf(half), c = cosf(half);
+        q[4 * t + 0] = dsn_div(r[0], angle) * s;
+        q[4 * t + 1] = dsn_div(r[1], angle) * s;
+        q[4 * t + 2] = dsn_div(r[2], angle) * s;
+        q[4 * t + 3] = c - 1.0f;
+    }
+    if (t < 16) dp[t] = d_pose[t];
+    __syncthreads();
+    if (t < 64) {
+        float acc = b0[t];
+        for (int k = 0; k < 92; ++k) acc += w0[t * 92 + k] * q[k];
+        h1[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 64) {
+        float acc = b2[t];
+        for (int k = 0; k < 64; ++k) acc += w2[t * 64 + k] * h1[k];
+        h2[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 64) {
+        float acc = 0.f;
+        for (int o = 0; o < 16; ++o) acc += w4[o * 64 + t] * dp[o];
+        dh2[t] = h2[t] > 0.f ? acc : 0.f;
+    }
+    if (t < 16) gb4[t] += dp[t];
+    for (int i = t; i < 16 * 64; i += 256) gw4[i] += dp[i / 64] * h2[i % 64];
+    __syncthreads();
+    if (t < 64) {
+        float acc = 0.f;
+        for (int o = 0; o < 64; ++o) acc += w2[o * 64 + t] * dh2[o];
+        dh1[t] = h1[t] > 0.f ? acc : 0.f;
+        gb2[t] += dh2[t];
+    }
+    for (int i = t; i < 64 * 64; i += 256) gw2[i] += dh2[i / 64] * h1[i % 64];
+    __syncthreads();
+    if (t < 64) gb0[t] += dh1[t];
+    for (int i = t; i < 64 * 92; i += 256) gw0[i] += dh1[i / 92] * q[i % 92];
+}
+
+struct TrainWs {
+    uint8_t* transparent;
+    int32_t* idx_c;
+    float *x_c, *pe, *h[7], *ap[7], *rr, *ess, *sig, *g, *t0, *t1, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
+    float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
+    size_t bytes;
+};
+
+TrainWs carve(void* base, int64_t N) {
+    TrainWs w;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* q = p; p += dsn_align256(bytes); return q; };
+    const size_t n = (size_t)N;
+    w.transparent = (uint8_t*)take(n);
+    w.idx_c = (int32_t*)take(4 * n);
+    w.x_c = (float*)take(12 * n);
+    w.pe = (float*)take(4 * PE_LD * n);
+    for (int l = 0; l < 7; ++l) w.h[l] = (float*)take(1024 * n);
+    for (int l = 0; l < 7; ++l) w.ap[l] = (float*)take(1024 * n);
+    w.rr = (float*)take(512 * n);
+    w.ess = (float*)take(12 * n);
+    w.sig = (float*)take(4 * n);
+    w.g = (float*)take(12 * n);
+    w.t0 = (float*)take(1024 * n);
+    w.t1 = (float*)take(1024 * n);
+    w.tpe = (float*)take(4 * PE_LD * n);
+    w.n_w = (float*)take(12 * n);
+    w.xl = (float*)take(36 * n);
+    w.hl1 = (float*)take(512 * n);
+    w.hl2 = (float*)take(512 * n);
+    w.pre = (float*)take(4 * n);
+    w.wl = (float*)take(4 * n);
+    w.col = (float*)take(12 * n);
+    w.d_sig = (float*)take(4 * n);
+    w.d_col = (float*)take(12 * n);
+    w.d_ess = (float*)take(12 * n);
+    w.d_pre = (float*)take(4 * n);
+    w.d_hl2 = (float*)take(512 * n);
+    w.d_hl1 = (float*)take(512 * n);
+    w.d_xl = (float*)take(36 * n);
+    w.d_rr = (float*)take(512 * n);
+    w.u = (float*)take(12 * n);
+    w.scratch_t = (float*)take(4 * n);
+    w.small = (float*)take(4 * 1024);
+    w.bytes = (size_t)(p - (char*)base);
+    return w;
+}
+
+void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st) {
+    const int rows = 4096;
+    hipLaunchKernelGGL(k_t_colsum, dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, a, C, N, rows, out);
+}
+
+}  // namespace
+
+size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
+
+#define T_CHECK(x) do { if (!(x)) return #x; } while (0)
+
+// returns nullptr on success, else a static description of the step that failed
+const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const float* poses, int frame_idx, int zero_code,
+                          const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
+                          const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
+                          const float* d_weights, float* const* grd, void* workspace, hipStream_t st) {
+    const int64_t N64 = (int64_t)R * S;
+    if (N64 > (int64_t)1 << 30) return "batch too large for the 32-bit GEMM interface";
+    const int N = (int)N64;
+    rocblas_handle h = blas(st);
+    if (!h) return "rocBLAS handle";
+    TrainWs w = carve(workspace, N64);
+    for (int i = 0; i < 33; ++i)
+        if (hipMemsetAsync(grd[i], 0, sizeof(float) * (size_t)kParamCount[i], st) != hipSuccess) return "zeroing the gradients";
+    if (hipMemsetAsync(w.small, 0, 4 * 1024, st) != hipSuccess) return "zeroing scratch";
+
+    // ---- forward: warp, encoding, trunk, heads ------------------------------------------------------------
+    dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
+                    nullptr, false, st);
+    hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe);
+    const int64_t tot = N64 * 256;
+    for (int l = 0; l < 7; ++l) {
+        const float* W = prm[kTrunkW[l]];
+        if (l == 0) {
+            T_CHECK(lin_fwd(h, N, PE_K, 256, w.pe, PE_LD, W + W0_PE_COL, 87, w.h[0], 256, 0.0f));
+            hipLaunchKernelGGL(k_t_bias_relu, grid_for(tot), dim3(T_THREADS), 0, st, w.h[0], s.frame->bias0, 256, tot);
+        } else {
+            T_CHECK(lin_fwd(h, N, 256, 256, w.h[l - 1], 256, W, kTrunkLd[l], w.h[l], 256, 0.0f));
+            if (l == 4) T_CHECK(lin_fwd(h, N, PE_K, 256, w.pe, PE_LD, W + W4_PE_COL, 319, w.h[4], 256, 1.0f));
+            hipLaunchKernelGGL(k_t_bias_relu, grid_for(tot), dim3(T_THREADS), 0, st, w.h[l], prm[kTrunkB[l]], 256, tot);
+        }
+    }
+    const dim3 wave_grid((unsigned)((N64 + 3) / 4));
+    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.h[6], 256, prm[P_DEN_W], prm[P_DEN_B], 1, N64, w.sig);
+    T_CHECK(lin_fwd(h, N, 256, 128, w.h[6], 256, prm[P_RGB1_W], 256, w.rr, 128, 0.0f));
+    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.rr, prm[P_RGB1_B], 128, N64 * 128);
+    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.rr, 128, prm[P_RGB3_W], prm[P_RGB3_B], 3, N64, w.ess);
+
+    // ---- reverse pass for g = d sigma / d x_c; the masked adjoints a_l stay resident -------------------------
+    hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], nullptr, nullptr, 256, tot, w.ap[6]);
+    for (int l = 6; l >= 1; --l) {
+        T_CHECK(lin_bwd(h, N, 256, 256, w.ap[l], 256, prm[kTrunkW[l]], kTrunkLd[l], w.ap[l - 1], 256, 0.0f));
+        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, w.ap[l - 1], w.h[l - 1], tot);
+    }
+    T_CHECK(lin_bwd(h, N, PE_K, 256, w.ap[4], 256, prm[P_S2_0W] + W4_PE_COL, 319, w.tpe, PE_LD, 0.0f));
+    T_CHECK(lin_bwd(h, N, PE_K, 256, w.ap[0], 256, prm[P_S1_0W] + W0_PE_COL, 87, w.tpe, PE_LD, 1.0f));
+    hipLaunchKernelGGL(k_t_pe_reverse, grid_for(N64 * 3), dim3(T_THREADS), 0, st, w.x_c, w.tpe, N64, w.g);
+
+    // ---- normals, lighting, colour ---------------------------------------------------------------------------
+    dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
+    hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl);
+    T_CHECK(lin_fwd(h, N, 9, 128, w.xl, 9, prm[P_L0_W], 9, w.hl1, 128, 0.0f));
+    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl1, prm[P_L0_B], 128, N64 * 128);
+    T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
+    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
+    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
+    hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
+
+    // ---- adjoint of compositing and of the colour product ------------------------------------------------------
+    hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
+                       noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig);
+    hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, w.d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
+                       w.d_pre);
+
+    // ---- lighting MLP backward -----------------------------------------------------------------------------------
+    T_CHECK(lin_wgrad(h, N, 128, 1, w.hl2, 128, w.d_pre, 1, grd[P_L4_W], 128));
+    colsum(w.d_pre, 1, N64, grd[P_L4_B], st);
+    hipLaunchKernelGGL(k_t_seed, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
+                       w.d_hl2);
+    T_CHECK(lin_wgrad(h, N, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128));
+    colsum(w.d_hl2, 128, N64, grd[P_L2_B], st);
+    T_CHECK(lin_bwd(h, N, 128, 128, w.d_hl2, 128, prm[P_L2_W], 128, w.d_hl1, 128, 0.0f));
+    hipLaunchKernelGGL(k_t_mask, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
+    T_CHECK(lin_wgrad(h, N, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9));
+    colsum(w.d_hl1, 128, N64, grd[P_L0_B], st);
+    T_CHECK(lin_bwd(h, N, 9, 128, w.d_hl1, 128, prm[P_L0_W], 9, w.d_xl, 9, 0.0f));
+
+    // ---- u = dL/dg through the normal map, then the tangent pass (second-order term) ---------------------------
+    hipLaunchKernelGGL(k_t_normal_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, s.face_world, s.face_canon, w.x_c, w.g, w.idx_c,
+                       w.d_xl, N64, w.u);
+    hipLaunchKernelGGL(k_t_pe_tangent, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe);
+    float *cur = w.t0, *nxt = w.t1;
+    T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, prm[P_S1_0W] + W0_PE_COL, 87, cur, 256, 0.0f));
+    hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, cur, w.h[0], tot);
+    T_CHECK(lin_wgrad(h, N, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87));
+    for (int l = 1; l < 7; ++l) {
+        const float* W = prm[kTrunkW[l]];
+        T_CHECK(lin_fwd(h, N, 256, 256, cur, 256, W, kTrunkLd[l], nxt, 256, 0.0f));
+        T_CHECK(lin_wgrad(h, N, 256, 256, cur, 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l]));
+        if (l == 4) {
+            T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, W + W4_PE_COL, 319, nxt, 256, 1.0f));
+            T_CHECK(lin_wgrad(h, N, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319));
+        }
+        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l], tot);
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    colsum(cur, 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
+
+    // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
+    T_CHECK(lin_wgrad(h, N, 128, 3, w.rr, 128, w.d_ess, 3, grd[P_RGB3_W], 128));
+    colsum(w.d_ess, 3, N64, grd[P_RGB3_B], st);
+    hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
+                       w.d_rr);
+    T_CHECK(lin_wgrad(h, N, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256));
+    colsum(w.d_rr, 128, N64, grd[P_RGB1_B], st);
+    T_CHECK(lin_wgrad(h, N, 256, 1, w.h[6], 256, w.d_sig, 1, grd[P_DEN_W], 256));
+    colsum(w.d_sig, 1, N64, grd[P_DEN_B], st);
+    T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
+    hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
+    for (int l = 6; l >= 0; --l) {
+        float* gW = grd[kTrunkW[l]];
+        colsum(cur, 256, N64, l == 0 ? w.small : grd[kTrunkB[l]], st);
+        if (l == 0) {
+            T_CHECK(lin_wgrad(h, N, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W0_PE_COL, 87));
+            break;
+        }
+        T_CHECK(lin_wgrad(h, N, 256, 256, w.h[l - 1], 256, cur, 256, gW, kTrunkLd[l]));
+        if (l == 4) T_CHECK(lin_wgrad(h, N, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W4_PE_COL, 319));
+        T_CHECK(lin_bwd(h, N, 256, 256, cur, 256, prm[kTrunkW[l]], kTrunkLd[l], nxt, 256, 0.0f));
+        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l - 1], tot);
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
+    if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
+    hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,
+                       grd[P_S1_0W], grd[P_EMB], w.small + 256);
+    hipLaunchKernelGGL(k_t_pose_mlp_adjoint, dim3(1), dim3(256), 0, st, prm[P_PM0_W], prm[P_PM0_B], prm[P_PM2_W], prm[P_PM2_B],
+                       prm[P_PM4_W], poses, w.small + 256, grd[P_PM0_W], grd[P_PM0_B], grd[P_PM2_W], grd[P_PM2_B], grd[P_PM4_W],
+                       grd[P_PM4_B]);
+    return nullptr;
+}

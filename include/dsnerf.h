@@ -124,6 +124,23 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
 DSN_EXPORT int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
                     float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream);
 
+/* ---- training backward: what loss.backward() computes in trainer.py:70-81 -----------------
+ * Gradients of L w.r.t. the 33 parameters, given the cotangents of Renderer.render's outputs
+ * (utils/loss.py:17-27 uses color and acc_map): d_rgb [R,3] (required), d_disp / d_acc / d_depth [R] and
+ * d_weights [R,S] (optional, NULL = zero).  Inputs are what the forward call produced / consumed: z_vals [R,S] (the
+ * sampler's output, jitter included), noise [R,S] or NULL, the frame set by dsn_set_frame with the same parameters
+ * (frame_idx / zero_code / poses repeated here for the embedding and pose_mlp gradients).  params33_host / grads33_host
+ * are HOST arrays of 33 device pointers in state_dict order with torch Linear layouts; every gradient is overwritten.
+ * Includes the second-order path through d sigma/dx -> normal -> lighting (model/spacenet.py:251-265) as a forward
+ * tangent pass.  Evaluates the networks layer by layer in fp32 (rocBLAS GEMMs) with activations resident in
+ * `workspace` (dsn_grad_workspace_bytes(R,S), 16 KB per sample). */
+DSN_EXPORT size_t dsn_grad_workspace_bytes(int R, int S);
+DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const float* const* params33_host, const float* poses24x3,
+                         int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
+                         const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
+                         const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
+                         void* stream);
+
 /* ---- fused path: can_render.py:137-168 Renderer.render on R rays --------------------------
  * flags: DSN_SKIP_TRANSPARENT evaluates the networks only on non-transparent samples (exact in
  * eval mode: their sigma is forced to 0 and their colour is multiplied by weight 0; must not be

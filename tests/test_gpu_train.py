@@ -1,0 +1,118 @@
+"""GPU parity of the training row: parameter gradients of Renderer.render through the C ABI
+(dsn_render_rays_grad) against (a) gradients captured from the reference's own loss.backward()
+(tests/golden/*_grads.npz) and (b) the differentiable CPU oracle (oracle/train_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+import train_oracle as TO
+from helpers import load, state
+from test_gpu_render import make_batch, make_renderer
+
+pytestmark = pytest.mark.gpu
+
+GRAD_CASES = ["small_train_grads", "small_train_grads_nonoise", "full_train_grads"]
+FULL_LIMIT, SAMPLE = 20000, 4096
+
+
+def sample_index(n):                         # the sub-sampling rule of tests/golden/make_golden_grads.py
+    return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def reference_loss(out, target, occ):
+    """utils/loss.py:11-30 with LOSSwMask: MSE on colour + 0.1 * L1(acc with occupied rays forced to 1, occupancy);
+    trainer.py:73-76 sums the terms."""
+    loss = torch.nn.functional.mse_loss(out["color"], target)
+    acc = out["acc_map"]
+    acc[occ == 1] = 1                         # in place, as the reference does on the renderer's output
+    return loss + 0.1 * torch.nn.functional.l1_loss(acc, occ)
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_backward_matches_reference_autograd(name):
+    g = load(name)
+    r = make_renderer(g)
+    r.cfg.MODEL.raw_noise_std = float(g["raw_noise_std"])
+    r.train()
+    torch.manual_seed(int(g["seed"]))
+    out = r.render(make_batch(g))["coarse"]
+    assert np.array_equal(out["z_vals"].cpu().numpy(), g["render:z_vals"])
+    loss = reference_loss(out, torch.from_numpy(g["target_rgb"]).cuda(), torch.from_numpy(g["occupancy"]).cuda())
+    ref = float(g["loss"])
+    assert abs(float(loss) - ref) < 2e-6 * max(1.0, abs(ref)), (float(loss), ref)
+    r.net.zero_grad()
+    loss.backward()
+    worst = {}
+    for k, p in r.net.named_parameters():
+        assert p.grad is not None, k
+        a = p.grad.detach().cpu().numpy().reshape(-1)
+        a = a if a.size <= FULL_LIMIT else a[sample_index(a.size)]
+        b32, b64 = g["grad:" + k], g["grad:" + k + "_f64"]
+        # the reference's float32 and float64 runs differ by 1e-3 .. 4e-2 per tensor (ReLU-kink flips, PE x512):
+        # stay within twice that spread of the float32 reference, and within 2e-3 where the spread is smaller
+        tol = max(2e-3, 2.0 * rel(b32, b64))
+        worst[k] = (rel(a, b32), tol)
+        assert rel(a, b32) < tol, (k, rel(a, b32), tol)
+        assert abs(np.linalg.norm(p.grad.detach().cpu().numpy().astype(np.float64)) - float(g["norm:" + k])) \
+            < tol * float(g["norm:" + k]) + 1e-12, k
+    print({k: "%.1e" % v[0] for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("name", ["small_train_grads", "full_train_grads"])
+def test_backward_matches_oracle_all_cotangents(name):
+    """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) == autograd of the
+    CPU oracle on the same inputs, full tensors."""
+    from dsnerf_amd import _lib
+    g = load(name)
+    sd = state()
+    r = make_renderer(g)
+    z = g["render:z_vals"]
+    R, S = z.shape
+    noise = g["noise"] if float(g["raw_noise_std"]) > 0 else None
+    rng = np.random.default_rng(4)
+    cot = {k: rng.standard_normal(s).astype(np.float32) for k, s in
+           (("color", (R, 3)), ("disp_map", (R,)), ("acc_map", (R,)), ("depth_map", (R,)), ("weights", (R, S)))}
+    # oracle: L = sum(cotangent * output); disparity only where the ray hit something (NaN elsewhere, as the reference)
+    params = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    out = TO.render(params, g, jitter_z=z, noise=noise)
+    ok = out["acc_map"].detach() > 1e-3
+    cot["disp_map"] = np.where(ok.numpy(), cot["disp_map"] * 1e-2, 0.0).astype(np.float32)
+    L = sum((torch.from_numpy(cot[k]) * out[k]).sum() for k in ("color", "acc_map", "depth_map", "weights"))
+    L = L + (torch.from_numpy(cot["disp_map"])[ok] * out["disp_map"][ok]).sum()
+    L.backward()
+    dev = r.device
+    b = make_batch(g)
+    r._set_frame(b)
+    T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    grads = _lib.render_rays_grad(r.scene, {k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, T(g["poses"]),
+                                  int(g["frame"]), False, T(g["ray_o"]), T(g["ray_d"]), T(z), T(noise), T(cot["color"]),
+                                  T(cot["disp_map"]), T(cot["acc_map"]), T(cot["depth_map"]), T(cot["weights"]))
+    for k, gr in zip(_lib.PARAM_ORDER, grads):
+        want = params[k].grad.numpy() if params[k].grad is not None else np.zeros_like(sd[k])
+        e = rel(gr.cpu().numpy(), want)
+        assert e < 5e-3, (k, e)
+
+
+def test_training_steps_reduce_the_loss():
+    """trainer.py:66-81 in miniature: Adam on the mirror's parameters through render() -> loss -> backward()."""
+    g = load("small_train_grads")
+    r = make_renderer(g)
+    r.train()
+    target = torch.from_numpy(g["target_rgb"]).cuda()
+    opt = torch.optim.Adam(r.net.parameters(), lr=5e-4)
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        out = r.render(make_batch(g))["coarse"]
+        loss = torch.nn.functional.mse_loss(out["color"], target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses

@@ -109,3 +109,21 @@ def test_camera_rays_restatement():
     assert np.array_equal(mask, g["mask_at_box"]) and 0 < mask.sum() < mask.size
     assert np.array_equal(ro, g["ray_o"]) and np.array_equal(rd, g["ray_d"])
     assert np.array_equal(near[mask], g["near"]) and np.array_equal(far[mask], g["far"])
+
+
+@pytest.mark.parametrize("name", ["small_train_grads", "small_train_grads_nonoise", "full_train_grads"])
+def test_train_oracle_reproduces_reference_autograd(name):
+    """oracle/train_oracle.py (differentiable restatement, torch CPU) against the loss and the parameter gradients the
+    reference's own loss.backward() produced (tests/golden/make_golden_grads.py)."""
+    import train_oracle as TO
+    g = load(name)
+    noise = g["noise"] if float(g["raw_noise_std"]) > 0 else None
+    loss, grads, out = TO.loss_and_grads(state(), g, g["render:z_vals"], noise, g["target_rgb"], g["occupancy"])
+    assert abs(loss - float(g["loss"])) < 1e-6
+    assert maxdiff(out["color"], g["render:color"]) < 1e-5
+    idx = lambda n: (np.arange(4096, dtype=np.int64) * 2654435761 + 12345) % n
+    for k, a in grads.items():
+        a = a.reshape(-1).astype(np.float64)
+        a = a if a.size <= 20000 else a[idx(a.size)]
+        b = g["grad:" + k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-12, k
