@@ -51,6 +51,14 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays the CPU oracle is timed on (0 = sized for ~15 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
+                         "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
+    ap.add_argument("--train-rays", type=int, default=8192)
+    ap.add_argument("--eager-baseline", action="store_true",
+                    help="secondary mode: time the eager-PyTorch restatement of the path (oracle/train_oracle.py) on this GPU "
+                         "the way the reference runs it (3072-ray chunks; 8192-ray training step), nearest-face searches "
+                         "excluded - SURVEY 8d baseline (i)")
     return ap.parse_args()
 
 
@@ -70,6 +78,10 @@ def main():
     import dsnerf_amd
     from dsnerf_amd import _lib, synth
 
+    if args.train:
+        return train_bench(args, dsnerf_amd, synth, dev, world, rank)
+    if args.eager_baseline:
+        return eager_baseline(args, _lib, synth, dev)
     H = W = args.hw
     S = args.samples
     R = H * W
@@ -161,6 +173,144 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_bench(args, dsnerf_amd, synth, dev, world, rank):
+    """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
+    backward (dsn_render_rays_grad), Adam step.  Every rank trains on its own batch (no gradient all-reduce: the
+    reference has no data-parallel training either); value = rays per second over all ranks."""
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    S, R = args.samples, args.train_rays
+    canon, faces = synth.make_body()
+    sd = synth.make_state_dict()
+    xyz = synth.pose_body(canon, seed=3 + rank)
+    rays = synth.make_rays(args.hw, args.hw, xyz, fit_box=True)
+    sel = np.linspace(0, args.hw * args.hw - 1, R).astype(np.int64)
+    cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
+                          MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0, raw_noise_std=1.0,
+                                                TYPE="nerf", FINE_RAY_SAMPLING=-1))
+    net = dsnerf_amd.DualSpaceNeRF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(dev)
+    r = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+    r.train()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    batch = {"ray_o": T(rays["ray_o"][sel])[None], "ray_d": T(rays["ray_d"][sel])[None], "near": T(rays["near"][sel])[None],
+             "far": T(rays["far"][sel])[None], "xyz": T(xyz)[None], "poses": T(synth.make_poses(seed=5 + rank))[None],
+             "Th": torch.zeros(1, 1, 3, device=dev), "frame": torch.tensor([5])}
+    target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32))
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    torch.manual_seed(233)
+    loss = None
+
+    def step():
+        nonlocal loss
+        opt.zero_grad()
+        out = r.render(batch)["coarse"]
+        loss = torch.nn.functional.mse_loss(out["color"], target)
+        loss.backward()
+        opt.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        flop = 6.0 * FLOP_FIELD_PER_SAMPLE / 2.0 * R * S     # fwd, reverse, tangent, adjoint, 2 weight-gradient products
+        print(json.dumps({
+            "metric": "training rays/sec (64 samples/ray, forward + backward + Adam step)", "value": world * R * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training step on {R} rays x {S} samples per GPU (BASELINE configs[2]), dense evaluation "
+                                   f"(jitter + noise), synthetic body V=6890/F=13776", "final_loss": float(loss),
+                       "approx_algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def eager_baseline(args, _lib, synth, dev):
+    """Stand-in for "the reference on one MI355X" (it cannot travel): the differentiable torch restatement the tests
+    use as their oracle, run with eager PyTorch-ROCm on this GPU.  The parameter-independent geometry (sampling, both
+    nearest-face searches, warp) is taken from the HIP kernels and NOT timed, which favours the baseline: in the
+    reference those are pytorch3d knn_points calls over 13 776 centroids per sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import train_oracle as TO
+    H = W = args.hw
+    S = args.samples
+    canon, faces = synth.make_body()
+    sd = synth.make_state_dict()
+    poses = synth.make_poses(seed=5)
+    xyz = synth.pose_body(canon, seed=3)
+    rays = synth.make_rays(H, W, xyz, fit_box=True)
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    scene.set_frame(packed, torch.from_numpy(xyz), torch.from_numpy(poses), 5, False, None, None, None)
+    t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    base = {"xyz": xyz, "canonical_vertex": canon, "faces": faces, "poses": poses, "frame": 5}
+
+    def prepare(sel):
+        o, d = T(rays["ray_o"][sel]), T(rays["ray_d"][sel])
+        near, far = T(rays["near"][sel]), T(rays["far"][sel])
+        pts, z = _lib.sample(scene, o, d, near, far, S, t_vals, None, want_pts=True)
+        w = _lib.warp(scene, pts, d, S, want_dir=False)
+        sig, ess, gr = _lib.field(scene, packed, w["x_c"])
+        idx, _nw, _col = _lib.shade(scene, packed, w["x_c"], gr, pts, d, ess, S)
+        g = dict(base, ray_o=rays["ray_o"][sel], ray_d=rays["ray_d"][sel])
+        geom = {"x_c": w["x_c"].reshape(-1, 3), "transparent": w["transparent"].reshape(-1).bool(), "idx_canon": idx.long()}
+        return g, z.cpu().numpy(), geom
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # eval: one 3072-ray chunk of the frame (can_render.py:172-245 processes 86 of them per 512x512 frame)
+    chunk = 3072
+    sel = np.arange(H * W // 2, H * W // 2 + chunk)
+    g, z, geom = prepare(sel)
+    params = {k: T(v) for k, v in sd.items()}
+    t_eval = timed(lambda: TO.render(params, g, jitter_z=z, geom=geom), 5)
+    # train: forward + backward of an MSE loss on 8192 rays (trainer.py:70-81)
+    R = args.train_rays
+    sel = np.linspace(0, H * W - 1, R).astype(np.int64)
+    g2, z2, geom2 = prepare(sel)
+    pt = {k: T(v).requires_grad_(True) for k, v in sd.items()}
+    target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32))
+
+    def train_step():
+        for p in pt.values():
+            p.grad = None
+        out = TO.render(pt, g2, jitter_z=z2, geom=geom2)
+        torch.nn.functional.mse_loss(out["color"], target).backward()
+
+    t_train = timed(train_step, 3)
+    print(json.dumps({"metric": "eager-PyTorch baseline on this GPU (network, normals, lighting, compositing; nearest-face "
+                                "searches excluded)", "eval_rays_per_s": chunk / t_eval, "eval_ms_per_3072_ray_chunk": 1e3 * t_eval,
+                      "eval_ms_per_512x512_frame": 1e3 * t_eval * (H * W / chunk), "train_rays_per_s": R / t_train,
+                      "train_ms_per_step": 1e3 * t_train, "train_rays": R, "samples_per_ray": S, "kind": "port",
+                      "torch": torch.__version__}))
 
 
 def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):

@@ -17,9 +17,11 @@
 //           face are affine in the point (utils/geo_utils.py:96-113,138-156,181-200), then F.normalize.
 //
 // First implementation of this row: layer-by-layer, activations of one training batch resident in HBM (16 KB per
-// sample - 8.6 GB for the 8192 x 64 batch of BASELINE configs[2], sized for 288 GB), the dense contractions are
-// plain fp32 GEMMs handed to rocBLAS (forward, reverse, tangent, adjoint and the two weight-gradient products per
-// layer), everything else is the kernels below.  Fusing these passes like k_field16 is the follow-up.
+// sample - 8.6 GB for the 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The activation-times-weight
+// products (forward, reverse, tangent, adjoint) are plain fp32 GEMMs handed to rocBLAS; the weight-gradient
+// products, which contract over the half-million samples of the batch, run on the hand-written exact-fp32 MFMA
+// kernel k_t_wgrad below; everything else is element-wise kernels.  Fusing these passes like k_field16 is the
+// follow-up.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
 #include <rocblas/rocblas.h>
@@ -444,6 +446,101 @@ __global__ void __launch_bounds__(256) k_t_pose_mlp_adjoint(const float* __restr
     for (int i = t; i < 64 * 92; i += 256) gw0[i] += dh1[i / 92] * q[i % 92];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// weight-gradient product  dW [out,in] += dY^T X  over N samples (the contraction index): exact-fp32 MFMA.
+// rocBLAS' fp32 GEMM for this shape (256 x 256 output, K = 524 288) runs at 22 TFLOP/s; here the sample axis is
+// split over one workgroup per CU, each wave keeps OT x IT 32x32 accumulator tiles in registers for its whole chunk,
+// and both operands are read straight from their row-major [N,C] arrays in MFMA operand layout: lane l supplies
+// dY[n + (l>>5)][o0 + (l&31)] as A and X[n + (l>>5)][j0 + (l&31)] as B - two coalesced 128-byte rows per load, no
+// LDS, no transposes.  Partial tiles are combined with fp32 atomics (256 workgroups -> 16.7 M atomics per product).
+// ------------------------------------------------------------------------------------------------------------
+typedef float t_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int OT, int IT, int WO, int WI>
+__global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
+                                                  int64_t N, int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wo = wave / WI, wi = wave % WI;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t n1 = n0 + rows_per_wg;
+    if (n1 > N) n1 = N;
+    t_f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const float* pa = dY + (wo * OT) * 32 + col;
+    const float* pb = X + (wi * IT) * 32 + col;
+    // DEPTH contraction steps (2 samples each) are in flight ahead of the matrix pipe: at 16 MFMAs x 64 cycles per
+    // step a single step of look-ahead (0.5 us) is shorter than the HBM latency under load
+    constexpr int DEPTH = (OT * IT >= 16) ? 4 : 8;
+    float af[DEPTH][OT], bf[DEPTH][IT], an[DEPTH][OT], bn[DEPTH][IT];
+    auto load = [&](int64_t n, float (*fa)[OT], float (*fb)[IT]) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int64_t row = n + 2 * s + half;
+            const bool ok = row < n1;
+#pragma unroll
+            for (int a = 0; a < OT; ++a) fa[s][a] = ok ? pa[row * ldy + a * 32] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < IT; ++b) fb[s][b] = (ok && (wi * IT + b) * 32 + col < in_valid) ? pb[row * ldx + b * 32] : 0.0f;
+        }
+    };
+    if (n0 < n1) load(n0, af, bf);
+    for (int64_t n = n0; n < n1; n += 2 * DEPTH) {
+        load(n + 2 * DEPTH, an, bn);   // rows beyond the chunk read as zero
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s)
+#pragma unroll
+            for (int a = 0; a < OT; ++a)
+#pragma unroll
+                for (int b = 0; b < IT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+#pragma unroll
+            for (int a = 0; a < OT; ++a) af[s][a] = an[s][a];
+#pragma unroll
+            for (int b = 0; b < IT; ++b) bf[s][b] = bn[s][b];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b) {
+            const int j = (wi * IT + b) * 32 + col;
+            if (j >= in_valid) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (wo * OT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r]);
+            }
+        }
+}
+
+// dW [out,in] += dY[N,out]^T X[N,in]; out in {128,256}, padded in (multiple of 32) in {32,64,128,256}, in_valid <= in
+// (columns >= in_valid are neither read nor written)
+bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ldx, const float* dY, int ldy, float* dW, int ldw,
+                hipStream_t st) {
+    int groups = (out == 256 && in == 256) ? 256 : 768;   // the smaller tiles leave room for 3 workgroups per CU
+    int rows = (int)((N + groups - 1) / groups);
+    if (rows < 64) rows = 64;
+    rows = (rows + 1) & ~1;
+    groups = (int)((N + rows - 1) / rows);
+    const dim3 g((unsigned)groups), b(256);
+    if (out == 256 && in == 256) hipLaunchKernelGGL((k_t_wgrad<4, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    else if (out == 256 && in == 64) hipLaunchKernelGGL((k_t_wgrad<2, 2, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    else if (out == 128 && in == 256) hipLaunchKernelGGL((k_t_wgrad<2, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    else if (out == 128 && in == 128) hipLaunchKernelGGL((k_t_wgrad<2, 2, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    else if (out == 128 && in == 32) hipLaunchKernelGGL((k_t_wgrad<1, 1, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    else return false;
+    return true;
+}
+
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
@@ -493,7 +590,7 @@ TrainWs carve(void* base, int64_t N) {
 }
 
 void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st) {
-    const int rows = 4096;
+    const int rows = 256;
     hipLaunchKernelGGL(k_t_colsum, dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, a, C, N, rows, out);
 }
 
@@ -571,11 +668,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
     colsum(w.d_pre, 1, N64, grd[P_L4_B], st);
     hipLaunchKernelGGL(k_t_seed, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                        w.d_hl2);
-    T_CHECK(lin_wgrad(h, N, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128));
+    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st));
     colsum(w.d_hl2, 128, N64, grd[P_L2_B], st);
     T_CHECK(lin_bwd(h, N, 128, 128, w.d_hl2, 128, prm[P_L2_W], 128, w.d_hl1, 128, 0.0f));
     hipLaunchKernelGGL(k_t_mask, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
-    T_CHECK(lin_wgrad(h, N, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9));
+    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st));
     colsum(w.d_hl1, 128, N64, grd[P_L0_B], st);
     T_CHECK(lin_bwd(h, N, 9, 128, w.d_hl1, 128, prm[P_L0_W], 9, w.d_xl, 9, 0.0f));
 
@@ -586,14 +683,14 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
     float *cur = w.t0, *nxt = w.t1;
     T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, prm[P_S1_0W] + W0_PE_COL, 87, cur, 256, 0.0f));
     hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, cur, w.h[0], tot);
-    T_CHECK(lin_wgrad(h, N, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87));
+    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87, st));
     for (int l = 1; l < 7; ++l) {
         const float* W = prm[kTrunkW[l]];
         T_CHECK(lin_fwd(h, N, 256, 256, cur, 256, W, kTrunkLd[l], nxt, 256, 0.0f));
-        T_CHECK(lin_wgrad(h, N, 256, 256, cur, 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l]));
+        T_CHECK(wgrad_mfma(N64, 256, 256, 256, cur, 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l], st));
         if (l == 4) {
             T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, W + W4_PE_COL, 319, nxt, 256, 1.0f));
-            T_CHECK(lin_wgrad(h, N, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319));
+            T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
         }
         hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l], tot);
         float* tmp = cur; cur = nxt; nxt = tmp;
@@ -605,7 +702,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
     colsum(w.d_ess, 3, N64, grd[P_RGB3_B], st);
     hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                        w.d_rr);
-    T_CHECK(lin_wgrad(h, N, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256));
+    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st));
     colsum(w.d_rr, 128, N64, grd[P_RGB1_B], st);
     T_CHECK(lin_wgrad(h, N, 256, 1, w.h[6], 256, w.d_sig, 1, grd[P_DEN_W], 256));
     colsum(w.d_sig, 1, N64, grd[P_DEN_B], st);
@@ -615,11 +712,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
         float* gW = grd[kTrunkW[l]];
         colsum(cur, 256, N64, l == 0 ? w.small : grd[kTrunkB[l]], st);
         if (l == 0) {
-            T_CHECK(lin_wgrad(h, N, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W0_PE_COL, 87));
+            T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W0_PE_COL, 87, st));
             break;
         }
-        T_CHECK(lin_wgrad(h, N, 256, 256, w.h[l - 1], 256, cur, 256, gW, kTrunkLd[l]));
-        if (l == 4) T_CHECK(lin_wgrad(h, N, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W4_PE_COL, 319));
+        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.h[l - 1], 256, cur, 256, gW, kTrunkLd[l], st));
+        if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W4_PE_COL, 319, st));
         T_CHECK(lin_bwd(h, N, 256, 256, cur, 256, prm[kTrunkW[l]], kTrunkLd[l], nxt, 256, 0.0f));
         hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l - 1], tot);
         float* tmp = cur; cur = nxt; nxt = tmp;

@@ -45,7 +45,7 @@ def linear(p, prefix, x):
 
 def face_frames(verts, faces, dtype):
     """Per-face constants of utils/geo_utils.py:96-113,138-156,181-200 (float32 values of the mesh, cast)."""
-    v = _t(verts, dtype)
+    v = torch.from_numpy(np.ascontiguousarray(verts)).to(dtype)
     f = torch.from_numpy(np.asarray(faces, np.int64))
     v0, v1, v2 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
     e1, e2 = v1 - v0, v2 - v0
@@ -70,17 +70,26 @@ def embed(u, v, h, fr):
     return v0 + u[:, None] * e2 + v[:, None] * e1 + h[:, None] * n
 
 
-def render(params: dict, g: dict, jitter_z=None, noise=None, zero_code=False, dtype=torch.float32):
+def render(params: dict, g: dict, jitter_z=None, noise=None, zero_code=False, dtype=torch.float32, geom=None):
     """params: name -> torch tensor (requires_grad as wanted); g: batch arrays (ray_o, ray_d, xyz, canonical_vertex,
     faces, poses, frame) and z_vals [R,S] (the sampler's output, float32).  Returns the outputs of
-    can_render.py:137-168 as torch tensors attached to the graph."""
+    can_render.py:137-168 as torch tensors attached to the graph.
+    geom (optional, used by bench.py's eager-torch baseline): precomputed parameter-independent geometry as torch
+    tensors {x_c [N,3], transparent [N] bool, idx_canon [N] int64} on the device the parameters live on; the
+    nearest-face searches are then NOT part of what runs here."""
     z = np.ascontiguousarray(jitter_z, np.float32)
     R, S = z.shape
     o, d = np.asarray(g["ray_o"], np.float32), np.asarray(g["ray_d"], np.float32)
     pts = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)          # utils/pts_utils.py:14
-    wp = O.warp(pts.reshape(-1, 3), None, g["xyz"], g["canonical_vertex"], g["faces"])    # can_render.py:333-379
-    x_c = _t(wp["x_c"], dtype).requires_grad_(True)                                     # model/spacenet.py:220
-    transparent = torch.from_numpy(wp["transparent"])
+    dev = torch.device("cpu") if geom is None else geom["x_c"].device
+    _t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)   # noqa: E731
+    if geom is None:
+        wp = O.warp(pts.reshape(-1, 3), None, g["xyz"], g["canonical_vertex"], g["faces"])    # can_render.py:333-379
+        cent = O.centroids(g["canonical_vertex"], g["faces"])
+        geom = {"x_c": _t(wp["x_c"], dtype), "transparent": torch.from_numpy(wp["transparent"]),
+                "idx_canon": torch.from_numpy(O.nearest_face(wp["x_c"], cent).astype(np.int64))}
+    x_c = geom["x_c"].to(dtype).detach().requires_grad_(True)                           # model/spacenet.py:220
+    transparent = geom["transparent"]
     N = R * S
 
     # model/spacenet.py:223-236 pose code, :125-129 frame code
@@ -102,10 +111,9 @@ def render(params: dict, g: dict, jitter_z=None, noise=None, zero_code=False, dt
     # model/spacenet.py:301-311
     grad = torch.autograd.grad(sigma.sum(), x_c, create_graph=True)[0]
     # model/spacenet.py:278-298: nearest canonical face (a constant index), both points through the same face pair
-    cent = O.centroids(g["canonical_vertex"], g["faces"])
-    idx = torch.from_numpy(O.nearest_face(wp["x_c"], cent).astype(np.int64))
-    fc = tuple(t[idx] for t in face_frames(g["canonical_vertex"], g["faces"], dtype))
-    fw = tuple(t[idx] for t in face_frames(g["xyz"], g["faces"], dtype))
+    idx = geom["idx_canon"]
+    fc = tuple(t.to(dev)[idx] for t in face_frames(g["canonical_vertex"], g["faces"], dtype))
+    fw = tuple(t.to(dev)[idx] for t in face_frames(g["xyz"], g["faces"], dtype))
     start = embed(*project(x_c, fc), fw)
     end = embed(*project(x_c + grad, fc), fw)
     n_w = torch.nn.functional.normalize(end - start, dim=-1)
@@ -122,12 +130,12 @@ def render(params: dict, g: dict, jitter_z=None, noise=None, zero_code=False, dt
     sig = sigma.reshape(R, S)
     sig = torch.where(transparent.reshape(R, S), torch.zeros_like(sig), sig)
     zt = _t(z, dtype)
-    dists = torch.cat([zt[:, 1:] - zt[:, :-1], torch.full((R, 1), 1e10, dtype=dtype)], dim=-1)
+    dists = torch.cat([zt[:, 1:] - zt[:, :-1], torch.full((R, 1), 1e10, dtype=dtype, device=dev)], dim=-1)
     dists = dists * torch.norm(dd, dim=-1, keepdim=True)
     if noise is not None:
         sig = sig + _t(noise, dtype)
     alpha = 1.0 - torch.exp(-torch.relu(sig) * dists)
-    T = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=dtype), 1.0 - alpha + 1e-10], dim=-1), dim=-1)[:, :-1]
+    T = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=dtype, device=dev), 1.0 - alpha + 1e-10], dim=-1), dim=-1)[:, :-1]
     weights = alpha * T
     rgb = (weights[:, :, None] * colour.reshape(R, S, 3)).sum(1)
     depth = (weights * zt).sum(-1)
