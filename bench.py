@@ -177,8 +177,9 @@ def main():
 
 def train_bench(args, dsnerf_amd, synth, dev, world, rank):
     """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
-    backward (dsn_render_rays_grad), Adam step.  Every rank trains on its own batch (no gradient all-reduce: the
-    reference has no data-parallel training either); value = rays per second over all ranks."""
+    backward (dsn_render_rays_grad), Adam step.  With N>1 every rank renders its own 8192-ray batch of the step and
+    the 33 gradients are averaged with ONE 2 MB RCCL all-reduce (parallel.RayParallel.average_gradients) before the
+    optimizer step - plain data parallelism (the reference itself trains on one GPU); value = rays/s over all ranks."""
     from types import SimpleNamespace
     import torch.distributed as dist
     S, R = args.samples, args.train_rays
@@ -201,8 +202,9 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank):
              "Th": torch.zeros(1, 1, 3, device=dev), "frame": torch.tensor([5])}
     target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
-    torch.manual_seed(233)
+    torch.manual_seed(233 + rank)
     loss = None
+    rp = dsnerf_amd.RayParallel()
 
     def step():
         nonlocal loss
@@ -210,6 +212,7 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank):
         out = r.render(batch)["coarse"]
         loss = torch.nn.functional.mse_loss(out["color"], target)
         loss.backward()
+        rp.average_gradients(net.parameters())
         opt.step()
 
     def barrier():

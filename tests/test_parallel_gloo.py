@@ -68,3 +68,43 @@ def test_single_process_is_identity():
     assert rp.world == 1 and rp.shard(9) == (0, 9)
     x = torch.arange(12.0).reshape(4, 3)
     assert rp.gather(x, 4) is x
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("par", os.path.join(root, "dual-space-nerf_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(par)
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    ps[0].grad = torch.full((3, 4), float(rank + 1))
+    ps[1].grad = torch.arange(5.0) * (rank + 1)
+    # ps[2] has no gradient on rank 0 (counts as zeros), ones on rank 1
+    if rank == 1:
+        ps[2].grad = torch.ones(2, 2)
+    par.RayParallel().average_gradients(ps)
+    ok = (torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[1].grad, torch.arange(5.0) * 1.5)
+          and torch.allclose(ps[2].grad, torch.full((2, 2), 0.5)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_average_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
