@@ -34,7 +34,8 @@ EXPORTS = [
     "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
-    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
+    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -54,7 +55,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
         for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
-                  "dsn_grad_workspace_bytes"):
+                  "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
         _lib = L
     return _lib
@@ -344,6 +345,37 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
                                       _ptr(buf), _stream()), "dsn_render_rays_grad")
     scene._keep_grad = (prm, args, poses)
     return grads
+
+
+def image_scatter(out: dict, mask_at_box, H, W, clamp=False):
+    """post_process on the device (utils/render_utils.py:466-472): compacted per-ray outputs -> [H,W,*] images with
+    zeros outside mask_at_box.  out: dict with color [R,3], disp_map, acc_map, depth_map [R] (device)."""
+    dev = out["color"].device
+    mask = mask_at_box.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
+    R = out["color"].shape[0]
+    ws = torch.empty(lib().dsn_image_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    img = {k: torch.empty(H, W, c, dtype=torch.float32, device=dev) for k, c in
+           (("coarse_color", 3), ("coarse_disp", 1), ("coarse_acc", 1), ("coarse_depth", 1))}
+    _check(lib().dsn_image_scatter(_ptr(out["color"], torch.float32), _ptr(out["disp_map"]), _ptr(out["acc_map"]),
+                                   _ptr(out["depth_map"]), R, _ptr(mask), H, W, int(bool(clamp)), _ptr(img["coarse_color"]),
+                                   _ptr(img["coarse_disp"]), _ptr(img["coarse_acc"]), _ptr(img["coarse_depth"]), _ptr(ws),
+                                   _stream()), "dsn_image_scatter")
+    return img
+
+
+def image_psnr(img_rgb, gt, mask_at_box=None):
+    """metrics.py:8-21 on the device: returns a float64 device tensor {mse_all, mse_masked, psnr_all, psnr_masked}."""
+    dev = img_rgb.device
+    H, W = img_rgb.shape[:2]
+    gt = gt.reshape(H, W, 3).to(dev).contiguous()
+    assert gt.dtype in (torch.float64, torch.float32)
+    mask = None if mask_at_box is None else mask_at_box.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
+    ws = torch.empty(lib().dsn_image_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    g64, g32 = (gt, None) if gt.dtype == torch.float64 else (None, gt)
+    _check(lib().dsn_image_psnr(_ptr(img_rgb.contiguous(), torch.float32), _ptr(g64), _ptr(g32), _ptr(mask), H, W, _ptr(out),
+                                _ptr(ws), _stream()), "dsn_image_psnr")
+    return out
 
 
 def camera_rays(K, R, T, bounds, H, W, device=None):

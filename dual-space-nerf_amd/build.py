@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dsn_api.hip", "dsn_geom.hip", "dsn_nn.hip", "dsn_field.hip", "dsn_field16.hip", "dsn_train.hip"]
+SOURCES = ["dsn_api.hip", "dsn_geom.hip", "dsn_nn.hip", "dsn_field.hip", "dsn_field16.hip", "dsn_train.hip", "dsn_image.hip"]
 HEADERS = ["dsn_common.h", "dsn_nn.h", "dsn_kernels.h", os.path.join("..", "..", "include", "dsnerf.h")]
 LIB = os.path.join(HERE, "libdsnerf_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",

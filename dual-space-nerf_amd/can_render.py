@@ -276,17 +276,27 @@ class Renderer:
         coarse = {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
         return coarse, {}
 
-    def render_view(self, batch, chunk=None):
+    def render_view(self, batch, chunk=None, device_output=False):
+        """device_output=True (not in the reference) keeps the [H,W,*] images on the GPU - for multi-frame sequences
+        (novel_pose_vis.py:41-66) and on-device metrics (`image_metrics`)."""
         coarse, _ = self.batchify_rays_view(batch["ray_o"], batch["ray_d"], batch["near"], batch["far"], batch, chunk)
         _, H, W, _ = batch["img"].shape
-        mask = batch["mask_at_box"][0].to(self.device).bool()
-        # utils/render_utils.py:466-472 post_process, done on the device; ONE device->host copy
-        packed = torch.zeros(H * W, 6, dtype=torch.float32, device=self.device)
-        packed[mask] = torch.cat([coarse["color"], coarse["disp_map"][:, None], coarse["acc_map"][:, None],
-                                  coarse["depth_map"][:, None]], dim=1)
-        img = packed.cpu().reshape(H, W, 6)
-        return {"coarse_color": img[..., 0:3].contiguous(), "coarse_disp": img[..., 3:4].contiguous(),
-                "coarse_acc": img[..., 4:5].contiguous(), "coarse_depth": img[..., 5:6].contiguous()}
+        # utils/render_utils.py:466-472 post_process, done on the device (dsn_image_scatter); ONE device->host copy
+        img = _lib.image_scatter(coarse, batch["mask_at_box"][0], H, W)
+        if device_output:
+            return img
+        packed = torch.cat([img["coarse_color"], img["coarse_disp"], img["coarse_acc"], img["coarse_depth"]], dim=-1).cpu()
+        return {"coarse_color": packed[..., 0:3].contiguous(), "coarse_disp": packed[..., 3:4].contiguous(),
+                "coarse_acc": packed[..., 4:5].contiguous(), "coarse_depth": packed[..., 5:6].contiguous()}
+
+    def image_metrics(self, color_img, batch, clamp=True):
+        """test.py:62-71 on the device: clamp to [0,1], psnr with and without mask_at_box against batch["img"].
+        Returns a dict of python floats (one 32-byte device->host copy)."""
+        img = color_img.to(self.device)
+        if clamp:
+            img = torch.clamp(img, min=0.0, max=1.0)
+        m = _lib.image_psnr(img, batch["img"][0], batch["mask_at_box"][0]).cpu()
+        return {"mse": float(m[0]), "mse_wMask": float(m[1]), "psnr_woMask": float(m[2]), "psnr_wMask": float(m[3])}
 
     # ---- density query for marching cubes (reference :280-296) ----
     def query_volume(self, pts, code_idx, transparent_mask=None, batch_info={}):

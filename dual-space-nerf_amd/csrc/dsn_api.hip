@@ -185,6 +185,29 @@ int dsn_composite(const float* colour, const float* sigma, const uint8_t* transp
     return dsn_check_launch("dsn_composite");
 }
 
+size_t dsn_image_workspace_bytes(int H, int W) { return (H > 0 && W > 0) ? dsn_image_workspace_size(H, W) : 0; }
+
+int dsn_image_scatter(const float* rgb, const float* disp, const float* acc, const float* depth, int R, const uint8_t* mask_at_box,
+                      int H, int W, int clamp_rgb, float* img_rgb, float* img_disp, float* img_acc, float* img_depth,
+                      void* workspace, void* stream) {
+    DSN_REQUIRE((rgb || R == 0) && mask_at_box && img_rgb && workspace, "dsn_image_scatter: null argument");
+    DSN_REQUIRE(H > 0 && W > 0 && R >= 0, "dsn_image_scatter: bad sizes");
+    DSN_REQUIRE((int64_t)H * W < ((int64_t)1 << 31), "dsn_image_scatter: image too large");
+    DSN_REQUIRE(R == 0 || ((!img_disp || disp) && (!img_acc || acc) && (!img_depth || depth)), "dsn_image_scatter: image requested without its source");
+    dsn_launch_image_scatter(rgb, disp, acc, depth, R, mask_at_box, H, W, clamp_rgb, img_rgb, img_disp, img_acc, img_depth,
+                             workspace, (hipStream_t)stream);
+    return dsn_check_launch("dsn_image_scatter");
+}
+
+int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f32, const uint8_t* mask_at_box, int H, int W,
+                   double* out4, void* workspace, void* stream) {
+    DSN_REQUIRE(img_rgb && out4 && workspace, "dsn_image_psnr: null argument");
+    DSN_REQUIRE((gt_f64 != nullptr) != (gt_f32 != nullptr), "dsn_image_psnr: exactly one ground-truth pointer");
+    DSN_REQUIRE(H > 0 && W > 0, "dsn_image_psnr: bad sizes");
+    dsn_launch_image_psnr(img_rgb, gt_f64, gt_f32, mask_at_box, H, W, out4, workspace, (hipStream_t)stream);
+    return dsn_check_launch("dsn_image_psnr");
+}
+
 size_t dsn_grad_workspace_bytes(int R, int S) { return (R > 0 && S > 0) ? dsn_train_workspace_size((int64_t)R * S) : 0; }
 
 int dsn_render_rays_grad(const void* scene, int V, int F, const float* const* params33_host, const float* poses24x3,

@@ -52,3 +52,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* params33, c
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
                           const float* d_weights, float* const* grads33, void* workspace, hipStream_t st);
+
+// dsn_image.hip: image epilogue on the device (post_process scatter, clamp, mse / psnr)
+size_t dsn_image_workspace_size(int H, int W);
+void dsn_launch_image_scatter(const float* rgb, const float* disp, const float* acc, const float* depth, int R,
+                              const uint8_t* mask, int H, int W, int clamp_rgb, float* img_rgb, float* img_disp,
+                              float* img_acc, float* img_depth, void* workspace, hipStream_t st);
+void dsn_launch_image_psnr(const float* img_rgb, const double* gt64, const float* gt32, const uint8_t* mask, int H, int W,
+                           double* out4, void* workspace, hipStream_t st);

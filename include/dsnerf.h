@@ -124,6 +124,21 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
 DSN_EXPORT int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
                     float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream);
 
+/* ---- image epilogue on the device ----------------------------------------------------------
+ * utils/render_utils.py:466-472 post_process: row k of the compacted per-ray outputs (rgb [R,3], disp/acc/depth [R],
+ * the rays of the pixels where mask_at_box is set, in pixel order) goes to the k-th masked pixel of the [H,W] images;
+ * all other pixels are zero.  clamp_rgb != 0 applies test.py:62-63's clamp to [0,1] to the colour image.
+ * disp/acc/depth and their images may be NULL.  workspace: dsn_image_workspace_bytes(H,W). */
+DSN_EXPORT size_t dsn_image_workspace_bytes(int H, int W);
+DSN_EXPORT int dsn_image_scatter(const float* rgb, const float* disp, const float* acc, const float* depth, int R,
+                      const uint8_t* mask_at_box, int H, int W, int clamp_rgb, float* img_rgb, float* img_disp,
+                      float* img_acc, float* img_depth, void* workspace, void* stream);
+/* metrics.py:8-21 mse / psnr of an [H,W,3] float32 image against the ground truth (float64 as in the reference's
+ * batch["img"], or float32; exactly one of gt_f64 / gt_f32 non-NULL), over all pixels and over mask_at_box
+ * (test.py:70-71).  out4 (device, float64) = {mse_all, mse_masked, psnr_all, psnr_masked}; mask may be NULL. */
+DSN_EXPORT int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f32, const uint8_t* mask_at_box,
+                   int H, int W, double* out4, void* workspace, void* stream);
+
 /* ---- training backward: what loss.backward() computes in trainer.py:70-81 -----------------
  * Gradients of L w.r.t. the 33 parameters, given the cotangents of Renderer.render's outputs
  * (utils/loss.py:17-27 uses color and acc_map): d_rgb [R,3] (required), d_disp / d_acc / d_depth [R] and

@@ -54,7 +54,7 @@ def test_render_matches_reference_and_oracle(name):
     else:
         r.eval()
     out = r.render(make_batch(g))["coarse"]
-    out = {k: v.cpu().numpy() for k, v in out.items()}
+    out = {k: v.detach().cpu().numpy() for k, v in out.items()}   # train mode: attached to the autograd node
     assert np.array_equal(out["z_vals"], g["render:z_vals"])
     # reference float32 Renderer.render on the same batch
     for k, tol in (("color", 1e-4), ("acc_map", 1e-4), ("weights", 1e-4), ("depth_map", 3e-4)):
@@ -262,7 +262,72 @@ def test_train_forward_loss_parity():
     r.train()
     torch.manual_seed(233)
     out = r.render(make_batch(g))["coarse"]
-    loss = torch.nn.functional.mse_loss(out["color"].cpu(), torch.from_numpy(g["target_rgb"]))
+    assert out["color"].requires_grad and not out["z_vals"].requires_grad
+    loss = torch.nn.functional.mse_loss(out["color"].detach().cpu(), torch.from_numpy(g["target_rgb"]))
     ref = float(g["render:loss"])
     assert abs(float(loss) - ref) < 1e-6 * max(1.0, abs(ref)), (float(loss), ref)
-    assert maxdiff(out["color"].cpu().numpy(), g["render:color"]) < 1e-4
+    assert maxdiff(out["color"].detach().cpu().numpy(), g["render:color"]) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,frac", [(12, 12, 0.6), (37, 53, 0.3), (512, 512, 0.9), (300, 1, 0.5), (64, 64, 0.0), (64, 64, 1.0)])
+def test_image_scatter_is_exact(H, W, frac):
+    """f-3: post_process on the device (utils/render_utils.py:466-472) == numpy boolean-mask assignment, bit for bit,
+    incl. empty and full masks, sizes that are not multiples of the block, and the clamp of test.py:62-63"""
+    from dsnerf_amd import _lib
+    rng = np.random.default_rng(H * 1000 + W)
+    mask = rng.random(H * W) < frac
+    R = int(mask.sum())
+    src = {"color": rng.standard_normal((R, 3)).astype(np.float32), "disp_map": rng.random(R).astype(np.float32),
+           "acc_map": rng.random(R).astype(np.float32), "depth_map": rng.random(R).astype(np.float32)}
+    if R:
+        src["disp_map"][0] = np.nan                      # disparity is NaN where a ray hit nothing
+    dev = torch.device("cuda:0")
+    out = {k: torch.from_numpy(v).to(dev) for k, v in src.items()}
+    for clamp in (False, True):
+        img = _lib.image_scatter(out, torch.from_numpy(mask), H, W, clamp=clamp)
+        for key, name, c in (("color", "coarse_color", 3), ("disp_map", "coarse_disp", 1), ("acc_map", "coarse_acc", 1),
+                             ("depth_map", "coarse_depth", 1)):
+            want = np.zeros((H * W, c), np.float32)
+            v = src[key].reshape(R, c)
+            want[mask] = np.clip(v, 0.0, 1.0) if (clamp and key == "color") else v
+            got = img[name].cpu().numpy().reshape(H * W, c)
+            assert np.array_equal(got, want, equal_nan=True), (name, clamp)
+
+
+def test_image_psnr_matches_float64_reference_formula():
+    """metrics.py:8-21: -10 log10(mean((pred - gt)^2)) over all pixels and over mask_at_box, float64 accumulation"""
+    from dsnerf_amd import _lib
+    rng = np.random.default_rng(3)
+    H, W = 96, 80
+    pred = rng.random((H, W, 3)).astype(np.float32)
+    gt = rng.random((H, W, 3))                          # float64 like batch["img"]
+    mask = rng.random((H, W)) < 0.4
+    got = _lib.image_psnr(torch.from_numpy(pred).cuda(), torch.from_numpy(gt), torch.from_numpy(mask)).cpu().numpy()
+    d2 = (pred.astype(np.float64) - gt) ** 2
+    want = np.array([d2.mean(), d2[mask].mean(), -10 * np.log10(d2.mean()), -10 * np.log10(d2[mask].mean())])
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    got32 = _lib.image_psnr(torch.from_numpy(pred).cuda(), torch.from_numpy(gt.astype(np.float32)), torch.from_numpy(mask))
+    d2 = (pred.astype(np.float64) - gt.astype(np.float32).astype(np.float64)) ** 2
+    assert np.allclose(got32.cpu().numpy()[:2], [d2.mean(), d2[mask].mean()], rtol=1e-12)
+
+
+def test_render_view_device_output_and_metrics():
+    g = load("small_view")
+    r = make_renderer(g)
+    r.eval()
+    H, W = int(g["H"]), int(g["W"])
+    b = make_batch(g)
+    rng = np.random.default_rng(0)
+    b["img"] = torch.from_numpy(rng.random((1, H, W, 3)))
+    b["mask_at_box"] = torch.from_numpy(g["mask_at_box"])[None]
+    host = r.render_view(b)
+    dev = r.render_view(b, device_output=True)
+    for k in host:
+        assert dev[k].is_cuda and np.array_equal(dev[k].cpu().numpy(), host[k].numpy(), equal_nan=True)
+    assert maxdiff(host["coarse_color"].numpy(), g["coarse_color"]) < 1e-4
+    m = r.image_metrics(dev["coarse_color"], b)
+    c = np.clip(host["coarse_color"].numpy().astype(np.float64), 0, 1)
+    d2 = (c - b["img"][0].numpy()) ** 2
+    mk = g["mask_at_box"].reshape(H, W)
+    assert abs(m["psnr_woMask"] - (-10 * np.log10(d2.mean()))) < 1e-9
+    assert abs(m["psnr_wMask"] - (-10 * np.log10(d2[mk].mean()))) < 1e-9
