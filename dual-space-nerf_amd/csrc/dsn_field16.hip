@@ -77,11 +77,24 @@ __device__ __forceinline__ void w16_stage(const W16& w, int c) {
 }
 // chunk boundary in front of block b (b % 8 == 0): after the barrier chunk b/8 has landed for everyone and chunk
 // b/8 - 1 has been read by everyone (its last block is already in registers) -> its slots take chunk b/8 + 1
+#ifndef F16_SPREAD_DMA
+#define F16_SPREAD_DMA 0      // 1: issue the 8 LDS-DMA pieces of the next chunk one per block (measured: no faster, kept off)
+#endif
 __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of chunk b/8 have landed in LDS
     __syncthreads();
+#if !F16_SPREAD_DMA
     const int c = b / F16_CHUNK;
     if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
+#endif
+}
+// while block b is being multiplied: this wave's piece of block b + 8 (same ring slot as block b - 8, which every
+// wave finished reading before the last chunk barrier)
+__device__ __forceinline__ void w16_stage_one(const W16& w, int b) {
+#if F16_SPREAD_DMA
+    const int nb = b + F16_CHUNK;
+    if (nb < DSN_STREAM_BLOCKS) glds16(w.g + (size_t)nb * 4096, w.ring_off + (nb & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024);
+#endif
 }
 __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
     const char* s = w.ring + (b & (F16_RING_SLOTS - 1)) * 4096 + lane * 16;
@@ -100,7 +113,9 @@ __device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
 // One-block-ahead software pipeline: the LDS reads of block b+1 are issued before the 6 MFMAs of block b.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-template <int KB, class Hook = NoHook>
+// XLS = true : xl carries the 2^12 scale (reverse pass)  -> accM += Wh xh,  accC += Wh xl + Wl xh
+// XLS = false: xl is the plain fp16 residual (forward)    -> accM += Wh xh + Wh xl,  accC += Wl xh
+template <int KB, bool XLS, class Hook = NoHook>
 __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], const half8 (&xl)[KB][2],
                                         f32x16& accM, f32x16& accC, Hook&& hook = NoHook()) {
 #pragma unroll
@@ -117,12 +132,22 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
             w16_read(w, blk, lane, w.h0, w.l0, w.h1, w.l1);
         }
 #endif
-        accM = MFMA16(w.h0, xh[kb][0], accM);
-        accC = MFMA16(w.h0, xl[kb][0], accC);
-        accC = MFMA16(w.l0, xh[kb][0], accC);
-        accM = MFMA16(w.h1, xh[kb][1], accM);
-        accC = MFMA16(w.h1, xl[kb][1], accC);
-        accC = MFMA16(w.l1, xh[kb][1], accC);
+        if (XLS) {
+            accM = MFMA16(w.h0, xh[kb][0], accM);
+            accC = MFMA16(w.h0, xl[kb][0], accC);
+            accC = MFMA16(w.l0, xh[kb][0], accC);
+            accM = MFMA16(w.h1, xh[kb][1], accM);
+            accC = MFMA16(w.h1, xl[kb][1], accC);
+            accC = MFMA16(w.l1, xh[kb][1], accC);
+        } else {
+            accM = MFMA16(w.h0, xh[kb][0], accM);
+            accC = MFMA16(w.l0, xh[kb][0], accC);
+            accM = MFMA16(w.h0, xl[kb][0], accM);
+            accC = MFMA16(w.l1, xh[kb][1], accC);
+            accM = MFMA16(w.h1, xh[kb][1], accM);
+            accM = MFMA16(w.h1, xl[kb][1], accM);
+        }
+        w16_stage_one(w, blk);
         hook(kb);   // independent VALU work (the previous output block's epilogue slice) issues under these MFMAs
 #if F16_PREFETCH
         w.h0 = n0; w.l0 = m0; w.h1 = n1; w.l1 = m1;
@@ -159,14 +184,18 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int r = 0; r < 16; ++r) z[r] = 0.0f;
     return z;
 }
-// fp32 block (accumulator layout) -> the two k-steps of the next B operand, split hi / lo
+// fp32 block (accumulator layout) -> the two k-steps of the next B operand, split hi / lo.
+// v - (float)hi is exact in fp32; written as an fma so that it maps onto v_fma_mix_f32 (fp16 source, no separate
+// conversion).  SCALED: lo carries 2^12 (reverse pass: adjoints span many decades).  Unscaled (forward): the plain
+// fp16 residual - its absolute error is <= max(2^-25, 2^-22 |v|), i.e. fp32 rounding of the O(1) sums it feeds.
+template <bool SCALED>
 __device__ __forceinline__ void split16(const f32x16& v, half8 (&h)[2], half8 (&l)[2]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const _Float16 hi = (_Float16)v[r];
-        const _Float16 lo = (_Float16)((v[r] - (float)hi) * DSN_LO_SCALE);
+        const float res = fmaf((float)hi, -1.0f, v[r]);
         h[r >> 3][r & 7] = hi;
-        l[r >> 3][r & 7] = lo;
+        l[r >> 3][r & 7] = SCALED ? (_Float16)(res * DSN_LO_SCALE) : (_Float16)res;
     }
 }
 __device__ __forceinline__ f32x16 fold16(const f32x16& m, const f32x16& c) {
@@ -190,19 +219,29 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 #undef DSN_MK
 }
 #else
+// Pattern word of 16 accumulator elements: bit (15 - r) set <=> element r is active.  Two VALU ops per element:
+// v_alignbit shifts the sign bit of the pre-activation into the word, v_max applies the relu (a pre-activation of
+// exactly +0 counts as active; it contributes 0 either way in the forward pass, and rounding already decides the
+// pattern of any |z| < 1e-7 differently from an fp32 fma chain).
+__device__ __forceinline__ uint32_t dsn_push_sign(uint32_t word, float v) {
+    return __builtin_amdgcn_alignbit(word, __float_as_uint(v), 31);
+}
+__device__ __forceinline__ uint32_t dsn_active_word(uint32_t signs) { return ~signs & 0xffffu; }
+__device__ __forceinline__ float dsn_keep_active(float v, uint32_t word, int r) {
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)word, 15 - r, 1));
+}
 __device__ __forceinline__ uint32_t relu_bits16(f32x16& a) {
-    uint32_t m = 0;
+    uint32_t s = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const bool pos = a[r] > 0.0f;
-        m |= pos ? (1u << r) : 0u;
-        a[r] = pos ? a[r] : 0.0f;
+        s = dsn_push_sign(s, a[r]);
+        a[r] = fmaxf(a[r], 0.0f);
     }
-    return m;
+    return dsn_active_word(s);
 }
 __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = ((m >> r) & 1u) ? a[r] : 0.0f;
+    for (int r = 0; r < 16; ++r) a[r] = dsn_keep_active(a[r], m, r);
 }
 #endif
 
@@ -218,15 +257,15 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         const int r = 2 * kb + e;
         float v = fmaf(pC[r], DSN_LO_INV, pM[r]);
         if (FWD) {
-            const bool pos = v > 0.0f;
-            bits |= pos ? (1u << r) : 0u;
-            v = pos ? v : 0.0f;
+            bits = dsn_push_sign(bits, v);      // `bits` collects the 16 signs of this output block
+            v = fmaxf(v, 0.0f);
         } else {
-            v = ((mword >> r) & 1u) ? v : 0.0f;
+            v = dsn_keep_active(v, mword, r);
         }
         const _Float16 hi = (_Float16)v;
+        const float res = fmaf((float)hi, -1.0f, v);
         yh[r >> 3][r & 7] = hi;
-        yl[r >> 3][r & 7] = (_Float16)((v - (float)hi) * DSN_LO_SCALE);
+        yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
     }
 }
 
@@ -240,16 +279,16 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
-        if (m == 0) dense16<8>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1]); });
-        if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= bits << 16; else mk[(m - 1) >> 1] = bits; }
+        if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1]); });
+        if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) epi_slice<true>(pM, pC, kb, 0u, bits, yh[7], yl[7]);
-        mk[3] |= bits << 16;
+        mk[3] |= dsn_active_word(bits) << 16;
     }
 }
 // 256 -> 256 reverse layer
@@ -262,8 +301,8 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
-        if (m == 0) dense16<8>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1]); });
+        if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1]); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
@@ -349,8 +388,8 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         }
         pe[1][14] = half ? xa[1] : xa[0];
         pe[1][15] = half ? 0.0f : xa[2];
-        split16(pe[0], ph[0], pl[0]);
-        split16(pe[1], ph[1], pl[1]);
+        split16<false>(pe[0], ph[0], pl[0]);
+        split16<false>(pe[1], ph[1], pl[1]);
         s_pe[0][tid] = ph[0][0]; s_pe[1][tid] = ph[0][1]; s_pe[2][tid] = ph[1][0]; s_pe[3][tid] = ph[1][1];
         s_pe[4][tid] = pl[0][0]; s_pe[5][tid] = pl[0][1]; s_pe[6][tid] = pl[1][0]; s_pe[7][tid] = pl[1][1];
     }
@@ -359,11 +398,11 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_bias0, m, half), aC = zero16();
-        dense16<2>(w, blk, lane, ph, pl, aM, aC);
+        dense16<2, false>(w, blk, lane, ph, pl, aM, aC);
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        split16(v, ah[m], al[m]);
+        split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(0, mk)
     layer16_fwd(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk); MK_STORE(1, mk)
@@ -373,17 +412,17 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_b1 + 3 * 256, m, half), aC = zero16();
-        dense16<8>(w, blk, lane, bh, bl, aM, aC);
+        dense16<8, false>(w, blk, lane, bh, bl, aM, aC);
         {   // encoding operands come back from LDS just for these two blocks
             half8 qh[2][2], ql[2][2];
             qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
             ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
-            dense16<2>(w, blk, lane, qh, ql, aM, aC);
+            dense16<2, false>(w, blk, lane, qh, ql, aM, aC);
         }
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        split16(v, ah[m], al[m]);
+        split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(4, mk)
     layer16_fwd(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk); MK_STORE(5, mk)
@@ -392,14 +431,14 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_b1 + 5 * 256, m, half), aC = zero16();
-        dense16<8>(w, blk, lane, bh, bl, aM, aC);
+        dense16<8, false>(w, blk, lane, bh, bl, aM, aC);
         f32x16 v = fold16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
-        split16(v, ah[m], al[m]);
+        split16<false>(v, ah[m], al[m]);
     }
     sg_part += __shfl_xor(sg_part, 32);
     const float sg = sg_part + v_scal[0];
@@ -426,7 +465,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             f32x16 aM = rows16(v_brgb1, m, half), aC = zero16();
-            dense16<8>(w, blk, lane, ah, al, aM, aC);
+            dense16<8, false>(w, blk, lane, ah, al, aM, aC);
             const f32x16 v = fold16(aM, aC);
             const f32x16 w0 = rows16(v_wrgb3 + 0 * 128, m, half);
             const f32x16 w1 = rows16(v_wrgb3 + 1 * 128, m, half);
@@ -463,7 +502,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] *= F16_GSCALE;
         mask16(g, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
-        split16(g, ah[m], al[m]);
+        split16<true>(g, ah[m], al[m]);
     }
     MK_LOAD(5, mk) layer16_bwd(w, blk, lane, ah, al, bh, bl, mk);
     MK_LOAD(4, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
@@ -473,15 +512,15 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
-        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         f32x16 v = fold16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
-        split16(v, bh[m], bl[m]);
+        split16<true>(v, bh[m], bl[m]);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x16 aM = zero16(), aC = zero16();
-        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         dpe[b] = fold16(aM, aC);
     }
     MK_LOAD(2, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
@@ -490,7 +529,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x16 aM = zero16(), aC = zero16();
-        dense16<8>(w, blk, lane, ah, al, aM, aC);
+        dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         const f32x16 v = fold16(aM, aC);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpe[b][r] += v[r];
@@ -617,7 +656,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = zero16();
 #pragma unroll
         for (int j = 0; j < 5; ++j) v[j] = half ? in9[2 * j + 1] : in9[2 * j];
-        split16(v, xh, xl);
+        split16<true>(v, xh, xl);
     }
     half8 h1h[4][2], h1l[4][2];
 #pragma unroll
@@ -627,7 +666,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = fold16(aM, aC);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
-        split16(v, h1h[m], h1l[m]);
+        split16<true>(v, h1h[m], h1l[m]);
     }
     float part = 0.0f;
 #pragma unroll
