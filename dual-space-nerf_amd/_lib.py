@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsnerf_hip.so")
+# DSNERF_LIB: another build of the same library (kernel-variant experiments, scripts/variants.sh)
+LIB_PATH = os.environ.get("DSNERF_LIB") or os.path.join(_HERE, "libdsnerf_hip.so")
 _lib = None
 
 PARAM_ORDER = [

@@ -127,6 +127,12 @@ __host__ __device__ inline _Float16 dsn_pack_value16(const DsnImageX& x, const f
     const int t = hw >> 10, part = (hw >> 9) & 1, lane = (hw >> 3) & 63, j = hw & 7;
     const float v = dsn_weight_at(x, src, blk / im.KB, blk % im.KB, 8 * t + j, lane);
     const _Float16 hi = (_Float16)v;
+    if (x.im.dst < OFF_L6T) {
+        // forward trunk + rgb head images (k_field16 forward pass): the whole image carries 2^6 - hi and lo share one
+        // accumulator, and 2^6 keeps the residual of any weight >= 2^-8 a normal fp16 (weights up to 1023 fit)
+        if (!part) return (_Float16)((float)hi * 64.0f);
+        return (_Float16)((v - (float)hi) * 64.0f);
+    }
     if (!part) return hi;
     return (_Float16)((v - (float)hi) * DSN_LO_SCALE);
 }

@@ -39,6 +39,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_SGB
 #define F16_SGB 1             // sched_group_barrier interleave (1 MFMA : 4 VALU) inside every block + fence per block
 #endif
+#ifndef F16_SGB_VALU
+#define F16_SGB_VALU 4        // VALU instructions per MFMA in that pattern
+#endif
+#ifndef F16_SGB_DS
+#define F16_SGB_DS 0          // 1: pin one operand ds_read behind each of the first four MFMAs of a block
+#endif
 #ifndef F16_PREFETCH
 #define F16_PREFETCH 1        // explicit one-block-ahead LDS operand reads
 #endif
@@ -63,9 +69,8 @@ struct W16 {                 // weight stream state of one wave
 // prefetch.  M0 = wave-uniform LDS byte address of the destination; saved / restored around the statement
 // (cdna_hip_programming.md 5.7).  Completion is waited for by w16_boundary's own vmcnt(0) + barrier.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    // M0 is declared clobbered instead of saved / restored: nothing else in these kernels lives in it
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 // issue the loads of chunk c (8 blocks) into its ring slots: this wave moves quarter `wave` of every block
 __device__ __forceinline__ void w16_stage(const W16& w, int c) {
@@ -113,8 +118,10 @@ __device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
 // One-block-ahead software pipeline: the LDS reads of block b+1 are issued before the 6 MFMAs of block b.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-// XLS = true : xl carries the 2^12 scale (reverse pass)  -> accM += Wh xh,  accC += Wh xl + Wl xh
-// XLS = false: xl is the plain fp16 residual (forward)    -> accM += Wh xh + Wh xl,  accC += Wl xh
+// XLS = true : reverse pass - xl and Wl carry a 2^12 scale    -> accM += Wh xh,  accC += Wh xl + Wl xh
+// XLS = false: forward pass - the weight images are pre-scaled by 2^6 as a whole (hi and lo alike) and xl is the
+//              plain fp16 residual, so all three products share one scale and may go to either accumulator:
+//              accM + accC = 64 (Wh xh + Wh xl + Wl xh)
 template <int KB, bool XLS, class Hook = NoHook>
 __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], const half8 (&xl)[KB][2],
                                         f32x16& accM, f32x16& accC, Hook&& hook = NoHook()) {
@@ -140,12 +147,14 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
             accC = MFMA16(w.h1, xl[kb][1], accC);
             accC = MFMA16(w.l1, xh[kb][1], accC);
         } else {
+            // strictly alternating accumulators: a dependent MFMA issued right behind VALU fillers waits for the full
+            // write-back of its predecessor (MI355X_MICROARCH.md: +43 cycles), an independent one does not
             accM = MFMA16(w.h0, xh[kb][0], accM);
             accC = MFMA16(w.l0, xh[kb][0], accC);
             accM = MFMA16(w.h0, xl[kb][0], accM);
-            accC = MFMA16(w.l1, xh[kb][1], accC);
-            accM = MFMA16(w.h1, xh[kb][1], accM);
-            accM = MFMA16(w.h1, xl[kb][1], accM);
+            accC = MFMA16(w.h1, xh[kb][1], accC);
+            accM = MFMA16(w.l1, xh[kb][1], accM);
+            accC = MFMA16(w.h1, xl[kb][1], accC);
         }
         w16_stage_one(w, blk);
         hook(kb);   // independent VALU work (the previous output block's epilogue slice) issues under these MFMAs
@@ -159,7 +168,10 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#if F16_SGB_DS
+            if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one operand ds_read behind each of 4 MFMAs
+#endif
+            __builtin_amdgcn_sched_group_barrier(0x002, F16_SGB_VALU, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -197,6 +209,15 @@ __device__ __forceinline__ void split16(const f32x16& v, half8 (&h)[2], half8 (&
         h[r >> 3][r & 7] = hi;
         l[r >> 3][r & 7] = SCALED ? (_Float16)(res * DSN_LO_SCALE) : (_Float16)res;
     }
+}
+// forward accumulators hold 64 z (see dense16)
+#define F16_FWD_SCALE 64.0f
+#define F16_FWD_INV 0.015625f
+__device__ __forceinline__ f32x16 unscale16(const f32x16& m, const f32x16& c) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = (m[r] + c[r]) * F16_FWD_INV;
+    return v;
 }
 __device__ __forceinline__ f32x16 fold16(const f32x16& m, const f32x16& c) {
     f32x16 v;
@@ -255,7 +276,7 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * kb + e;
-        float v = fmaf(pC[r], DSN_LO_INV, pM[r]);
+        float v = FWD ? (pM[r] + pC[r]) * F16_FWD_INV : fmaf(pC[r], DSN_LO_INV, pM[r]);
         if (FWD) {
             bits = dsn_push_sign(bits, v);      // `bits` collects the 16 signs of this output block
             v = fmaxf(v, 0.0f);
@@ -348,6 +369,8 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 
     for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
         s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
+    // accumulators of the forward pass start from 64 x bias (6 trunk biases + rgb_net.1 bias follow bias0)
+    for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += F16_THREADS) s_vec[i] *= F16_FWD_SCALE;
     const float* const v_bias0 = s_vec;
     const float* const v_b1 = s_vec + 256;                                  // + l * 256
     const float* const v_brgb1 = s_vec + 256 + (OFF_BRGB1 - OFF_B1);
@@ -399,7 +422,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_bias0, m, half), aC = zero16();
         dense16<2, false>(w, blk, lane, ph, pl, aM, aC);
-        f32x16 v = fold16(aM, aC);
+        f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         split16<false>(v, ah[m], al[m]);
@@ -419,7 +442,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
             ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
             dense16<2, false>(w, blk, lane, qh, ql, aM, aC);
         }
-        f32x16 v = fold16(aM, aC);
+        f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         split16<false>(v, ah[m], al[m]);
@@ -432,7 +455,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_b1 + 5 * 256, m, half), aC = zero16();
         dense16<8, false>(w, blk, lane, bh, bl, aM, aC);
-        f32x16 v = fold16(aM, aC);
+        f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         const f32x16 wd = rows16(v_wden, m, half);
@@ -466,7 +489,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         for (int m = 0; m < 4; ++m) {
             f32x16 aM = rows16(v_brgb1, m, half), aC = zero16();
             dense16<8, false>(w, blk, lane, ah, al, aM, aC);
-            const f32x16 v = fold16(aM, aC);
+            const f32x16 v = unscale16(aM, aC);
             const f32x16 w0 = rows16(v_wrgb3 + 0 * 128, m, half);
             const f32x16 w1 = rows16(v_wrgb3 + 1 * 128, m, half);
             const f32x16 w2 = rows16(v_wrgb3 + 2 * 128, m, half);

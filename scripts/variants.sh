@@ -1,0 +1,14 @@
+#!/bin/bash
+# build k_field16 variants (extra -D flags) into dual-space-nerf_amd/variants/<name>.so; usage: variants.sh name "flags" [name "flags" ...]
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; P=$ROOT/dual-space-nerf_amd; mkdir -p $P/variants
+python $P/build.py > /dev/null
+while [ $# -gt 1 ]; do
+  name=$1; flags=$2; shift 2
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wno-unused-result -Wno-inline-asm $flags \
+      -c $P/csrc/dsn_field16.hip -o $P/variants/$name.o 2> $P/variants/$name.log && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build/dsn_api.o $P/build/dsn_geom.o $P/build/dsn_nn.o $P/build/dsn_field.o \
+      $P/variants/$name.o $P/build/dsn_train.o $P/build/dsn_image.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $P/variants/$name.so && echo "built $name" ) &
+done
+wait
+rm -f $P/variants/*.o
