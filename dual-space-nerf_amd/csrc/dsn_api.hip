@@ -254,6 +254,7 @@ int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, co
 }
 
 // workspace carve for the fused path
+#define DSN_CELLMAJOR_MIN 8192   // below this many samples the five extra launches cost more than they save
 struct DsnWorkspace {
     int32_t* count;       // [64] (first word = number of active samples)
     int32_t* active;      // [N]
@@ -267,6 +268,7 @@ struct DsnWorkspace {
     float* colour;        // [N,3]
     int32_t* pos;         // [N]   samples with sigma > 0 (eval-mode split of the field kernel)
     void* masks;          // [N] x 224 B relu-mask records
+    void* nn_small;       // per-cell scratch of the cell-major nearest-face search
     size_t bytes;
 };
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
@@ -285,6 +287,7 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.colour = (float*)p;         p += dsn_align256(12 * N);
     w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
     w.masks = (void*)p;           p += dsn_align256(224 * N);
+    w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -314,13 +317,27 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     int32_t* cnt = skip ? w.count : nullptr;
     if (skip) {
         if (hipMemsetAsync(w.count, 0, 256, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
-        // untouched (skipped) samples must still hold finite colour / sigma for the compositor
+    }
+    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
+    const int32_t* nn_pre = nullptr;
+    if (!exh && N >= (int64_t)DSN_CELLMAJOR_MIN) {
+        // cell-major search: samples counting-sorted by fine cell, lists through the scalar cache (dsn_nn.hip).
+        // Scratch: buffers that are not written before the field's reverse pass / the normal and lighting kernels -
+        // cell ids and the result in the gradient buffer (2 N ints of 3 N), the sorted (point, id) records in n_w | colour
+        // (16 N bytes of 24 N; colour is cleared below, after the search).
+        int32_t* g3 = (int32_t*)w.grad;
+        dsn_launch_nn_cellmajor(s.nn_world, nullptr, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, g3 + N, w.nn_small, st);
+        nn_pre = g3 + N;
+    }
+    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
+                    nn_pre);
+    if (skip) {
+        // untouched (skipped) samples must still hold finite colour / sigma for the compositor (cleared here, after the
+        // nearest-face search has finished with its scratch)
         if (hipMemsetAsync(w.sigma, 0, sizeof(float) * N, st) != hipSuccess ||
             hipMemsetAsync(w.colour, 0, sizeof(float) * 3 * N, st) != hipSuccess)
             return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
-    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
-    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st);
     if (flags & DSN_FIELD_FP32)
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     else if (skip) {

@@ -238,7 +238,8 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
                                                         float* __restrict__ h_out, uint8_t* __restrict__ transparent,
                                                         float* __restrict__ x_c, float* __restrict__ ray_d_can,
                                                         int32_t* __restrict__ active_list,
-                                                        int32_t* __restrict__ active_count) {
+                                                        int32_t* __restrict__ active_count,
+                                                        const int32_t* __restrict__ nn_pre) {
     __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
     const bool valid = i < N;
@@ -256,7 +257,10 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
     }
     int fi = 0;
     if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_world, F, p[0], p[1], p[2], s_tile);
-    else if (valid) fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_world, F, p[0], p[1], p[2]);
+    else if (valid) {
+        const int pre = nn_pre ? nn_pre[i] : -1;     // cell-major search result (dsn_launch_nn_cellmajor), -1 = not covered
+        fi = pre >= 0 ? pre : dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_world, F, p[0], p[1], p[2]);
+    }
     bool active = false;
     if (valid) {
         DsnFaceRec fw = dsn_load_face(face_world, fi);
@@ -299,17 +303,17 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st) {
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
     DsnNNArgs nn = dsn_nn_args(s.nn_world);
     if (exhaustive)
         hipLaunchKernelGGL(k_warp<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count);
+                           ray_d_can, active_list, active_count, nullptr);
     else
         hipLaunchKernelGGL(k_warp<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count);
+                           ray_d_can, active_list, active_count, nn_pre);
 }
 
 // ---------------------------------------------------------------------------------------------

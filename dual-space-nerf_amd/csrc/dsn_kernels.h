@@ -13,7 +13,11 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st);
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre = nullptr);
+// dsn_nn.hip: cell-major exact search of the fine lists (nn [N]: index, or -1 where the fine grid does not cover)
+size_t dsn_nn_sort_scratch_size(int64_t N);
+void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
+                             int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
                        bool exhaustive, hipStream_t st);

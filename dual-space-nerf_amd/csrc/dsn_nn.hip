@@ -152,3 +152,193 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
     dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), true, st);
     dsn_build_level(cent, F, nn.coarse, pad_coarse, t_coarse, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), false, st);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Cell-major query of the fine lists (fused path).  k_warp's per-lane list scan is bound by the vector L1
+// return path: every lane pulls 16 B per candidate (~290 candidates per sample) even when neighbouring lanes
+// read the same entry.  Here the samples are counting-sorted by fine cell first; one wave then owns 64 samples
+// of ONE cell, the candidate list is read through the scalar cache (uniform address -> s_load, operands in
+// SGPRs) and only the distance arithmetic runs on the VALU.  Same list, same order, same fma chain, same strict
+// '<' as dsn_nearest_lists, hence the same index bit for bit.  Samples outside the fine grid keep nn = -1 and
+// are searched by k_warp as before.
+// ---------------------------------------------------------------------------------------------
+#define NNS_THREADS 256
+
+__device__ __forceinline__ void nns_point(const float* __restrict__ pts, const float* __restrict__ ray_o,
+                                          const float* __restrict__ ray_d, const float* __restrict__ z_vals, int64_t i, int S,
+                                          float* p) {
+    if (pts) { p[0] = pts[3 * i]; p[1] = pts[3 * i + 1]; p[2] = pts[3 * i + 2]; return; }
+    const int64_t ray = i / S;
+    const float z = z_vals[i];      // the same expression as k_warp: bit-identical points
+    p[0] = ray_o[3 * ray + 0] + ray_d[3 * ray + 0] * z;
+    p[1] = ray_o[3 * ray + 1] + ray_d[3 * ray + 1] * z;
+    p[2] = ray_o[3 * ray + 2] + ray_d[3 * ray + 2] * z;
+}
+
+// Runs of equal cell inside a wave: the 64 lanes of a wave are consecutive samples, i.e. (pieces of) rays, and a
+// straight line visits a convex cell in ONE contiguous run - so "distinct cells of the wave" are found by comparing
+// with the previous lane, and each run head issues one atomic for the whole run (no per-cell loop).  A cell that does
+// come back in a later run of the same wave (ray boundary inside the wave) simply gets a second atomic.
+struct NnsRun { bool head; int head_lane; int len; int rank; };
+__device__ __forceinline__ NnsRun nns_run(int c, int lane) {
+    const int prev = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);         // heads at or below this lane (lane 63: all)
+    NnsRun r;
+    r.head = head;
+    r.head_lane = 63 - __clzll((long long)(lane == 63 ? heads : below));
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;      // next head after this lane
+    r.len = next - r.head_lane;       // same for every lane of the run
+    r.rank = lane - r.head_lane;
+    return r;
+}
+
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __restrict__ gf, const float* __restrict__ pts,
+                                                              const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                              const float* __restrict__ z_vals, int64_t N, int S,
+                                                              int32_t* __restrict__ cell_of, int32_t* __restrict__ nn,
+                                                              int32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int c = -1;
+    if (i < N) {
+        float p[3];
+        nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
+        c = dsn_grid_cell(*gf, p[0], p[1], p[2]);
+        cell_of[i] = c;
+        if (c < 0) nn[i] = -1;
+    }
+    const NnsRun r = nns_run(c, lane);
+    if (r.head && c >= 0) atomicAdd(counts + c, r.len);
+}
+
+// exclusive scans over the cells: sample offsets and wave offsets (ceil(count / 64) waves per cell); counts are
+// cleared for their second life as scatter cursors.  Single workgroup, 64 cells per thread.
+__global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
+                                                    int32_t* __restrict__ totals) {
+    __shared__ int s_a[1024], s_b[1024];
+    const int ncell = gf->ok ? gf->ncell : 0;
+    const int per = (ncell + 1023) / 1024;
+    const int t = threadIdx.x, c0 = t * per;
+    int a = 0, b = 0;
+    for (int k = 0; k < per; ++k) {
+        const int c = c0 + k;
+        if (c < ncell) { const int n = counts[c]; a += n; b += (n + 63) >> 6; }
+    }
+    s_a[t] = a; s_b[t] = b;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int xa = t >= off ? s_a[t - off] : 0, xb = t >= off ? s_b[t - off] : 0;
+        __syncthreads();
+        s_a[t] += xa; s_b[t] += xb;
+        __syncthreads();
+    }
+    int ra = s_a[t] - a, rb = s_b[t] - b;
+    for (int k = 0; k < per; ++k) {
+        const int c = c0 + k;
+        if (c < ncell) {
+            const int n = counts[c];
+            offs[c] = ra; wave_offs[c] = rb;
+            ra += n; rb += (n + 63) >> 6;
+            counts[c] = 0;
+        }
+    }
+    if (t == 1023) { totals[0] = s_b[1023]; totals[1] = s_a[1023]; }
+}
+
+// wave w -> its cell (cells with many samples own several consecutive waves)
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_expand(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ wave_offs,
+                                                            const int32_t* __restrict__ totals, int32_t* __restrict__ wave_cell) {
+    const int c = blockIdx.x * NNS_THREADS + threadIdx.x;
+    const int ncell = gf->ok ? gf->ncell : 0;
+    if (c >= ncell) return;
+    const int w0 = wave_offs[c], w1 = (c + 1 < ncell) ? wave_offs[c + 1] : totals[0];
+    for (int w = w0; w < w1; ++w) wave_cell[w] = c;
+}
+
+// sorted[pos] = (point, sample id): the search kernel then reads its samples with one coalesced 16-byte load
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter(const int32_t* __restrict__ cell_of, const float* __restrict__ pts,
+                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                             const float* __restrict__ z_vals, int64_t N, int S,
+                                                             const int32_t* __restrict__ offs, int32_t* __restrict__ cursor,
+                                                             float4* __restrict__ sorted) {
+    const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = i < N ? cell_of[i] : -1;
+    const NnsRun r = nns_run(c, lane);
+    int base = 0;
+    if (r.head && c >= 0) base = offs[c] + atomicAdd(cursor + c, r.len);
+    base = __shfl(base, r.head_lane);
+    if (c >= 0) {
+        float p[3];
+        nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
+        sorted[base + r.rank] = make_float4(p[0], p[1], p[2], __int_as_float((int)i));
+    }
+}
+
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __restrict__ off_f, const float4* __restrict__ list_f,
+                                                            const int32_t* __restrict__ wave_cell, const int32_t* __restrict__ wave_offs,
+                                                            const int32_t* __restrict__ totals, const int32_t* __restrict__ offs,
+                                                            const int32_t* __restrict__ counts, const float4* __restrict__ sorted,
+                                                            int32_t* __restrict__ nn) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (NNS_THREADS / 64) + (threadIdx.x >> 6));
+    if (w >= totals[0]) return;
+    const int c = __builtin_amdgcn_readfirstlane(wave_cell[w]);
+    const int slot = (w - __builtin_amdgcn_readfirstlane(wave_offs[c])) * 64 + lane;
+    const bool valid = slot < __builtin_amdgcn_readfirstlane(counts[c]);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) q = sorted[__builtin_amdgcn_readfirstlane(offs[c]) + slot];
+    const float p[3] = {q.x, q.y, q.z};
+    const int o = __builtin_amdgcn_readfirstlane(off_f[c]);
+    const int n = __builtin_amdgcn_readfirstlane(off_f[c + 1]) - o;
+    const float4* __restrict__ e = list_f + o;
+    float best = INFINITY;
+    int bi = 0;
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {                     // wave-uniform addresses: 128 B of candidates per scalar-load batch
+        float4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = e[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = dsn_d2(p[0], p[1], p[2], a[j]);
+            if (d < best) { best = d; bi = __float_as_int(a[j].w); }
+        }
+    }
+    for (; k < n; ++k) {
+        const float4 a = e[k];
+        const float d = dsn_d2(p[0], p[1], p[2], a);
+        if (d < best) { best = d; bi = __float_as_int(a.w); }
+    }
+    if (valid) nn[__float_as_int(q.w)] = bi;
+}
+
+size_t dsn_nn_sort_scratch_size(int64_t N) {
+    // counts, offs, wave_offs: one int per fine cell (+1); totals; wave_cell: one int per wave
+    return 3 * dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1)) + 256 + dsn_align256(4 * (size_t)(N / 64 + DSN_NN_FINE_MAXCELL + 1));
+}
+
+// nn [N] <- exact nearest-centroid index for every sample inside the fine grid, -1 elsewhere.
+// cell_of: N ints of scratch; sorted: N float4 of scratch; small: dsn_nn_sort_scratch_size(N) bytes
+void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
+                             int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st) {
+    char* q = (char*)small;
+    int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* offs = (int32_t*)q;       q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* wave_offs = (int32_t*)q;  q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* totals = (int32_t*)q;     q += 256;
+    int32_t* wave_cell = (int32_t*)q;
+    (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
+    const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
+    hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, pts, ray_o, ray_d, z_vals, N, S, cell_of, nn, counts);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
+    hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
+    const int64_t max_waves = N / 64 + DSN_NN_FINE_MAXCELL + 1;
+    hipLaunchKernelGGL(k_nns_search, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn);
+}
