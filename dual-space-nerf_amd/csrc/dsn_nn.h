@@ -40,17 +40,26 @@ struct DsnGrid {            // device-resident descriptor (64 B)
 __host__ __device__ inline int dsn_nn_fine_cap(int F) { long long c = 1600LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
 __host__ __device__ inline int dsn_nn_coarse_cap(int F) { long long c = 1000LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
 
+#define DSN_SUPER 4                 // build acceleration: super-cells of 4 x 4 x 4 cells ...
+#define DSN_SUPER_CAP 4096          // ... each with a candidate superset of at most this many faces
 struct DsnGridView {        // one level
     DsnGrid* g;
     int32_t* offsets;       // [maxcell + 1]
     float* u2;              // [maxcell] scratch: U(B)^2
     void* list;             // [cap] entries: float4 {x,y,z,index bits} (fine level) or int32 index (coarse level)
+    int32_t* super_cnt;     // [maxcell] (fine level only, else NULL): size of each super-cell's superset (> CAP: unusable)
+    float4* super_list;     // [maxsuper][DSN_SUPER_CAP] supersets, ascending face order
 };
+__host__ __device__ inline int dsn_grid_maxsuper(int maxcell) { return maxcell / 32; }   // grids with more super-cells (very thin ones) build unaccelerated
 struct DsnNNView { DsnGridView fine, coarse; };
 
 __host__ __device__ inline size_t dsn_grid_bytes(int maxcell, int cap, int entry_bytes) {
-    return dsn_align256(sizeof(DsnGrid)) + dsn_align256(sizeof(int32_t) * ((size_t)maxcell + 1)) +
-           dsn_align256(sizeof(float) * (size_t)maxcell) + dsn_align256((size_t)entry_bytes * (size_t)cap);
+    size_t b = dsn_align256(sizeof(DsnGrid)) + dsn_align256(sizeof(int32_t) * ((size_t)maxcell + 1)) +
+               dsn_align256(sizeof(float) * (size_t)maxcell) + dsn_align256((size_t)entry_bytes * (size_t)cap);
+    if (entry_bytes == 16)
+        b += dsn_align256(sizeof(int32_t) * (size_t)maxcell) +
+             dsn_align256(sizeof(float) * 4 * (size_t)dsn_grid_maxsuper(maxcell) * DSN_SUPER_CAP);
+    return b;
 }
 __host__ __device__ inline DsnGridView dsn_grid_view(char*& p, int maxcell, int cap, int entry_bytes) {
     DsnGridView v;
@@ -58,6 +67,12 @@ __host__ __device__ inline DsnGridView dsn_grid_view(char*& p, int maxcell, int 
     v.offsets = (int32_t*)p;    p += dsn_align256(sizeof(int32_t) * ((size_t)maxcell + 1));
     v.u2 = (float*)p;           p += dsn_align256(sizeof(float) * (size_t)maxcell);
     v.list = (void*)p;          p += dsn_align256((size_t)entry_bytes * (size_t)cap);
+    v.super_cnt = nullptr;
+    v.super_list = nullptr;
+    if (entry_bytes == 16) {
+        v.super_cnt = (int32_t*)p;  p += dsn_align256(sizeof(int32_t) * (size_t)maxcell);
+        v.super_list = (float4*)p;  p += dsn_align256(sizeof(float) * 4 * (size_t)dsn_grid_maxsuper(maxcell) * DSN_SUPER_CAP);
+    }
     return v;
 }
 __host__ __device__ inline size_t dsn_nn_bytes(int F) {

@@ -3,6 +3,7 @@
 // float4 loads, table is L2-resident), wave-level min / ballot compaction, single-block scan.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
+#include <cstdlib>
 
 __global__ void __launch_bounds__(256) k_grid_params(const float4* __restrict__ cent, int F, float pad,
                                                       int target_cells, int maxcell, int cap, DsnGrid* __restrict__ g) {
@@ -60,15 +61,95 @@ __device__ __forceinline__ float dsn_box_dmax2(const float4 c, const float* blo,
 }
 __device__ __forceinline__ bool dsn_in_list(float dmin2, float u2) { return dmin2 <= u2 * (1.0f + 1e-5f) + 1e-12f; }
 
+// Build acceleration.  For a super-cell SB (4 x 4 x 4 cells, box = union of their guarded boxes) and any cell B in it:
+// dmax(B, c) <= dmax(SB, c) and dmin(SB, c) <= dmin(B, c) for every centroid c (same fp32 expressions, rounding is
+// monotonic), hence U(B) <= U(SB), the minimiser of U(B) and every member of L(B) lie in
+//   S(SB) = { f : dmin(SB, c_f)^2 <= U(SB)^2 (1 + 1e-5) + 1e-12 },
+// and sweeping S(SB) instead of all F centroids yields the SAME U(B) and the SAME list, entry for entry.
+// One workgroup per super-cell writes S(SB) in ascending face order (<= DSN_SUPER_CAP entries, else the super-cell is
+// marked unusable and its cells sweep the whole table as before).
+__device__ __forceinline__ int dsn_super_dims(const DsnGrid& g, int& sx, int& sy, int& sz) {
+    sx = (g.nx + DSN_SUPER - 1) / DSN_SUPER; sy = (g.ny + DSN_SUPER - 1) / DSN_SUPER; sz = (g.nz + DSN_SUPER - 1) / DSN_SUPER;
+    return sx * sy * sz;
+}
+__device__ __forceinline__ int dsn_super_of(const DsnGrid& g, int cell) {
+    int sx, sy, sz;
+    dsn_super_dims(g, sx, sy, sz);
+    const int iz = cell % g.nz, iy = (cell / g.nz) % g.ny, ix = cell / (g.nz * g.ny);
+    return ((ix / DSN_SUPER) * sy + iy / DSN_SUPER) * sz + iz / DSN_SUPER;
+}
+
+__global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ cent, int F, const DsnGrid* __restrict__ gp,
+                                                     int maxsuper, int32_t* __restrict__ super_cnt,
+                                                     float4* __restrict__ super_list) {
+    const DsnGrid g = *gp;
+    int sx, sy, sz;
+    const int nsuper = dsn_super_dims(g, sx, sy, sz);
+    const int sb = blockIdx.x;
+    if (sb >= nsuper || nsuper > maxsuper) return;
+    const int kz = sb % sz, ky = (sb / sz) % sy, kx = sb / (sz * sy);
+    // union of the guarded cell boxes: lo of the first cell, hi of the last cell (the cells' own expressions)
+    const int x0 = kx * DSN_SUPER, y0 = ky * DSN_SUPER, z0 = kz * DSN_SUPER;
+    const int x1 = min(x0 + DSN_SUPER, g.nx) - 1, y1 = min(y0 + DSN_SUPER, g.ny) - 1, z1 = min(z0 + DSN_SUPER, g.nz) - 1;
+    float blo[3], bhi[3], t0[3], t1[3];
+    dsn_cell_box(g, (x0 * g.ny + y0) * g.nz + z0, blo, t1);
+    dsn_cell_box(g, (x1 * g.ny + y1) * g.nz + z1, t0, bhi);
+    __shared__ float s_m[256];
+    __shared__ int s_cnt[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float m = INFINITY;
+    for (int f = t; f < F; f += 256) m = fminf(m, dsn_box_dmax2(cent[f], blo, bhi));
+    s_m[t] = m;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (t < o) s_m[t] = fminf(s_m[t], s_m[t + o]);
+        __syncthreads();
+    }
+    m = s_m[0];
+    int base = 0;
+    float4* out = super_list + (size_t)sb * DSN_SUPER_CAP;
+    for (int f0 = 0; f0 < F; f0 += 256) {
+        const int f = f0 + t;
+        const float4 c = cent[f < F ? f : 0];
+        const bool in = f < F && dsn_in_list(dsn_box_dmin2(c, blo, bhi), m);
+        const unsigned long long mask = __ballot(in);
+        __syncthreads();
+        if (lane == 0) s_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) at += s_cnt[w];
+        if (in && at < DSN_SUPER_CAP) out[at] = c;
+        base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+    if (t == 0) super_cnt[sb] = base;
+}
+
+// the table a cell sweeps: its super-cell's superset when there is a usable one, else all centroids
+__device__ __forceinline__ const float4* dsn_cell_source(const DsnGrid& g, int cell, const float4* cent, int F, int maxsuper,
+                                                         const int32_t* super_cnt, const float4* super_list, int& n) {
+    n = F;
+    if (!super_cnt) return cent;
+    int sx, sy, sz;
+    if (dsn_super_dims(g, sx, sy, sz) > maxsuper) return cent;
+    const int sb = dsn_super_of(g, cell);
+    const int c = super_cnt[sb];
+    if (c > DSN_SUPER_CAP) return cent;
+    n = c;
+    return super_list + (size_t)sb * DSN_SUPER_CAP;
+}
+
 // pass 1+2: U(B)^2 and the list length of every cell (one wavefront per cell)
-__global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ cent, int F, const DsnGrid* __restrict__ gp,
-                                                     float* __restrict__ u2, int32_t* __restrict__ offsets) {
+__global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
+                                                     float* __restrict__ u2, int32_t* __restrict__ offsets, int maxsuper,
+                                                     const int32_t* __restrict__ super_cnt, const float4* __restrict__ super_list) {
     const DsnGrid g = *gp;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
     float blo[3], bhi[3];
     dsn_cell_box(g, cell, blo, bhi);
+    int F;
+    const float4* __restrict__ cent = dsn_cell_source(g, cell, cent_all, F_all, maxsuper, super_cnt, super_list, F);
     float m = INFINITY;
     for (int f = lane; f < F; f += 64) m = fminf(m, dsn_box_dmax2(cent[f], blo, bhi));
 #pragma unroll
@@ -107,9 +188,10 @@ __global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int
 
 // pass 3: write the lists in ascending face order (ballot compaction keeps the order)
 template <bool INLINE>
-__global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ cent, int F, const DsnGrid* __restrict__ gp,
+__global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                     const float* __restrict__ u2, const int32_t* __restrict__ offsets,
-                                                    void* __restrict__ list) {
+                                                    void* __restrict__ list, int maxsuper, const int32_t* __restrict__ super_cnt,
+                                                    const float4* __restrict__ super_list) {
     const DsnGrid g = *gp;
     if (!g.ok) return;
     const int lane = threadIdx.x & 63;
@@ -117,6 +199,8 @@ __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ ce
     if (cell >= g.ncell) return;
     float blo[3], bhi[3];
     dsn_cell_box(g, cell, blo, bhi);
+    int F;
+    const float4* __restrict__ cent = dsn_cell_source(g, cell, cent_all, F_all, maxsuper, super_cnt, super_list, F);
     const float m = u2[cell];
     int base = offsets[cell];
     for (int f0 = 0; f0 < F; f0 += 64) {
@@ -127,7 +211,7 @@ __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ ce
         if (in) {
             const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
             if (INLINE) reinterpret_cast<float4*>(list)[at] = c;
-            else reinterpret_cast<int32_t*>(list)[at] = f;
+            else reinterpret_cast<int32_t*>(list)[at] = __float_as_int(c.w);
         }
         base += __popcll(mask);
     }
@@ -135,13 +219,21 @@ __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ ce
 
 static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, float pad, int target, int maxcell, int cap,
                             bool inline_entries, hipStream_t st) {
+    const int maxsuper = dsn_grid_maxsuper(maxcell);
+    DsnGridView vv = v;
+    if (getenv("DSN_NN_NO_SUPER")) vv.super_cnt = nullptr;     // cross-check switch: build with full sweeps
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, st, cent, F, pad, target, maxcell, cap, v.g);
-    hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets);
+    if (vv.super_cnt)
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list);
+    hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
     hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets);
     if (inline_entries)
-        hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list);
+        hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
     else
-        hipLaunchKernelGGL(k_grid_fill<false>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list);
+        hipLaunchKernelGGL(k_grid_fill<false>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
 }
 
 static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }

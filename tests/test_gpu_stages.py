@@ -259,3 +259,34 @@ def test_camera_rays(ctx):
     d = ctx["lib"].camera_rays(K, g["R"], g["T"], g["bounds"], 512, 512)
     assert np.array_equal(d[4].cpu().numpy(), o[4])
     assert maxdiff(d[1].cpu().numpy(), o[1]) <= 1.2e-7 and maxdiff(d[2].cpu().numpy(), o[2]) <= 4.8e-7
+
+
+def test_accelerated_list_build_equals_full_sweep(ctx, monkeypatch):
+    """the super-cell accelerated build (dsn_nn.hip) produces the same lists as sweeping all centroids per cell:
+    same entry totals on every level and the same nearest face on a cloud of query points"""
+    import dsnerf_amd.synth as synth
+    _lib, dev = ctx["lib"], ctx["dev"]
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    poses = torch.from_numpy(synth.make_poses())
+
+    def build():
+        sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+        sc.set_frame(ctx["packed"], torch.from_numpy(xyz), poses, 5)
+        return sc
+
+    fast = build()
+    monkeypatch.setenv("DSN_NN_NO_SUPER", "1")
+    slow = build()
+    monkeypatch.delenv("DSN_NN_NO_SUPER")
+    assert _lib.nn_stats(fast) == _lib.nn_stats(slow)
+    rng = np.random.default_rng(11)
+    v = xyz[rng.integers(0, xyz.shape[0], 200000)]
+    pts = (v + rng.normal(0, 0.04, v.shape)).astype(np.float32)
+    pts[:5000] += rng.normal(0, 0.5, (5000, 3)).astype(np.float32)      # far points: coarse level / fallback
+    d = torch.zeros(pts.shape[0], 3, device=dev)
+    a = _lib.warp(fast, T(pts, dev), d, 1, want_dir=False)
+    b = _lib.warp(slow, T(pts, dev), d, 1, want_dir=False)
+    c = _lib.warp(fast, T(pts, dev), d, 1, want_dir=False, exhaustive=True)
+    assert torch.equal(a["face_idx"], b["face_idx"]) and torch.equal(a["face_idx"], c["face_idx"])
+    assert torch.equal(a["x_c"], c["x_c"])
