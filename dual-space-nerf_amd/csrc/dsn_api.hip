@@ -330,7 +330,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         nn_pre = g3 + N;
     }
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
-                    nn_pre);
+                    nn_pre, skip);
     if (skip) {
         // untouched (skipped) samples must still hold finite colour / sigma for the compositor (cleared here, after the
         // nearest-face search has finished with its scratch)

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
                                                         float* __restrict__ x_c, float* __restrict__ ray_d_can,
                                                         int32_t* __restrict__ active_list,
                                                         int32_t* __restrict__ active_count,
-                                                        const int32_t* __restrict__ nn_pre) {
+                                                        const int32_t* __restrict__ nn_pre, int lazy_canon) {
     __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
     const bool valid = i < N;
@@ -264,11 +264,17 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
     bool active = false;
     if (valid) {
         DsnFaceRec fw = dsn_load_face(face_world, fi);
-        DsnFaceRec fc = dsn_load_face(face_canon, fi);
-        float u, v, h, xc[3];
+        float u, v, h, xc[3] = {0.f, 0.f, 0.f};
         dsn_project(p, fw, u, v, h);
         bool tr = (u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f);
-        dsn_map2face(u, v, h, fc, xc);
+        // fused eval path (lazy_canon): the canonical point of a transparent sample is never read, so the gather of its
+        // canonical face record is skipped (61 % of the samples of the benchmark frame); x_c is written as zeros
+        const bool need_c = !(tr && lazy_canon);
+        DsnFaceRec fc;
+        if (need_c) {
+            fc = dsn_load_face(face_canon, fi);
+            dsn_map2face(u, v, h, fc, xc);
+        }
         if (face_idx) face_idx[i] = fi;
         if (uv_out) { uv_out[2 * i] = u; uv_out[2 * i + 1] = v; }
         if (h_out) h_out[i] = h;
@@ -286,16 +292,24 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
         active = !tr;
     }
     if (active_list) {
-        // wave-aggregated append: one atomic per wave
-        unsigned long long m = __ballot(active);
-        int lane = threadIdx.x & 63;
-        int cnt = __popcll(m);
-        int base = 0;
-        if (lane == 0 && cnt) base = atomicAdd(active_count, cnt);
-        base = __shfl(base, 0);
+        // workgroup-aggregated append: ONE atomic per 256 samples (every wave of the grid hits the same counter, and
+        // same-address atomics serialise in L2 - one per wave was the floor of this kernel)
+        __shared__ int s_cnt[WARP_THREADS / 64];
+        __shared__ int s_base;
+        const unsigned long long m = __ballot(active);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < WARP_THREADS / 64; ++k) tot += s_cnt[k];
+            s_base = tot ? atomicAdd(active_count, tot) : 0;
+        }
+        __syncthreads();
         if (active) {
-            int off = __popcll(m & ((1ull << lane) - 1ull));
-            active_list[base + off] = (int32_t)i;
+            int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < wave; ++k) off += s_cnt[k];
+            active_list[off] = (int32_t)i;
         }
     }
 }
@@ -303,17 +317,17 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st, const int32_t* nn_pre) {
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre, bool lazy_canon) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
     DsnNNArgs nn = dsn_nn_args(s.nn_world);
     if (exhaustive)
         hipLaunchKernelGGL(k_warp<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count, nullptr);
+                           ray_d_can, active_list, active_count, nullptr, (int)(lazy_canon && !ray_d_can));
     else
         hipLaunchKernelGGL(k_warp<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count, nn_pre);
+                           ray_d_can, active_list, active_count, nn_pre, (int)(lazy_canon && !ray_d_can));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st, const int32_t* nn_pre = nullptr);
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre = nullptr, bool lazy_canon = false);
 // dsn_nn.hip: cell-major exact search of the fine lists (nn [N]: index, or -1 where the fine grid does not cover)
 size_t dsn_nn_sort_scratch_size(int64_t N);
 void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
