@@ -128,6 +128,33 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
     }
     float zmin = 99999.f, zmax = -99999.f;
     bool any = false;
+    // Per-wave conservative cull: the 64 rays of a wave (consecutive pixels) form a narrow bundle around the axis a with
+    // half-angle theta = max angle(a, du_r).  A vertex w (relative to the common origin) at angle phi from the axis is at
+    // distance >= |w| sin(phi' - theta), phi' = min(phi, pi - phi), from every line of the bundle; when that exceeds
+    // gamma (+10 % and 0.1 mm of slack, far above the rounding of this test) it cannot satisfy rho^2 < gamma^2 for any
+    // ray of the wave and is left out.  The survivors go through the reference's exact test unchanged, and min / max
+    // do not depend on the order, so near / far are bit-identical to the full sweep.
+    __shared__ unsigned short s_keep[GG_THREADS / 64][GG_TILE];
+    const int lane = tid & 63, wave = tid >> 6;
+    float ax, ay, az, cos_t, sin_t;
+    {
+        const bool ok = r < R;
+        const int src = __ffsll((long long)__ballot(ok)) - 1;       // first valid lane (or -1)
+        float ux = du[0], uy = du[1], uz = du[2];
+        if (!ok && src >= 0) { ux = __shfl(du[0], src); uy = __shfl(du[1], src); uz = __shfl(du[2], src); }
+        else if (!ok) { ux = 0.f; uy = 0.f; uz = 1.f; }
+        float sx = ux, sy = uy, sz = uz;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+        const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+        ax = sx * inv; ay = sy * inv; az = sz * inv;
+        float c = ax * ux + ay * uy + az * uz;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c = fminf(c, __shfl_xor(c, o));
+        cos_t = fminf(c, 1.0f);
+        sin_t = sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
+    }
+    const float keep_r = 0.05f * 1.10f + 1e-4f;
     for (int base = 0; base < V; base += GG_TILE) {
         int n = min(GG_TILE, V - base);
         __syncthreads();
@@ -136,9 +163,27 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
             sv[j] = make_float4(dx, dy, dz, dsn_sum3(dx * dx, dy * dy, dz * dz));
         }
         __syncthreads();
+        int kept = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool keep = false;
+            if (j < n) {
+                const float4 v = sv[j];
+                const float wn = sqrtf(v.w);
+                const float ca = (ax * v.x + ay * v.y + az * v.z) / fmaxf(wn, 1e-20f);
+                const float cc = fminf(fabsf(ca), 1.0f);
+                const float ss = sqrtf(fmaxf(0.f, 1.0f - cc * cc));
+                const float lb = wn * fmaxf(0.f, ss * cos_t - cc * sin_t);
+                keep = !(lb > keep_r);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) s_keep[wave][kept + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            kept += __popcll(m);
+        }
+        // (same-wave LDS writes are visible to the wave's later reads; no barrier needed for a wave-private list)
 #pragma unroll 4
-        for (int j = 0; j < n; ++j) {
-            float4 v = sv[j];
+        for (int k = 0; k < kept; ++k) {
+            float4 v = sv[s_keep[wave][k]];
             float z0 = dsn_sum3(v.x * du[0], v.y * du[1], v.z * du[2]);
             float tmp = v.w - z0 * z0;
             if (tmp < gamma2) {

@@ -290,3 +290,30 @@ def test_accelerated_list_build_equals_full_sweep(ctx, monkeypatch):
     c = _lib.warp(fast, T(pts, dev), d, 1, want_dir=False, exhaustive=True)
     assert torch.equal(a["face_idx"], b["face_idx"]) and torch.equal(a["face_idx"], c["face_idx"])
     assert torch.equal(a["x_c"], c["x_c"])
+
+
+def test_sampler_bundle_cull_is_exact_at_full_size(ctx):
+    """k_sample_gg culls vertices per 64-ray bundle before the reference's exact test: near / far / z_vals of a whole
+    512 x 512 frame must equal the oracle's full sweep bit for bit (4096 rays checked, all wave positions), also for a
+    ray count that is not a multiple of the wave / block size and for rays handed over in shuffled (incoherent) order"""
+    import dsnerf_amd.synth as synth
+    _lib, dev = ctx["lib"], ctx["dev"]
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(512, 512, xyz, fit_box=True)
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(ctx["packed"], torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    S = 64
+    tv = torch.linspace(0.0, 1.0, steps=S)
+    rng = np.random.default_rng(5)
+    for order in ("raster", "shuffled"):
+        idx = np.arange(512 * 512 - 37)
+        if order == "shuffled":
+            idx = rng.permutation(idx)
+        near, far = T(rays["near"][idx], dev), T(rays["far"][idx], dev)
+        _, z = _lib.sample(sc, T(rays["ray_o"][idx], dev), T(rays["ray_d"][idx], dev), near, far, S, tv.to(dev), None)
+        sel = np.sort(rng.choice(len(idx), 4096, replace=False))
+        n0, f0 = rays["near"][idx][sel].copy(), rays["far"][idx][sel].copy()
+        o = O.sample_gg(rays["ray_o"][idx][sel], rays["ray_d"][idx][sel], n0, f0, xyz, S, t_vals=tv.numpy())
+        assert np.array_equal(z.cpu().numpy()[sel], o["z_vals"]), order
+        assert np.array_equal(near.cpu().numpy()[sel], o["near"]) and np.array_equal(far.cpu().numpy()[sel], o["far"]), order
