@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays the CPU oracle is timed on (0 = sized for ~15 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="frames in flight (each on its own HIP stream with its own scene / workspace): the per-frame setup, "
+                         "sampling and warp kernels of frame k+1 run beside the field kernels of frame k; 1 = strictly serial")
     ap.add_argument("--train", action="store_true",
                     help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
                          "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
@@ -92,8 +95,11 @@ def main():
     rays = synth.make_rays(H, W, xyz, fit_box=True)    # every ray crosses the padded body AABB (= mask_at_box rays)
 
     packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
-    scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
-    ws = _lib.RenderWorkspace(dev)
+    depth = max(1, args.pipeline)
+    scenes = [_lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev) for _ in range(depth)]
+    wss = [_lib.RenderWorkspace(dev) for _ in range(depth)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    scene, ws = scenes[0], wss[0]
     t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
     d_xyz = torch.from_numpy(xyz).to(dev)
     d_poses = torch.from_numpy(poses).to(dev)
@@ -101,26 +107,35 @@ def main():
     ray_d = torch.from_numpy(rays["ray_d"]).to(dev)
     near0 = torch.from_numpy(rays["near"]).to(dev)
     far0 = torch.from_numpy(rays["far"]).to(dev)
-    near, far = near0.clone(), far0.clone()
-    out = None
-    gathered = torch.empty(world * R, 6, dtype=torch.float32, device=dev) if world > 1 else None
-    packed_px = torch.empty(R, 6, dtype=torch.float32, device=dev)
+    nears = [near0.clone() for _ in range(depth)]
+    fars = [far0.clone() for _ in range(depth)]
+    outs = [None] * depth
+    gathered = [torch.empty(world * R, 6, dtype=torch.float32, device=dev) if world > 1 else None for _ in range(depth)]
+    packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
+    torch.cuda.synchronize()
+    k_step = 0
 
     def step():
-        nonlocal out
-        near.copy_(near0)
-        far.copy_(far0)
-        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
-        out = _lib.render_rays(scene, packed, ws, ray_o, ray_d, near, far, S, t_vals, None, None,
-                               skip_transparent=not args.dense, want_weights=False, out=out, fp32=args.fp32)
-        if world > 1:
-            packed_px[:, 0:3] = out["color"]
-            packed_px[:, 3] = out["disp_map"]
-            packed_px[:, 4] = out["acc_map"]
-            packed_px[:, 5] = out["depth_map"]
-            dist.all_gather_into_tensor(gathered, packed_px)
+        # one whole frame on slot j's stream; consecutive frames use different slots, so the small geometry kernels of
+        # the next frame fill the gaps beside the LDS-bound field kernels of this one
+        nonlocal k_step
+        j = k_step % depth
+        k_step += 1
+        with torch.cuda.stream(streams[j]):
+            nears[j].copy_(near0)
+            fars[j].copy_(far0)
+            scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+            outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
+                                       skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32)
+            if world > 1:
+                packed_px[j][:, 0:3] = outs[j]["color"]
+                packed_px[j][:, 3] = outs[j]["disp_map"]
+                packed_px[j][:, 4] = outs[j]["acc_map"]
+                packed_px[j][:, 5] = outs[j]["depth_map"]
+                dist.all_gather_into_tensor(gathered[j], packed_px[j])
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -133,6 +148,14 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # latency of one frame alone (no overlap with a neighbour), for the record
+    k_step = 0
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+    ms_serial = 1e3 * (time.perf_counter() - t1) / 3
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -157,6 +180,7 @@ def main():
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
             "ms_per_frame": ms_step,
+            "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,

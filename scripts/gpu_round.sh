@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300
 timeout 600 python bench.py > gpurun_out/bench_round.log 2>&1; tail -1 gpurun_out/bench_round.log | cut -c1-2500
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --pipeline 1"   # profiles: one frame at a time, clean per-kernel durations
 rm -rf gpurun_out/prof_r gpurun_out/pmcr
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r -o r -- $B > gpurun_out/bench_prof_r.log 2>&1
 python scripts/rocpd_summary.py gpurun_out/prof_r/r_results.db > gpurun_out/kernel_trace_r.txt; cut -c1-150 gpurun_out/kernel_trace_r.txt | head -24
