@@ -39,6 +39,43 @@ class RayParallel:
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return out[:R]
 
+    # ---- load-balanced partition: tiles of `tile` rays dealt round-robin ----
+    # With the transparent skip the cost of a ray depends on where it crosses the body, so contiguous blocks of one
+    # frame are uneven (the rows through the torso cost several times the rows above the head).  Dealing small tiles
+    # round-robin gives every rank the same mix; the exchange is still ONE all-gather of equal-sized slabs.
+    def tile_indices(self, R: int, tile: int = 3072, rank: int = None) -> torch.Tensor:
+        """ray indices (ascending) of the tiles owned by `rank` (default: this rank)."""
+        rank = self.rank if rank is None else rank
+        ntiles = (R + tile - 1) // tile
+        mine = torch.arange(rank, ntiles, self.world)
+        idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
+        return idx[idx < R]
+
+    def render_tiled(self, render_fn, ray_o, ray_d, near, far, tile: int = 3072):
+        """like render(), with the round-robin tile partition.  NOTE: the geometry-guided sampler takes the FIRST ray's
+        origin for the whole batch (utils/pts_utils.py:31), so this is meant for rays of one camera."""
+        R = ray_o.shape[0]
+        dev = ray_o.device
+        idx = self.tile_indices(R, tile).to(dev)
+        if idx.numel():
+            loc = render_fn(ray_o[idx].contiguous(), ray_d[idx].contiguous(), near[idx].contiguous(), far[idx].contiguous())
+            packed = torch.cat([loc["color"], loc["disp_map"][:, None], loc["acc_map"][:, None], loc["depth_map"][:, None]], dim=1)
+        else:
+            packed = torch.zeros(0, 6, dtype=torch.float32, device=dev)
+        if self.world == 1:
+            full = packed
+        else:
+            slab = max(self.tile_indices(R, tile, r).numel() for r in range(self.world))   # rank 0 owns the most
+            pad = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
+            pad[: packed.shape[0]] = packed
+            allp = torch.empty(self.world * slab, 6, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(allp, pad, group=self.group)
+            full = torch.empty(R, 6, dtype=torch.float32, device=dev)
+            for r in range(self.world):
+                ir = self.tile_indices(R, tile, r).to(dev)
+                full[ir] = allp[r * slab: r * slab + ir.numel()]
+        return {"color": full[:, 0:3], "disp_map": full[:, 3], "acc_map": full[:, 4], "depth_map": full[:, 5]}
+
     def render(self, render_fn, ray_o, ray_d, near, far):
         """render_fn(ray_o, ray_d, near, far) -> dict(color [r,3], disp_map [r], acc_map [r], depth_map [r])
         on this rank's block; returns the same dict for all R rays on every rank."""

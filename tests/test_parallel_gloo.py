@@ -34,6 +34,11 @@ def _worker(rank, world, port, R, q):
     out = rp.render(_fake_render, o, d, n, f)
     ref = _fake_render(o, d, n, f)
     ok = all(torch.equal(out[k], ref[k]) for k in ref)
+    for tile in (1, 3, 64):                      # round-robin tiles: same pixels, every ray owned exactly once
+        out2 = rp.render_tiled(_fake_render, o, d, n, f, tile=tile)
+        ok = ok and all(torch.equal(out2[k], ref[k]) for k in ref)
+        owned = torch.cat([rp.tile_indices(R, tile, r) for r in range(world)])
+        ok = ok and torch.equal(torch.sort(owned).values, torch.arange(R))
     q.put((rank, s, e, ok))
     dist.barrier()
     dist.destroy_process_group()
