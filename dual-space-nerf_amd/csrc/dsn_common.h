@@ -245,6 +245,14 @@ enum {
     DSN_STREAM_BLOCKS_ALL = OFF_B1 / DSN_BLK,     // 892: + lights_encoding.0 (4) and .2 (16) for k_light16
     OFF_END = OFF16_BASE + DSN_STREAM_BLOCKS_ALL * DSN_BLK
 };
+// Position (in halfwords) of halfword hw (0..2047) of split-fp16 stream block gb.  The 872 trunk blocks are stored
+// chunk-major: a chunk = 8 consecutive blocks = 32 KB, laid out [quarter q = hw >> 9 (hi/lo of k-step 0, hi/lo of k-step 1)]
+// [block in chunk][512 halfwords], so that the 8 one-KB pieces one wave moves per chunk are contiguous - in memory AND in the
+// LDS ring - and one LDS-DMA base + 8 immediate offsets cover them (k_field16).  The lighting blocks behind them stay block-major.
+__host__ __device__ inline size_t dsn_stream16_index(int gb, int hw) {
+    if (gb >= DSN_STREAM_BLOCKS) return (size_t)gb * 2048 + hw;
+    return (size_t)(gb >> 3) * 16384 + (size_t)(hw >> 9) * 4096 + (size_t)(gb & 7) * 512 + (hw & 511);
+}
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
 #define DSN_LO_INV (1.0f / 4096.0f)
 

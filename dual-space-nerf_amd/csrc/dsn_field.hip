@@ -150,7 +150,7 @@ __global__ void k_pack_params16(DsnParamPtrs pp, _Float16* __restrict__ dst16) {
     const float* src = pp.p[x.im.src];
     const int nblk = x.im.count / DSN_BLK, b0 = x.im.dst / DSN_BLK;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nblk * 2048; e += gridDim.x * blockDim.x)
-        dst16[(size_t)(b0 + e / 2048) * 2048 + (e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
+        dst16[dsn_stream16_index(b0 + e / 2048, e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
 }
 #define DSN_NUM_STREAM_IMAGES 17
 
@@ -166,7 +166,7 @@ void dsn_pack_params_host(const float* const* params33_host, float* packed_host)
         const DsnImageX x = h_images[i];
         const float* src = params33_host[x.im.src];
         const int nblk = x.im.count / DSN_BLK, b0 = x.im.dst / DSN_BLK;
-        for (int e = 0; e < nblk * 2048; ++e) d16[(size_t)(b0 + e / 2048) * 2048 + (e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
+        for (int e = 0; e < nblk * 2048; ++e) d16[dsn_stream16_index(b0 + e / 2048, e % 2048)] = dsn_pack_value16(x, src, e / 2048, e % 2048);
     }
 }
 

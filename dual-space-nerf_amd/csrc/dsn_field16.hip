@@ -50,63 +50,49 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #endif
 
 #define F16_THREADS 256
-#define F16_RING_SLOTS 16
-#define F16_CHUNK 8
+#define F16_CHUNK 8              // blocks per ring barrier; the ring holds two chunks (fixed: the DMA immediates span one chunk)
+#define F16_RING_SLOTS (2 * F16_CHUNK)
 #define F16_NCHUNK (DSN_STREAM_BLOCKS / F16_CHUNK)   // 109
 #define F16_GSCALE 0.015625f                         // reverse pass runs on g / 64
 #define F16_GUNSCALE 64.0f
 
 struct W16 {                 // weight stream state of one wave
-    const char* g;           // this lane's source: stream base + wave * 1024 + lane * 16
-    char* ring;              // LDS ring base
+    const char* g;           // this lane's source: stream base + wave * 8192 + 4096 + lane * 16 (chunk-major layout, dsn_stream16_index)
+    char* ring;              // LDS ring base: [chunk parity][quarter][block in chunk][1 KB]
     unsigned ring_off;       // its LDS byte address (for M0)
     int wave;
     half8 h0, l0, h1, l1;    // the CURRENT block's operands: (hi, lo) for k-step 0 and 1
 };
 
-// LDS-DMA of 1 KB (64 lanes x 16 B) issued through inline asm: the compiler-visible builtin makes hipcc put
-// s_waitcnt vmcnt(0) in front of the next ds_read (it cannot prove the ring slots differ), which serialises the
-// prefetch.  M0 = wave-uniform LDS byte address of the destination; saved / restored around the statement
-// (cdna_hip_programming.md 5.7).  Completion is waited for by w16_boundary's own vmcnt(0) + barrier.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    // M0 is declared clobbered instead of saved / restored: nothing else in these kernels lives in it
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
-}
-// issue the loads of chunk c (8 blocks) into its ring slots: this wave moves quarter `wave` of every block
+// LDS-DMA of chunk c: this wave moves quarter `wave` of its 8 blocks = 8 contiguous KB, in memory and in the ring, so
+// ONE global address + ONE M0 + 8 immediate offsets (-4096 .. 3072, applied to both sides by the hardware) do it.
+// Issued through inline asm: the compiler-visible builtin makes hipcc put s_waitcnt vmcnt(0) in front of the next ds_read
+// (it cannot prove the ring slots differ), which serialises the prefetch.  M0 is declared clobbered (nothing else in these
+// kernels lives in it).  Completion is waited for by w16_boundary's own vmcnt(0) + barrier.
 __device__ __forceinline__ void w16_stage(const W16& w, int c) {
-#pragma unroll
-    for (int i = 0; i < F16_CHUNK; ++i) {
-        const int b = c * F16_CHUNK + i;
-        glds16(w.g + (size_t)b * 4096, w.ring_off + (b & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024);
-    }
+    const char* src = w.g + (size_t)c * 32768;
+    const unsigned dst = w.ring_off + (c & 1) * 32768 + w.wave * 8192 + 4096;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:-4096\n\tglobal_load_lds_dwordx4 %0, off offset:-3072\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:-2048\n\tglobal_load_lds_dwordx4 %0, off offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                 : : "v"(src), "s"(dst) : "memory", "m0");
 }
 // chunk boundary in front of block b (b % 8 == 0): after the barrier chunk b/8 has landed for everyone and chunk
-// b/8 - 1 has been read by everyone (its last block is already in registers) -> its slots take chunk b/8 + 1
-#ifndef F16_SPREAD_DMA
-#define F16_SPREAD_DMA 0      // 1: issue the 8 LDS-DMA pieces of the next chunk one per block (measured: no faster, kept off)
-#endif
+// b/8 - 1 has been read by everyone (its last block is already in registers) -> its half of the ring takes chunk b/8 + 1
 __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of chunk b/8 have landed in LDS
     __syncthreads();
-#if !F16_SPREAD_DMA
     const int c = b / F16_CHUNK;
     if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
-#endif
-}
-// while block b is being multiplied: this wave's piece of block b + 8 (same ring slot as block b - 8, which every
-// wave finished reading before the last chunk barrier)
-__device__ __forceinline__ void w16_stage_one(const W16& w, int b) {
-#if F16_SPREAD_DMA
-    const int nb = b + F16_CHUNK;
-    if (nb < DSN_STREAM_BLOCKS) glds16(w.g + (size_t)nb * 4096, w.ring_off + (nb & (F16_RING_SLOTS - 1)) * 4096 + w.wave * 1024);
-#endif
 }
 __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
-    const char* s = w.ring + (b & (F16_RING_SLOTS - 1)) * 4096 + lane * 16;
+    const char* s = w.ring + ((b >> 3) & 1) * 32768 + (b & 7) * 1024 + lane * 16;
     h0 = *reinterpret_cast<const half8*>(s);
-    l0 = *reinterpret_cast<const half8*>(s + 1024);
-    h1 = *reinterpret_cast<const half8*>(s + 2048);
-    l1 = *reinterpret_cast<const half8*>(s + 3072);
+    l0 = *reinterpret_cast<const half8*>(s + 8192);
+    h1 = *reinterpret_cast<const half8*>(s + 16384);
+    l1 = *reinterpret_cast<const half8*>(s + 24576);
 }
 __device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
     w16_stage(w, first_blk / F16_CHUNK);
@@ -156,7 +142,6 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
             accM = MFMA16(w.l1, xh[kb][1], accM);
             accC = MFMA16(w.h1, xl[kb][1], accC);
         }
-        w16_stage_one(w, blk);
         hook(kb);   // independent VALU work (the previous output block's epilogue slice) issues under these MFMAs
 #if F16_PREFETCH
         w.h0 = n0; w.l0 = m0; w.h1 = n1; w.l1 = m1;
@@ -378,7 +363,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const float* const v_wrgb3 = s_vec + 256 + (OFF_WRGB3 - OFF_B1);
     const float* const v_scal = s_vec + 2560;
     W16 w;
-    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 1024 + lane * 16;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;

@@ -1,0 +1,146 @@
+// microbenchmark of k_field16's inner loop, feature by feature (scripts/ubench/lds_read.hip measured reads / MFMA alone):
+//   MODE 0: 4 operand ds_read_b128 + 6 MFMA per 4 KB block (one block of prefetch)                 [the 253-cycle floor]
+//   MODE 1: + LDS-DMA refill of the ring (8 pieces per wave per 8 blocks) + vmcnt(0) + barrier per 8 blocks
+//   MODE 2: + 30 dependent-free VALU instructions per block (an epilogue stand-in), scheduled by the compiler
+//   MODE 3: MODE 1 without the barrier (DMA only)      MODE 4: MODE 1 without the DMA (barrier only)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define BLOCKS 128
+__device__ __forceinline__ void glds16(unsigned long long gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k(float* out, const char* wsrc, int reps) {
+    __shared__ __attribute__((aligned(16))) char ring[65536];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 16384; i += 256) ((float*)ring)[i] = (float)(i & 7) * 0.001f;
+    __syncthreads();
+    f32x16 a0 = {0}, a1 = {0};
+    half8 h0 = {0}, l0 = {0}, h1 = {0}, l1 = {0}, x = {0};
+    float e[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+    for (int j = 0; j < 8; ++j) x[j] = (_Float16)(0.01f * (lane + j));
+    const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    const unsigned base = ring_off + lane * 16;
+    const unsigned long long g = (unsigned long long)wsrc + wave * 1024 + lane * 16;
+    for (int it = 0; it < reps; ++it) {
+#pragma unroll
+        for (int b = 0; b < BLOCKS; ++b) {
+            if ((b & 7) == 0 && MODE >= 1) {
+                constexpr int M = (MODE == 2 || MODE == 5 || MODE == 6) ? 1 : MODE;
+                if (M != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (M != 3) __syncthreads();
+                if (M != 4) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int nb = (b + 8 + i) < BLOCKS ? (b + 8 + i) : (b + 8 + i - BLOCKS);
+                        glds16(g + (unsigned long long)nb * 4096ull, ring_off + (nb & 15) * 4096 + wave * 1024);
+                    }
+                }
+            }
+            half8 n0, m0, n1, m1;
+            const unsigned a = base + (b & 15) * 4096;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                         : "=v"(n0), "=v"(m0), "=v"(n1), "=v"(m1) : "v"(a) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1, x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, x, a1, 0, 0, 0);
+            if (MODE == 2 || MODE == 5 || MODE == 6) {
+#pragma unroll
+                for (int r = 0; r < (MODE == 6 ? 18 : 30); ++r) e[r & 7] = __builtin_fmaf(e[r & 7], 1.0001f, e[(r + 3) & 7]);
+            }
+            if (MODE == 5 || MODE == 6) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, MODE == 6 ? 3 : 5, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            h0 = n0; l0 = m0; h1 = n1; l1 = m1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    for (int r = 0; r < 8; ++r) s += e[r];
+    s += (float)h0[0] + (float)l1[3];
+    if (s == 123.456f) out[0] = s;
+}
+template <int MODE> void run(const char* name, float* d, const char* w, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(256 * 4), dim3(256), 0, 0, d, w, 1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256 * 4), dim3(256), 0, 0, d, w, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double us_per_block = ms * 1e3 / (4.0 * reps * BLOCKS);      // 4 workgroups per CU back to back
+    printf("%-34s %8.3f ms   %.4f us per block per wave = %.0f cycles @2.1 GHz (6 MFMA = 192)\n", name, ms, us_per_block, us_per_block * 2100); fflush(stdout);
+}
+// direct variant: every wave streams the whole 4 KB block from global memory (L2 / L1) straight into VGPRs, DEPTH blocks
+// ahead; no LDS ring, no DMA, no barrier
+template <int DEPTH, int VALU>
+__global__ void __launch_bounds__(256, 1) kd(float* out, const char* wsrc, int reps) {
+    const int lane = threadIdx.x & 63;
+    f32x16 a0 = {0}, a1 = {0};
+    half8 x = {0};
+    float e[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+    for (int j = 0; j < 8; ++j) x[j] = (_Float16)(0.01f * (lane + j));
+    const half8* g = reinterpret_cast<const half8*>(wsrc) + lane;
+    half8 q[DEPTH][4];
+    for (int it = 0; it < reps; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) q[d][p] = g[(d * 4 + p) * 64];
+#pragma unroll
+        for (int b = 0; b < BLOCKS; ++b) {
+            half8 c[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) c[p] = q[b % DEPTH][p];
+            const int nb = (b + DEPTH) < BLOCKS ? (b + DEPTH) : (b + DEPTH - BLOCKS);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) q[b % DEPTH][p] = g[(nb * 4 + p) * 64];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[3], x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], x, a1, 0, 0, 0);
+            if (VALU) {
+#pragma unroll
+                for (int r = 0; r < VALU; ++r) e[r & 7] = __builtin_fmaf(e[r & 7], 1.0001f, e[(r + 3) & 7]);
+            }
+        }
+    }
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    for (int r = 0; r < 8; ++r) s += e[r];
+    if (s == 123.456f) out[0] = s;
+}
+template <int DEPTH, int VALU> void rund(const char* name, float* d, const char* w, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kd<DEPTH, VALU>), dim3(256 * 4), dim3(256), 0, 0, d, w, 1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kd<DEPTH, VALU>), dim3(256 * 4), dim3(256), 0, 0, d, w, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double us_per_block = ms * 1e3 / (4.0 * reps * BLOCKS);
+    printf("%-34s %8.3f ms   %.4f us per block per wave = %.0f cycles @2.1 GHz (6 MFMA = 192)\n", name, ms, us_per_block, us_per_block * 2100); fflush(stdout);
+}
+int main() {
+    float* d; hipMalloc(&d, 1024);
+    char* w; hipMalloc(&w, 4096 * (BLOCKS + 16)); hipMemset(w, 0, 4096 * (BLOCKS + 16));
+    run<0>("reads + mfma", d, w, 20);
+    run<4>("+ barrier per 8 blocks", d, w, 20);
+    run<3>("+ LDS-DMA refill (no barrier)", d, w, 20);
+    run<1>("+ LDS-DMA refill + barrier", d, w, 20);
+    run<2>("+ DMA + barrier + 30 VALU / block", d, w, 20);
+    run<5>("  same, VALU interleaved 1:5 (SGB)", d, w, 20);
+    run<6>("  18 VALU / block interleaved 1:3", d, w, 20);
+    rund<2, 0>("direct global, 2 blocks ahead", d, w, 5);
+    return 0;
+}
