@@ -167,7 +167,7 @@ def main():
     value = world * R * args.steps / dt
 
     result = {
-        "metric": "rendered rays/sec (64 samples/ray), 512x512 frame",
+        "metric": f"rendered rays/sec ({S} samples/ray), {H}x{W} frame",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
