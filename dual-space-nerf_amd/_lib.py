@@ -128,7 +128,15 @@ class Scene:
         self.frame_key = None
 
     def set_frame(self, packed: PackedParams, xyz, poses, frame_idx: int, zero_code: bool = False,
-                  light_shift=None, rot=None, rot_center=None):
+                  light_shift=None, rot=None, rot_center=None, reuse: bool = False):
+        """reuse=True: skip the call when the scene already holds exactly this frame for these parameters (same tensors at
+        the same versions) - used by the backward of a training step, which follows its own forward."""
+        vkey = lambda a: None if a is None else (a.data_ptr(), a._version, tuple(a.shape))
+        key = (vkey(xyz), vkey(poses), int(frame_idx), bool(zero_code), vkey(light_shift), vkey(rot), vkey(rot_center),
+               id(packed), packed._versions)
+        if reuse and key == self.frame_key:
+            return self
+        self.frame_key = key
         xyz = _f32(xyz.reshape(-1, 3), self.device)
         assert xyz.shape[0] == self.V, "xyz must have the body model's vertex count"
         poses = _f32(poses.reshape(24, 3), self.device)

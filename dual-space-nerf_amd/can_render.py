@@ -61,7 +61,7 @@ class _RenderRays(torch.autograd.Function):
         params = [p.detach() for p in ctx.params]
         sd = dict(zip(_lib.PARAM_ORDER, params))
         packed = r.net.packed(r.device)
-        r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc)   # another frame may have been rendered since
+        r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc, reuse=True)   # no-op unless another frame was rendered since
         if g_color is None:
             g_color = torch.zeros(o.shape[0], 3, device=r.device)
         if not hasattr(r, "_grad_ws"):
