@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays the CPU oracle is timed on (0 = sized for ~15 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
+    ap.add_argument("--no-screen", action="store_true", help="disable the plain-fp16 density screen (DSN_NO_SCREEN)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="frames in flight (each on its own HIP stream with its own scene / workspace): the per-frame setup, "
                          "sampling and warp kernels of frame k+1 run beside the field kernels of frame k; 1 = strictly serial")
@@ -126,7 +127,8 @@ def main():
             fars[j].copy_(far0)
             scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
             outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
-                                       skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32)
+                                       skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
+                                       screen=not args.no_screen)
             if world > 1:
                 packed_px[j][:, 0:3] = outs[j]["color"]
                 packed_px[j][:, 3] = outs[j]["disp_map"]
@@ -163,6 +165,7 @@ def main():
 
     n_active = int(ws.buf[:4].view(torch.int32)[0]) if not args.dense else R * S
     n_pos = int(ws.buf[64:68].view(torch.int32)[0]) if (not args.dense and not args.fp32) else n_active
+    n_kept = int(ws.buf[128:132].view(torch.int32)[0]) if (not args.dense and not args.fp32 and not args.no_screen) else n_active
     ms_step = 1e3 * dt / args.steps
     value = world * R * args.steps / dt
 
@@ -179,6 +182,8 @@ def main():
             "transparent_skip": (not args.dense),
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
+            "density_screen": not (args.dense or args.fp32 or args.no_screen),
+            "accurate_pass_sample_fraction": n_kept / float(R * S),
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense

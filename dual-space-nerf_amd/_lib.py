@@ -36,13 +36,14 @@ EXPORTS = [
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
-    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
 NN_EXHAUSTIVE = 2
 FIELD_FP32 = 4
 SAMPLE_UNIFORM = 8
+NO_SCREEN = 16
 
 
 def lib():
@@ -238,6 +239,20 @@ def field_reverse(scene: Scene, packed: PackedParams, x_c, rec, pos):
     return g
 
 
+def screen_debug(scene: Scene, packed: PackedParams, x_c):
+    """plain-fp16 density and the magnitude of its terms for every point (dsn_debug_screen)."""
+    x_c = x_c.reshape(-1, 3)
+    N = x_c.shape[0]
+    dev = scene.device
+    sg = torch.zeros(N, dtype=torch.float32, device=dev)
+    s1 = torch.zeros(N, dtype=torch.float32, device=dev)
+    lst = torch.zeros(N, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(64, dtype=torch.int32, device=dev)
+    _check(lib().dsn_debug_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
+                                  _ptr(sg), _ptr(s1), _ptr(lst), _ptr(cnt), _stream()), "dsn_debug_screen")
+    return sg, s1
+
+
 def shade(scene: Scene, packed: PackedParams, x_c, grad, x_w, ray_d, essence, S, active=None, exhaustive=False, fp32=False):
     x_c = x_c.reshape(-1, 3)
     N = x_c.shape[0]
@@ -284,7 +299,7 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False):
+                fp32=False, uniform=False, screen=True):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -305,6 +320,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= FIELD_FP32
     if uniform:
         flags |= SAMPLE_UNIFORM
+    if not screen:
+        flags |= NO_SCREEN
     buf = ws.get(R, S)
     _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
                                  _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,

@@ -208,6 +208,17 @@ int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f
     return dsn_check_launch("dsn_image_psnr");
 }
 
+int dsn_debug_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, float* sigma_screen,
+                     float* s1, int32_t* scratch_list, int32_t* scratch_count, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && sigma_screen && s1 && scratch_list && scratch_count, "dsn_debug_screen: null argument");
+    DSN_REQUIRE(N > 0 && V > 0 && F > 0, "dsn_debug_screen: bad sizes");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    if (hipMemsetAsync(scratch_count, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return dsn_fail("%s", "dsn_debug_screen: memset failed");
+    dsn_launch_screen16((const float*)packed, s.frame, x_c, N, nullptr, nullptr, sigma_screen, scratch_list, scratch_count,
+                        sigma_screen, s1, (hipStream_t)stream);
+    return dsn_check_launch("dsn_debug_screen");
+}
+
 size_t dsn_grad_workspace_bytes(int R, int S) { return (R > 0 && S > 0) ? dsn_train_workspace_size((int64_t)R * S) : 0; }
 
 int dsn_render_rays_grad(const void* scene, int V, int F, const float* const* params33_host, const float* poses24x3,
@@ -269,6 +280,7 @@ struct DsnWorkspace {
     int32_t* pos;         // [N]   samples with sigma > 0 (eval-mode split of the field kernel)
     void* masks;          // [N] x 224 B relu-mask records
     void* nn_small;       // per-cell scratch of the cell-major nearest-face search
+    int32_t* keep;        // [N]   samples the density screen could not rule out
     size_t bytes;
 };
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
@@ -288,6 +300,7 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
     w.masks = (void*)p;           p += dsn_align256(224 * N);
     w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
+    w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -344,6 +357,14 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         // eval mode: forward for every non-transparent sample, then d sigma/dx, normals and lighting only where sigma > 0
         // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
         int32_t* pcnt = w.count + 16;
+        if (!(flags & DSN_NO_SCREEN)) {
+            // plain-fp16 screen: samples whose density is provably negative keep that (negative) density and leave the
+            // list; count[32] = samples that go through the accurate pass
+            int32_t* kcnt = w.count + 32;
+            dsn_launch_screen16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.keep, kcnt, nullptr, nullptr, st);
+            list = w.keep;
+            cnt = kcnt;
+        }
         dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st);
         dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st);
         list = w.pos;

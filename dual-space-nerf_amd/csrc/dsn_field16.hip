@@ -598,6 +598,215 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_screen16 : eval-mode density screen.  71 % of the non-transparent samples of a frame end up with sigma <= 0 and
+// contribute exactly nothing (alpha = 1 - exp(-relu(sigma) dist) = 0); the accurate forward pass is only needed to
+// KNOW that.  This kernel evaluates the trunk with the hi halves alone (plain fp16 operands, fp32 accumulation: one
+// MFMA product instead of three, half the weight traffic, no residuals, no relu records, no colour head) and keeps,
+// next to sigma~, the magnitude S1 = |b_d| + sum_i |w_d,i h6_i| of what was added up.  A sample is declared empty when
+//     sigma~ < -(F16_SCREEN_REL * S1 + F16_SCREEN_ABS),
+// a margin 36x the largest fp16-vs-fp32 deviation measured on the benchmark frame relative to S1 (2.75e-4 S1)
+// (tests/test_gpu_render.py::test_density_screen_margin); every other sample goes to the accurate pass.  An empty
+// sample keeps sigma~ (< 0) as its density, so the compositor sees the same exact zero.  DSN_NO_SCREEN turns it off.
+// ---------------------------------------------------------------------------------------------
+#ifndef F16_SCREEN_REL
+#define F16_SCREEN_REL 0.01f
+#endif
+#ifndef F16_SCREEN_ABS
+#define F16_SCREEN_ABS 0.01f
+#endif
+#define F16_SCREEN_BLOCKS (OFF_RGB1 / DSN_BLK)       // 416: stage1.0 ... stage2.4
+
+// hi quarters only: quarter q = 0 (k-step 0) and 2 (k-step 1) of every block; the 16 pieces of a chunk are shared out as
+// (quarter, half of the chunk's blocks) per wave - 4 contiguous KB each
+__device__ __forceinline__ void w16s_stage(const W16& w, int c) {
+    const char* src = w.g + (size_t)c * 32768;
+    // compact ring of the screen: [chunk parity][k-step][block in chunk][1 KB] = 2 x 16 KB
+    const unsigned dst = w.ring_off + (c & 1) * 16384 + (w.wave & 1) * 8192 + (w.wave >> 1) * 4096;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                 : : "v"(src), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ void w16s_boundary(const W16& w, int b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int c = b / F16_CHUNK;
+    if (c + 1 < F16_SCREEN_BLOCKS / F16_CHUNK) w16s_stage(w, c + 1);
+}
+__device__ __forceinline__ void w16s_read(const W16& w, int b, int lane, half8& h0, half8& h1) {
+    const char* s = w.ring + ((b >> 3) & 1) * 16384 + (b & 7) * 1024 + lane * 16;
+    h0 = *reinterpret_cast<const half8*>(s);
+    h1 = *reinterpret_cast<const half8*>(s + 8192);
+}
+// (a0, a1) += 64 Wh[32 rows][32*KB k] xh, one accumulator per k-step
+template <int KB, class Hook = NoHook>
+__device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], f32x16& a0, f32x16& a1,
+                                         Hook&& hook = NoHook()) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        half8 n0 = w.h0, n1 = w.h1;
+        if (blk + 1 < F16_SCREEN_BLOCKS) {
+            if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16s_boundary(w, blk + 1);
+            w16s_read(w, blk + 1, lane, n0, n1);
+        }
+        a0 = MFMA16(w.h0, xh[kb][0], a0);
+        a1 = MFMA16(w.h1, xh[kb][1], a1);
+        hook(kb);
+        w.h0 = n0; w.h1 = n1;
+        ++blk;
+    }
+}
+__device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r >> 3][r & 7] = (_Float16)fmaxf((a[r] + b[r]) * F16_FWD_INV, 0.0f);
+}
+__device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&xh)[8][2],
+                                         half8 (&yh)[8][2]) {
+    const int half = lane >> 5;
+    f32x16 p0 = zero16(), p1 = zero16();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(bias, m, half), a1 = zero16();
+        if (m == 0) dense16s<8>(w, blk, lane, xh, a0, a1);
+        else dense16s<8>(w, blk, lane, xh, a0, a1, [&](int kb) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * kb + e;
+                yh[m - 1][r >> 3][r & 7] = (_Float16)fmaxf((p0[r] + p1[r]) * F16_FWD_INV, 0.0f);
+            }
+        });
+        p0 = a0; p1 = a1;
+    }
+    relu_half16(p0, p1, yh[7]);
+}
+
+__global__ void __launch_bounds__(F16_THREADS, 2)   // 241 registers, 58 KB of LDS: two workgroups per CU
+k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
+           const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
+           int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
+           float* __restrict__ dbg_s1) {
+    __shared__ __attribute__((aligned(16))) char ring[2 * 16384];
+    __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
+    __shared__ __attribute__((aligned(16))) half8 s_pe[4][F16_THREADS];
+    __shared__ int s_cnt[F16_THREADS / 64];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    if ((int64_t)blockIdx.x * 128 >= count) return;
+    int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool valid = slot < count;
+    if (!valid) slot = count - 1;
+    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
+    const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+    for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
+        s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
+    for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += F16_THREADS) s_vec[i] *= F16_FWD_SCALE;
+    const float* const v_b1 = s_vec + 256;
+    const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + (wave & 1) * 16384 + (wave >> 1) * 4096 + lane * 16;
+    w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    w.wave = wave;
+    w16s_stage(w, 0);
+    w16s_boundary(w, 0);
+    w16s_read(w, 0, lane, w.h0, w.h1);
+    int blk = 0;
+    half8 ah[8][2], bh[8][2];
+    half8 ph[2][2];
+    {
+        f32x16 pe[2];
+#pragma unroll
+        for (int t = 0; t < 30; ++t) {
+            float s, c;
+            dsn_sincos(xa[t % 3] * (float)(1 << (t / 3)), s, c);
+            pe[t >> 4][t & 15] = half ? c : s;
+        }
+        pe[1][14] = half ? xa[1] : xa[0];
+        pe[1][15] = half ? 0.0f : xa[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ph[b][r >> 3][r & 7] = (_Float16)pe[b][r];
+        s_pe[0][tid] = ph[0][0]; s_pe[1][tid] = ph[0][1]; s_pe[2][tid] = ph[1][0]; s_pe[3][tid] = ph[1][1];
+    }
+    // stage1.0
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(s_vec, m, half), a1 = zero16();
+        dense16s<2>(w, blk, lane, ph, a0, a1);
+        relu_half16(a0, a1, ah[m]);
+    }
+    layer16s(w, blk, lane, v_b1 + 0 * 256, ah, bh);
+    layer16s(w, blk, lane, v_b1 + 1 * 256, bh, ah);
+    layer16s(w, blk, lane, v_b1 + 2 * 256, ah, bh);
+    // stage2.0 : [h, pe] -> 256
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(v_b1 + 3 * 256, m, half), a1 = zero16();
+        dense16s<8>(w, blk, lane, bh, a0, a1);
+        half8 qh[2][2];
+        qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
+        dense16s<2>(w, blk, lane, qh, a0, a1);
+        relu_half16(a0, a1, ah[m]);
+    }
+    layer16s(w, blk, lane, v_b1 + 4 * 256, ah, bh);
+    // stage2.4 + density head: sigma~ and the magnitude of its terms
+    float sg = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(v_b1 + 5 * 256, m, half), a1 = zero16();
+        dense16s<8>(w, blk, lane, bh, a0, a1);
+        const f32x16 wd = rows16(v_wden, m, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h = fmaxf((a0[r] + a1[r]) * F16_FWD_INV, 0.0f);
+            const float term = wd[r] * h;
+            sg += term;
+            s1 += fabsf(term);
+        }
+    }
+    sg += __shfl_xor(sg, 32);
+    s1 += __shfl_xor(s1, 32);
+    const float bd = s_vec[2560];
+    sg += bd;
+    s1 += fabsf(bd);
+    const bool mine = valid && half == 0;
+    const bool empty = sg < -(F16_SCREEN_REL * s1 + F16_SCREEN_ABS);
+    if (mine) {
+        if (empty) sigma[pt] = sg;
+        if (dbg_sigma) { dbg_sigma[pt] = sg; dbg_s1[pt] = s1; }
+    }
+    // the others go to the accurate pass: workgroup-aggregated append
+    const bool keep = mine && !empty;
+    const unsigned long long bm = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = __popcll(bm);
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(keep_count, tot) : 0;
+    }
+    __syncthreads();
+    if (keep) {
+        int off = s_base + __popcll(bm & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) off += s_cnt[k];
+        keep_list[off] = (int32_t)pt;
+    }
+}
+
+void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
+                         const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
+                         float* dbg_s1, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_screen16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, active_list, active_count,
+                       sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_light16 : model/spacenet.py:254-265 + :174-188 LightingMLP with the same split-fp16 products.
 // 9 -> 128 -> 128 -> 1 per point; the 20 weight blocks (80 KB) are L1/L2-resident, so every wave reads its
 // operands straight from memory (no LDS ring: the matrix work per point is 50x smaller than the trunk's).

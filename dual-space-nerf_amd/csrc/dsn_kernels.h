@@ -32,6 +32,9 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
                             hipStream_t st);
+void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
+                         const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
+                         float* dbg_s1, hipStream_t st);
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                         int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);

@@ -139,6 +139,11 @@ DSN_EXPORT int dsn_image_scatter(const float* rgb, const float* disp, const floa
 DSN_EXPORT int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f32, const uint8_t* mask_at_box,
                    int H, int W, double* out4, void* workspace, void* stream);
 
+/* diagnostics of the density screen: the plain-fp16 density sigma~ [N] and the magnitude S1 [N] of its terms for
+ * every point (no lists, nothing skipped) - lets tests measure the margin against dsn_field's sigma. */
+DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
+                     float* sigma_screen, float* s1, int32_t* scratch_list, int32_t* scratch_count, void* stream);
+
 /* ---- training backward: what loss.backward() computes in trainer.py:70-81 -----------------
  * Gradients of L w.r.t. the 33 parameters, given the cotangents of Renderer.render's outputs
  * (utils/loss.py:17-27 uses color and acc_map): d_rgb [R,3] (required), d_disp / d_acc / d_depth [R] and
@@ -171,6 +176,10 @@ DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const float
 /* cfg.MODEL.sample_points_mode == "uniform" (can_render.py:42-51): plain uniform_sampling between the given near/far
  * instead of the geometry-guided interval.  Valid for dsn_render_rays. */
 #define DSN_SAMPLE_UNIFORM 8
+/* eval-mode density screen off: by default dsn_render_rays (with DSN_SKIP_TRANSPARENT, split-fp16 field) first runs a
+ * plain-fp16 pass of the trunk and sends only the samples whose density is not provably negative - sigma~ >= -(1 % of the
+ * magnitude of its terms + 0.01) - through the accurate pass; the others contribute exactly zero either way. */
+#define DSN_NO_SCREEN 16
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,

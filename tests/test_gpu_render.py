@@ -331,3 +331,66 @@ def test_render_view_device_output_and_metrics():
     mk = g["mask_at_box"].reshape(H, W)
     assert abs(m["psnr_woMask"] - (-10 * np.log10(d2.mean()))) < 1e-9
     assert abs(m["psnr_wMask"] - (-10 * np.log10(d2[mk].mean()))) < 1e-9
+
+
+def test_density_screen_margin():
+    """the plain-fp16 density screen (k_screen16) may only declare a sample empty when its accurate density is negative:
+    on a whole 512 x 512 x 64 frame no empty-declared sample has sigma > 0, the margin (1 % of the term magnitude S1 + 0.01)
+    is >= 10x the largest deviation actually observed, and the rendered frame is bit-identical with the screen on / off"""
+    import dsnerf_amd
+    from dsnerf_amd import _lib, synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(512, 512, xyz, fit_box=True)
+    S = 64
+    r = make_renderer({"canonical_vertex": canon, "faces": faces, "S": S})
+    r.eval()
+    batch = {"ray_o": torch.from_numpy(rays["ray_o"])[None], "ray_d": torch.from_numpy(rays["ray_d"])[None],
+             "near": torch.from_numpy(rays["near"].copy())[None], "far": torch.from_numpy(rays["far"].copy())[None],
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(synth.make_poses())[None],
+             "Th": torch.tensor([0.2, -0.1, 1.0]).reshape(1, 1, 3), "frame": torch.tensor([5])}
+    r._set_frame(batch)
+    dev = r.device
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+    pts, z = _lib.sample(r.scene, o, d, n, f, S, r._t_vals(S), None)
+    w = _lib.warp(r.scene, pts, d, S, want_dir=False, want_active=True)
+    packed = r.net.packed(dev)
+    act = w["active_list"][: int(w["active_count"][0])].long()
+    sig, _, _ = _lib.field(r.scene, packed, w["x_c"], want_essence=False, want_grad=False, active=(w["active_list"], w["active_count"]), fp32=True)
+    sg, s1 = _lib.screen_debug(r.scene, packed, w["x_c"])
+    sig, sg, s1 = sig[act], sg[act], s1[act]
+    dev_rel = ((sg - sig).abs() / s1).max().item()
+    dev_abs = (sg - sig).abs().max().item()
+    empty = sg < -(0.01 * s1 + 0.01)
+    assert int((empty & (sig > 0)).sum()) == 0
+    assert float(sig[empty].max()) < 0.0
+    assert 0.01 >= 10 * dev_rel, (dev_rel, dev_abs)
+    print(f"screen: {float(empty.float().mean()):.3f} of the evaluated samples declared empty; max |sigma~ - sigma| = {dev_abs:.2e}"
+          f" = {dev_rel:.2e} S1; smallest slack of an empty sample {float((-sig[empty]).min()):.3e}")
+    outs = []
+    for screen in (True, False):
+        n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        outs.append(_lib.render_rays(r.scene, packed, _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S), screen=screen))
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert torch.equal(torch.isnan(outs[0]["disp_map"]), torch.isnan(outs[1]["disp_map"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_density_screen_is_invisible_on_the_golden_cases(name):
+    g = load(name)
+    r = make_renderer(g, name)
+    r.eval()
+    from dsnerf_amd import _lib
+    b = make_batch(g)
+    r._set_frame(b)
+    dev = r.device
+    S = int(g["S"])
+    o, d = r._dev(b["ray_o"][0]), r._dev(b["ray_d"][0])
+    outs = []
+    for screen in (True, False):
+        n2, f2 = r._dev(b["near"][0]).clone(), r._dev(b["far"][0]).clone()
+        outs.append(_lib.render_rays(r.scene, r.net.packed(dev), _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S), screen=screen))
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
