@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 FLOP_FIELD_PER_SAMPLE = 2.0 * 884608.0       # k_field: forward trunk+heads 458 880 MAC + reverse 425 728 MAC
 FLOP_FIELD_FWD_PER_SAMPLE = 2.0 * 458880.0   # k_field16<forward>: trunk + density/essence heads
 FLOP_FIELD_REV_PER_SAMPLE = 2.0 * 425728.0   # k_field16<reverse>: analytic d sigma/dx
+FLOP_SCREEN_PER_SAMPLE = 2.0 * 425728.0      # k_screen16: trunk + density head, one fp16 product per algorithmic product
 FLOP_ALL_PER_SAMPLE = 2.0 * 902272.0         # + lighting MLP 17 664 MAC
 PEAK_F32_MATRIX_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_F16_MATRIX_TFLOPS = 2500.0              # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
@@ -381,6 +382,17 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
         return float(np.mean(ms))
 
     split = not (args.fp32 or args.dense)
+    screen = split and not args.no_screen
+    ms_screen = None
+    n_all = n_eval
+    if screen:
+        # the density screen runs first, on every non-transparent sample; the accurate forward sees what it keeps
+        keep = torch.zeros(N, dtype=torch.int32, device=dev)
+        kcnt = torch.zeros(64, dtype=torch.int32, device=dev)
+        ms_screen = timed(lambda: L.dsn_field_screen(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(keep),
+                                                     _lib._ptr(kcnt), _lib._stream()), pre=lambda: kcnt.zero_())
+        lst, cnt = keep, kcnt
+        n_eval = int(kcnt[0])
     if split:
         rec = torch.empty(L.dsn_field_record_bytes(C.c_int64(N)), dtype=torch.uint8, device=dev)
         pos = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -407,6 +419,12 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
            "frac": ach / peak, "traffic": measured_traffic(kern, args), "kernel_ms": ms, "samples_per_launch": n_eval,
            "flop_per_sample": flop_per, "scheme": note, "x_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
+    if screen:
+        ach_s = n_all * FLOP_SCREEN_PER_SAMPLE / (ms_screen * 1e-3) / 1e12
+        out["screen_kernel"] = {"kernel": "k_screen16", "kernel_ms": ms_screen, "samples_per_launch": n_all,
+                                "flop_per_sample": FLOP_SCREEN_PER_SAMPLE, "achieved": ach_s, "peak": PEAK_F16_MATRIX_TFLOPS,
+                                "frac": ach_s / PEAK_F16_MATRIX_TFLOPS,
+                                "scheme": "plain fp16 operands, fp32 accumulate: 1 MFMA product per algorithmic product"}
     if split:
         ach_r = n_pos * FLOP_FIELD_REV_PER_SAMPLE / (ms_rev * 1e-3) / 1e12
         out["reverse_kernel"] = {"kernel": "k_field16<reverse>", "kernel_ms": ms_rev, "samples_per_launch": n_pos,

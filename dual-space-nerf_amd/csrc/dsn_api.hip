@@ -208,6 +208,17 @@ int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f
     return dsn_check_launch("dsn_image_psnr");
 }
 
+int dsn_field_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
+                     const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && sigma && keep_list && keep_count, "dsn_field_screen: null argument");
+    DSN_REQUIRE(N > 0 && V > 0 && F > 0, "dsn_field_screen: bad sizes");
+    DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_field_screen: active_list and active_count go together");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_screen16((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, keep_list, keep_count, nullptr,
+                        nullptr, (hipStream_t)stream);
+    return dsn_check_launch("dsn_field_screen");
+}
+
 int dsn_debug_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, float* sigma_screen,
                      float* s1, int32_t* scratch_list, int32_t* scratch_count, void* stream) {
     DSN_REQUIRE(scene && packed && x_c && sigma_screen && s1 && scratch_list && scratch_count, "dsn_debug_screen: null argument");

@@ -139,6 +139,13 @@ DSN_EXPORT int dsn_image_scatter(const float* rgb, const float* disp, const floa
 DSN_EXPORT int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const float* gt_f32, const uint8_t* mask_at_box,
                    int H, int W, double* out4, void* workspace, void* stream);
 
+/* The density screen as a stage (what dsn_render_rays runs first in eval mode): for the listed points (or all N) the
+ * plain-fp16 trunk; points whose density is provably negative get that negative value in sigma [N] and are dropped, the
+ * others are appended to keep_list (keep_count zeroed by the caller) for dsn_field_forward. */
+DSN_EXPORT int dsn_field_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
+                     const int32_t* active_list, const int32_t* active_count, float* sigma, int32_t* keep_list,
+                     int32_t* keep_count, void* stream);
+
 /* diagnostics of the density screen: the plain-fp16 density sigma~ [N] and the magnitude S1 [N] of its terms for
  * every point (no lists, nothing skipped) - lets tests measure the margin against dsn_field's sigma. */
 DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
