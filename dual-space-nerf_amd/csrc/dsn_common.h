@@ -121,24 +121,6 @@ __device__ __forceinline__ void dsn_sincos(float x, float& s, float& c) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// relu bit patterns without compare masks.  `x > 0 ? .. : ..` costs an SGPR pair per element and LLVM
-// canonicalises every arithmetic spelling of it back to v_cmp + v_cndmask; in the long unrolled network
-// kernels the scheduler then keeps hundreds of such pairs alive and spills them.  Two one-instruction
-// asm ops (opaque to instcombine, still schedulable) pin the VALU-only form.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dsn_nonzero_bit(float v) {       // 1 if v != 0 (v >= 0 by construction)
-    uint32_t b;
-    asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(v)));
-    return b;
-}
-template <int R>
-__device__ __forceinline__ float dsn_keep_if_bit(float a, uint32_t m) {   // a if bit R of m is set, else +0
-    int k;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(k) : "v"(m), "n"(R));
-    return __int_as_float(__float_as_int(a) & k);
-}
-#define DSN_FOR16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
 
 // per-face record: identical values to what the reference recomputes per point
 __device__ __forceinline__ void dsn_make_face(const float* v0, const float* v1, const float* v2, DsnFaceRec& r) {

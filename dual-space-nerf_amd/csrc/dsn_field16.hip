@@ -26,12 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-// build-time variant switches (probed with scripts/probe_field16_variants.sh; defaults = best measured)
+// build-time variant switches (A/B-ed with scripts/variants.sh + scripts/gpu_variants.sh; defaults = best measured)
 #ifndef F16_SINCOS_OCML
 #define F16_SINCOS_OCML 0     // 1: ocml sincosf (divergent large-argument path), 0: branch-free dsn_sincos
-#endif
-#ifndef F16_RELU_ASM
-#define F16_RELU_ASM 0        // 1: asm-pinned VALU-only relu/mask idioms, 0: plain C (LLVM picks cmp+cndmask)
 #endif
 #ifndef F16_FENCE
 #define F16_FENCE 0           // sched_barrier after every block
@@ -211,20 +208,6 @@ __device__ __forceinline__ f32x16 fold16(const f32x16& m, const f32x16& c) {
     return v;
 }
 // relu + its bit pattern / mask application
-#if F16_RELU_ASM
-__device__ __forceinline__ uint32_t relu_bits16(f32x16& a) {
-    uint32_t m = 0;
-#define DSN_RB(R) { const float v = fmaxf(a[R], 0.0f); m = (dsn_nonzero_bit(v) << R) | m; a[R] = v; }
-    DSN_FOR16(DSN_RB)
-#undef DSN_RB
-    return m;
-}
-__device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
-#define DSN_MK(R) a[R] = dsn_keep_if_bit<R>(a[R], m);
-    DSN_FOR16(DSN_MK)
-#undef DSN_MK
-}
-#else
 // Pattern word of 16 accumulator elements: bit (15 - r) set <=> element r is active.  Two VALU ops per element:
 // v_alignbit shifts the sign bit of the pre-activation into the word, v_max applies the relu (a pre-activation of
 // exactly +0 counts as active; it contributes 0 either way in the forward pass, and rounding already decides the
@@ -249,7 +232,6 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = dsn_keep_active(a[r], m, r);
 }
-#endif
 
 // Deferred epilogue, two accumulator registers at a time.  With one wave per SIMD nothing else can cover the VALU
 // work of an epilogue (fold, relu / mask, hi-lo split, pack: ~12 instructions per element), so the epilogue of output
