@@ -179,8 +179,8 @@ def test_full_size_properties():
                           exhaustive=True)
     for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
         assert torch.equal(ex[k], out[k]), k
-    # oracle on 48 rays spread over the image
-    sel = np.linspace(0, 512 * 512 - 1, 48).astype(np.int64)
+    # oracle on 1024 rays spread over the image
+    sel = np.linspace(0, 512 * 512 - 1, 1024).astype(np.int64)
     sd = state()
     tv = torch.linspace(0.0, 1.0, steps=S).numpy()
     # same first-ray origin for the sampler: put ray 0 first (all rays share the camera origin anyway)
