@@ -590,6 +590,12 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
 // (tests/test_gpu_render.py::test_density_screen_margin); every other sample goes to the accurate pass.  An empty
 // sample keeps sigma~ (< 0) as its density, so the compositor sees the same exact zero.  DSN_NO_SCREEN turns it off.
 // ---------------------------------------------------------------------------------------------
+#ifndef F16_SCREEN_SGB
+#define F16_SCREEN_SGB 0      // n > 0: pin 1 MFMA : n VALU inside every block of the screen kernel
+#endif
+#ifndef F16_SCREEN_ACC
+#define F16_SCREEN_ACC 1
+#endif
 #ifndef F16_SCREEN_REL
 #define F16_SCREEN_REL 0.01f
 #endif
@@ -620,7 +626,8 @@ __device__ __forceinline__ void w16s_read(const W16& w, int b, int lane, half8& 
     h0 = *reinterpret_cast<const half8*>(s);
     h1 = *reinterpret_cast<const half8*>(s + 8192);
 }
-// (a0, a1) += 64 Wh[32 rows][32*KB k] xh, one accumulator per k-step
+// a0 += 64 Wh[32 rows][32*KB k] xh.  F16_SCREEN_ACC = 1: one accumulator (the second wave of the SIMD covers the
+// dependent MFMA pair, and the epilogue saves an accumulator read and an add per element); 2: one per k-step
 template <int KB, class Hook = NoHook>
 __device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], f32x16& a0, f32x16& a1,
                                          Hook&& hook = NoHook()) {
@@ -632,15 +639,24 @@ __device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8
             w16s_read(w, blk + 1, lane, n0, n1);
         }
         a0 = MFMA16(w.h0, xh[kb][0], a0);
-        a1 = MFMA16(w.h1, xh[kb][1], a1);
+        if (F16_SCREEN_ACC == 1) a0 = MFMA16(w.h1, xh[kb][1], a0);
+        else a1 = MFMA16(w.h1, xh[kb][1], a1);
         hook(kb);
         w.h0 = n0; w.h1 = n1;
         ++blk;
+#if F16_SCREEN_SGB
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, F16_SCREEN_SGB, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 __device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r >> 3][r & 7] = (_Float16)fmaxf((a[r] + b[r]) * F16_FWD_INV, 0.0f);
+    for (int r = 0; r < 16; ++r) y[r >> 3][r & 7] = (_Float16)fmaxf((F16_SCREEN_ACC == 1 ? a[r] : a[r] + b[r]) * F16_FWD_INV, 0.0f);
 }
 __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&xh)[8][2],
                                          half8 (&yh)[8][2]) {
@@ -654,7 +670,7 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * kb + e;
-                yh[m - 1][r >> 3][r & 7] = (_Float16)fmaxf((p0[r] + p1[r]) * F16_FWD_INV, 0.0f);
+                yh[m - 1][r >> 3][r & 7] = (_Float16)fmaxf((F16_SCREEN_ACC == 1 ? p0[r] : p0[r] + p1[r]) * F16_FWD_INV, 0.0f);
             }
         });
         p0 = a0; p1 = a1;
@@ -745,7 +761,7 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float h = fmaxf((a0[r] + a1[r]) * F16_FWD_INV, 0.0f);
+            const float h = fmaxf((F16_SCREEN_ACC == 1 ? a0[r] : a0[r] + a1[r]) * F16_FWD_INV, 0.0f);
             const float term = wd[r] * h;
             sg += term;
             s1 += fabsf(term);
