@@ -654,9 +654,23 @@ __device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8
 #endif
     }
 }
+// two accumulator elements (64 z) -> relu(z) as packed fp16: convert first, then packed max and packed scale by 2^-6
+// (exact; a |64 z| beyond the fp16 range becomes inf and the sample is simply kept for the accurate pass)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v relu_pair16(float u, float v) {
+    half2v h = {(_Float16)u, (_Float16)v};
+    const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+    const half2v s = {(_Float16)F16_FWD_INV, (_Float16)F16_FWD_INV};
+    h = __builtin_elementwise_max(h, z);
+    return h * s;
+}
 __device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r >> 3][r & 7] = (_Float16)fmaxf((F16_SCREEN_ACC == 1 ? a[r] : a[r] + b[r]) * F16_FWD_INV, 0.0f);
+    for (int r = 0; r < 16; r += 2) {
+        const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(a[r], a[r + 1]) : relu_pair16(a[r] + b[r], a[r + 1] + b[r + 1]);
+        y[r >> 3][r & 7] = h[0];
+        y[r >> 3][(r & 7) + 1] = h[1];
+    }
 }
 __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&xh)[8][2],
                                          half8 (&yh)[8][2]) {
@@ -667,11 +681,10 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
         f32x16 a0 = rows16(bias, m, half), a1 = zero16();
         if (m == 0) dense16s<8>(w, blk, lane, xh, a0, a1);
         else dense16s<8>(w, blk, lane, xh, a0, a1, [&](int kb) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int r = 2 * kb + e;
-                yh[m - 1][r >> 3][r & 7] = (_Float16)fmaxf((F16_SCREEN_ACC == 1 ? p0[r] : p0[r] + p1[r]) * F16_FWD_INV, 0.0f);
-            }
+            const int r = 2 * kb;
+            const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(p0[r], p0[r + 1]) : relu_pair16(p0[r] + p1[r], p0[r + 1] + p1[r + 1]);
+            yh[m - 1][r >> 3][r & 7] = h[0];
+            yh[m - 1][r >> 3][(r & 7) + 1] = h[1];
         });
         p0 = a0; p1 = a1;
     }
