@@ -394,3 +394,32 @@ def test_density_screen_is_invisible_on_the_golden_cases(name):
         outs.append(_lib.render_rays(r.scene, r.net.packed(dev), _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S), screen=screen))
     for k in ("color", "acc_map", "depth_map", "weights"):
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("seed,unit_dirs,S", [(1, False, 64), (2, True, 64), (3, False, 48), (4, True, 96)])
+def test_fast_paths_equal_plain_paths_on_random_frames(seed, unit_dirs, S):
+    """every exact shortcut at once (cell-major + super-cell nearest face, sampler bundle cull, density screen, forward /
+    reverse split) against the plain path (exhaustive search, no screen) on other poses, cameras and sample counts:
+    bit-identical outputs"""
+    import dsnerf_amd
+    from dsnerf_amd import _lib, synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon, seed=20 + seed)
+    rays = synth.make_rays(160, 160, xyz, fit_box=True, unit_dirs=unit_dirs)
+    r = make_renderer({"canonical_vertex": canon, "faces": faces, "S": S})
+    r.eval()
+    batch = {"ray_o": torch.from_numpy(rays["ray_o"])[None], "ray_d": torch.from_numpy(rays["ray_d"])[None],
+             "near": torch.from_numpy(rays["near"].copy())[None], "far": torch.from_numpy(rays["far"].copy())[None],
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(synth.make_poses(seed=40 + seed))[None],
+             "Th": torch.zeros(1, 1, 3), "frame": torch.tensor([7 * seed])}
+    r._set_frame(batch)
+    dev = r.device
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    outs = []
+    for fast in (True, False):
+        n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        outs.append(_lib.render_rays(r.scene, r.net.packed(dev), _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S),
+                                     screen=fast, exhaustive=not fast))
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[0]["acc_map"].max()) > 0.05          # the frame is not empty
