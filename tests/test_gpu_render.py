@@ -423,3 +423,29 @@ def test_fast_paths_equal_plain_paths_on_random_frames(seed, unit_dirs, S):
     for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert float(outs[0]["acc_map"].max()) > 0.05          # the frame is not empty
+
+
+@pytest.mark.parametrize("name", ["small_eval", "full_eval"])
+def test_cellmajor_search_forced_on_golden_cases(name, monkeypatch):
+    """the cell-major nearest-face path (normally only above ~1 M samples) forced on the golden cases: same pixels as the
+    reference and as the per-lane path, bit for bit"""
+    from dsnerf_amd import _lib
+    g = load(name)
+    r = make_renderer(g, name)
+    r.eval()
+    b = make_batch(g)
+    r._set_frame(b)
+    dev = r.device
+    S = int(g["S"])
+    o, d = r._dev(b["ray_o"][0]), r._dev(b["ray_d"][0])
+    outs = []
+    for forced in (True, False):
+        if forced:
+            monkeypatch.setenv("DSN_CELLMAJOR_MIN", "1")
+        else:
+            monkeypatch.delenv("DSN_CELLMAJOR_MIN")
+        n2, f2 = r._dev(b["near"][0]).clone(), r._dev(b["far"][0]).clone()
+        outs.append(_lib.render_rays(r.scene, r.net.packed(dev), _lib.RenderWorkspace(dev), o, d, n2, f2, S, r._t_vals(S)))
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert maxdiff(outs[0]["color"].cpu().numpy(), g["render:color"]) < 1e-4
