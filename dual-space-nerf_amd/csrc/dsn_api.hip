@@ -373,7 +373,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
         int32_t* pcnt = w.count + 16;
         if (!(flags & DSN_NO_SCREEN)) {
-            // plain-fp16 screen: samples whose density is provably negative keep that (negative) density and leave the
+            // plain-fp16 screen: samples whose fp16 density is negative by the safety margin keep that (negative) density and leave the
             // list; count[32] = samples that go through the accurate pass
             int32_t* kcnt = w.count + 32;
             dsn_launch_screen16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.keep, kcnt, nullptr, nullptr, st);
