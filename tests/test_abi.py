@@ -48,6 +48,34 @@ def test_errors_are_loud(lib):
     assert b"dsn_render_rays" in lib.dsn_last_error()
 
 
+def test_every_entry_point_rejects_null_arguments(lib):
+    """each compute entry point checks its arguments before touching the device: all-NULL calls return non-zero and
+    leave a message that names the function (the wrapper turns it into RuntimeError)"""
+    z, i64 = None, C.c_int64
+    calls = {
+        "dsn_set_body": lambda: lib.dsn_set_body(z, z, z, 0, 0, z),
+        "dsn_set_frame": lambda: lib.dsn_set_frame(z, 1, 1, z, z, z, 0, 0, z, z, z, z),
+        "dsn_sample_gg": lambda: lib.dsn_sample_gg(z, 1, 1, z, z, z, z, 0, 0, z, z, z, z, z),
+        "dsn_warp": lambda: lib.dsn_warp(z, 1, 1, z, z, i64(0), 1, z, z, z, z, z, z, z, z, 0, z),
+        "dsn_field": lambda: lib.dsn_field(z, 1, 1, z, z, i64(0), z, z, z, z, z, 0, z),
+        "dsn_field_screen": lambda: lib.dsn_field_screen(z, 1, 1, z, z, i64(0), z, z, z, z, z, z),
+        "dsn_field_forward": lambda: lib.dsn_field_forward(z, 1, 1, z, z, i64(0), z, z, z, z, z, z, z, z),
+        "dsn_field_reverse": lambda: lib.dsn_field_reverse(z, 1, 1, z, z, i64(0), z, z, z, z, z),
+        "dsn_shade": lambda: lib.dsn_shade(z, 1, 1, z, z, z, z, z, z, i64(0), 1, z, z, z, z, z, 0, z),
+        "dsn_camera_rays": lambda: lib.dsn_camera_rays(z, z, z, z, 0, 0, z, z, z, z, z, z),
+        "dsn_image_scatter": lambda: lib.dsn_image_scatter(z, z, z, z, 1, z, 0, 0, 0, z, z, z, z, z, z),
+        "dsn_image_psnr": lambda: lib.dsn_image_psnr(z, z, z, z, 0, 0, z, z, z),
+        "dsn_render_rays_grad": lambda: lib.dsn_render_rays_grad(z, 1, 1, z, z, 0, 0, z, z, z, z, 0, 0, z, z, z, z, z, z, z, z),
+    }
+    for name, call in calls.items():
+        assert call() != 0, name
+        assert name.encode() in lib.dsn_last_error(), (name, lib.dsn_last_error())
+    # frame index outside the embedding table (model/spacenet.py:84: maxFrame = 500) is an argument error, not a crash
+    one = C.c_void_p(1)
+    assert lib.dsn_set_frame(one, 1, 1, one, one, one, 500, 0, z, z, z, z) != 0
+    assert b"frame index" in lib.dsn_last_error()
+
+
 def test_no_fallback_without_gpu():
     import torch
     import dsnerf_amd
