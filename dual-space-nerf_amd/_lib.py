@@ -36,7 +36,7 @@ EXPORTS = [
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
-    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -237,6 +237,26 @@ def field_reverse(scene: Scene, packed: PackedParams, x_c, rec, pos):
     _check(lib().dsn_field_reverse(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
                                    _ptr(pos[0]), _ptr(pos[1]), _ptr(rec), _ptr(g), _stream()), "dsn_field_reverse")
     return g
+
+
+def lbs_warp(scene: Scene, pts, smpl_weights, joint_transforms, bw_type="rigid_center", exhaustive=False):
+    """dormant alternate (utils/render_utils.py:352-403 + utils/blend_utils.py:72-81): nearest-face blend weights and inverse
+    LBS.  Returns dict(face_idx, weights [N,24], transparent, pts_zero [N,3])."""
+    if bw_type not in ("rigid_center", "rigid_interp"):
+        raise ValueError("unsupport value: bw_type")
+    dev = scene.device
+    pts = _f32(pts.reshape(-1, 3), dev)
+    N = pts.shape[0]
+    W = _f32(smpl_weights.reshape(-1, 24), dev)
+    assert W.shape[0] == scene.V
+    A = _f32(joint_transforms.reshape(24, 16), dev)
+    out = {"face_idx": torch.empty(N, dtype=torch.int32, device=dev), "weights": torch.empty(N, 24, dtype=torch.float32, device=dev),
+           "transparent": torch.empty(N, dtype=torch.uint8, device=dev), "pts_zero": torch.empty(N, 3, dtype=torch.float32, device=dev)}
+    _check(lib().dsn_lbs_warp(_ptr(scene.buf), scene.V, scene.F, _ptr(pts), C.c_int64(N), _ptr(W), _ptr(A),
+                              0 if bw_type == "rigid_center" else 1, _ptr(out["face_idx"]), _ptr(out["weights"]),
+                              _ptr(out["transparent"]), _ptr(out["pts_zero"]), NN_EXHAUSTIVE if exhaustive else 0, _stream()),
+           "dsn_lbs_warp")
+    return out
 
 
 def screen_debug(scene: Scene, packed: PackedParams, x_c):

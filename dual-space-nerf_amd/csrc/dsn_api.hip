@@ -115,6 +115,18 @@ int dsn_warp(const void* scene, int V, int F, const float* pts, const float* ray
     return dsn_check_launch("dsn_warp");
 }
 
+int dsn_lbs_warp(const void* scene, int V, int F, const float* pts, int64_t N, const float* smpl_weights,
+                 const float* joint_transforms, int bw_type, int32_t* face_idx, float* weights, uint8_t* transparent,
+                 float* pts_zero, int flags, void* stream) {
+    DSN_REQUIRE(scene && pts && smpl_weights && joint_transforms, "dsn_lbs_warp: null argument");
+    DSN_REQUIRE(N > 0 && V > 0 && F > 0, "dsn_lbs_warp: bad sizes");
+    DSN_REQUIRE(bw_type == 0 || bw_type == 1, "dsn_lbs_warp: unsupport value: bw_type");   // the reference raises ValueError
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_lbs_warp(s, pts, N, smpl_weights, joint_transforms, bw_type, face_idx, weights, transparent, pts_zero,
+                        (flags & DSN_NN_EXHAUSTIVE) != 0, (hipStream_t)stream);
+    return dsn_check_launch("dsn_lbs_warp");
+}
+
 int dsn_field(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* active_list,
               const int32_t* active_count, float* sigma, float* essence, float* grad, int flags, void* stream) {
     DSN_REQUIRE(scene && packed && x_c && sigma, "dsn_field: null argument");

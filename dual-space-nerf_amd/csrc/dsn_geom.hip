@@ -376,6 +376,84 @@ void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dormant alternate of the warp (no reference entry point calls it any more): nearest posed face ->
+// blend weights of the point (utils/render_utils.py:112-164: "rigid_center" = mean of the three vertex rows,
+// "rigid_interp" = softmax over the three vertex distances, as written) -> inverse linear-blend skinning
+// (utils/blend_utils.py:72-81 ppts_to_pts: blend the 24 joint transforms, subtract the translation, apply the inverse
+// rotation).  One thread per point; the nearest face comes from the same exact lists as k_warp.
+// ---------------------------------------------------------------------------------------------
+template <bool EXHAUSTIVE>
+__global__ void __launch_bounds__(WARP_THREADS) k_lbs_warp(DsnNNArgs nn, const float4* __restrict__ cent_world,
+                                                            const DsnFaceRec* __restrict__ face_world,
+                                                            const int32_t* __restrict__ faces, const float* __restrict__ xyz, int F,
+                                                            const float* __restrict__ pts, int64_t N,
+                                                            const float* __restrict__ smpl_w, const float* __restrict__ A,
+                                                            int bw_type, int32_t* __restrict__ face_idx,
+                                                            float* __restrict__ weights, uint8_t* __restrict__ transparent,
+                                                            float* __restrict__ pts_zero) {
+    __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
+    __shared__ float s_A[24 * 12];
+    for (int e = threadIdx.x; e < 24 * 12; e += WARP_THREADS) s_A[e] = A[16 * (e / 12) + (e % 12)];   // rows 0..2 of every 4x4
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
+    const bool valid = i < N;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (valid) { p[0] = pts[3 * i]; p[1] = pts[3 * i + 1]; p[2] = pts[3 * i + 2]; }
+    int fi = 0;
+    if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_world, F, p[0], p[1], p[2], s_tile);
+    else if (valid) fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_world, F, p[0], p[1], p[2]);
+    if (!valid) return;
+    const DsnFaceRec fw = dsn_load_face(face_world, fi);
+    float u, v, h;
+    dsn_project(p, fw, u, v, h);
+    if (face_idx) face_idx[i] = fi;
+    if (transparent) transparent[i] = ((u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f)) ? 1 : 0;
+    const int v0 = faces[3 * fi], v1 = faces[3 * fi + 1], v2 = faces[3 * fi + 2];
+    float w3[3] = {0.f, 0.f, 0.f};
+    if (bw_type == 1) {
+        float d[3];
+        const int vid[3] = {v0, v1, v2};
+        for (int k = 0; k < 3; ++k) {
+            const float e[3] = {xyz[3 * vid[k]] - p[0], xyz[3 * vid[k] + 1] - p[1], xyz[3 * vid[k] + 2] - p[2]};
+            d[k] = dsn_norm3(e);
+        }
+        const float m = fmaxf(fmaxf(d[0], d[1]), d[2]);
+        float s = 0.f;
+        for (int k = 0; k < 3; ++k) { w3[k] = expf(d[k] - m); s += w3[k]; }
+        for (int k = 0; k < 3; ++k) w3[k] = dsn_div(w3[k], s);
+    }
+    float M[12];
+    for (int e = 0; e < 12; ++e) M[e] = 0.f;
+    for (int j = 0; j < 24; ++j) {
+        const float a = smpl_w[24 * v0 + j], b = smpl_w[24 * v1 + j], c = smpl_w[24 * v2 + j];
+        const float bw = bw_type == 1 ? (w3[0] * a + w3[1] * b) + w3[2] * c : dsn_div((a + b) + c, 3.0f);
+        if (weights) weights[24 * i + j] = bw;
+        for (int e = 0; e < 12; ++e) M[e] = fmaf(bw, s_A[12 * j + e], M[e]);
+    }
+    if (pts_zero) {
+        const float a = M[0], b = M[1], c = M[2], d = M[4], e2 = M[5], f = M[6], g = M[8], hh = M[9], k2 = M[10];
+        const float c00 = e2 * k2 - f * hh, c01 = d * k2 - f * g, c02 = d * hh - e2 * g;
+        const float det = a * c00 - b * c01 + c * c02;
+        const float q[3] = {p[0] - M[3], p[1] - M[7], p[2] - M[11]};
+        const float inv[9] = {c00, c * hh - b * k2, b * f - c * e2, -c01, a * k2 - c * g, c * d - a * f, c02, b * g - a * hh, a * e2 - b * d};
+        for (int r = 0; r < 3; ++r)
+            pts_zero[3 * i + r] = dsn_div(inv[3 * r] * q[0] + inv[3 * r + 1] * q[1] + inv[3 * r + 2] * q[2], det);
+    }
+}
+
+void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, const float* smpl_w, const float* A, int bw_type,
+                         int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st) {
+    int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
+    DsnNNArgs nn = dsn_nn_args(s.nn_world);
+    if (exhaustive)
+        hipLaunchKernelGGL(k_lbs_warp<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world, s.faces,
+                           s.xyz, s.F, pts, N, smpl_w, A, bw_type, face_idx, weights, transparent, pts_zero);
+    else
+        hipLaunchKernelGGL(k_lbs_warp<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world, s.faces,
+                           s.xyz, s.F, pts, N, smpl_w, A, bw_type, face_idx, weights, transparent, pts_zero);
+}
+
+// ---------------------------------------------------------------------------------------------
 // normals: model/spacenet.py:278-298 normal_local2world.  One thread per (listed) point.
 // ---------------------------------------------------------------------------------------------
 template <bool EXHAUSTIVE>

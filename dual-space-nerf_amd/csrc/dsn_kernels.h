@@ -18,6 +18,8 @@ void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o
 size_t dsn_nn_sort_scratch_size(int64_t N);
 void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
                              int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
+void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, const float* smpl_w, const float* A, int bw_type,
+                         int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
                        bool exhaustive, hipStream_t st);

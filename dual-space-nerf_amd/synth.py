@@ -257,3 +257,26 @@ def make_state_dict(seed: int = 11, gain: float = 1.6) -> dict:
 def make_poses(seed: int = 5) -> np.ndarray:
     """SMPL axis-angle pose [24,3] ~ N(0, 0.2^2) (batch['poses'] without the leading 1)."""
     return (hash_normal(72, seed) * np.float32(0.2)).reshape(24, 3).astype(np.float32)
+
+
+def make_joint_transforms(seed: int = 303) -> np.ndarray:
+    """24 rigid joint transforms [24,4,4] (Rodrigues rotations up to ~0.8 rad + small translations), float32."""
+    r = (hash_uniform(72, seed).reshape(24, 3) - 0.5) * 0.9
+    t = (hash_uniform(72, seed + 1).reshape(24, 3) - 0.5) * 0.3
+    A = np.zeros((24, 4, 4), np.float64)
+    for j in range(24):
+        th = np.linalg.norm(r[j]) + 1e-12
+        k = r[j] / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        A[j, :3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        A[j, :3, 3] = t[j]
+        A[j, 3, 3] = 1
+    return A.astype(np.float32)
+
+
+def make_skin_weights(V: int, seed: int = 302) -> np.ndarray:
+    """[V,24] rows on the simplex with a few dominant joints each (the shape of SMPL's blend weights), float32."""
+    u = hash_uniform(V * 24, seed).reshape(V, 24).astype(np.float64)
+    w = np.exp(12.0 * u)
+    return (w / w.sum(1, keepdims=True)).astype(np.float32)
+

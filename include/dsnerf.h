@@ -83,6 +83,16 @@ DSN_EXPORT int dsn_warp(const void* scene, int V, int F, const float* pts, const
              float* h, uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list,
              int32_t* active_count, int flags, void* stream);
 
+/* Dormant alternate of the warp (nothing in the reference calls it any more, pinned at function level):
+ * utils/render_utils.py:352-403 compute_nn_mesh - blend weights of each point from its nearest posed face (:112-164,
+ * bw_type 0 = "rigid_center", 1 = "rigid_interp") and the transparency mask - followed by utils/blend_utils.py:72-81
+ * ppts_to_pts, the inverse linear-blend skinning with those weights.  smpl_weights [V,24], joint_transforms [24,4,4]
+ * row-major (device).  Outputs (any may be NULL): face_idx [N], weights [N,24], transparent [N], pts_zero [N,3].
+ * flags: DSN_NN_EXHAUSTIVE. */
+DSN_EXPORT int dsn_lbs_warp(const void* scene, int V, int F, const float* pts, int64_t N, const float* smpl_weights,
+                 const float* joint_transforms, int bw_type, int32_t* face_idx, float* weights, uint8_t* transparent,
+                 float* pts_zero, int flags, void* stream);
+
 /* model/spacenet.py:93-148 SpaceNet.forward + :301-311 gradient(): sigma [N], essence [N,3],
  * grad = d sigma / d x_c [N,3].  If active_list != NULL only the listed points (count read from
  * active_count on the device) are evaluated and written; the rest are left untouched. */

@@ -230,6 +230,65 @@ ORC_API void orc_warp(const float* pts, const float* dirs, int64_t N, const floa
     if (!idx_out) free(idx);
 }
 
+/* dormant alternate of the warp: utils/render_utils.py:352-403 compute_nn_mesh with
+ * :112-164 get_base_blending_weights (bw_type 0 = "rigid_center": mean of the nearest face's three vertex weights;
+ * 1 = "rigid_interp": softmax over the three vertex DISTANCES as written there) and utils/blend_utils.py:72-81
+ * ppts_to_pts (blend the 24 joint transforms, subtract the translation, apply the inverse rotation).
+ * smpl_w [V,24], A [24,16] row-major 4x4.  Outputs (any may be NULL): idx [N], weights [N,24], transparent [N], pts_zero [N,3]. */
+ORC_API void orc_lbs_warp(const float* pts, int64_t N, const float* xyz, const int32_t* faces, int F, const float* smpl_w,
+                          const float* A, int bw_type, int32_t* idx_out, float* weights, uint8_t* transparent,
+                          float* pts_zero) {
+    float* cent = (float*)malloc(sizeof(float) * 3 * F);
+    int32_t* idx = idx_out ? idx_out : (int32_t*)malloc(sizeof(int32_t) * N);
+    orc_centroids(xyz, faces, F, cent);
+    orc_nearest_face(pts, N, cent, F, idx);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        float tw[9], uv[2], h, bw[24], wk[3];
+        const float* p = pts + 3 * i;
+        gather_tri(xyz, faces, idx[i], tw);
+        project_pt(p, tw, uv, &h);
+        if (transparent)
+            transparent[i] = (uv[0] > 5.f) || (uv[0] < -4.f) || (uv[1] > 5.f) || (uv[1] < -4.f) || (fabsf(h) > 0.1f);
+        const int32_t* vid = faces + 3 * idx[i];
+        if (bw_type == 1) {
+            float d[3], m, s = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                float e[3] = {tw[3 * k] - p[0], tw[3 * k + 1] - p[1], tw[3 * k + 2] - p[2]};
+                d[k] = norm3(e);
+            }
+            m = d[0] > d[1] ? d[0] : d[1];
+            m = m > d[2] ? m : d[2];
+            for (int k = 0; k < 3; ++k) { wk[k] = expf(d[k] - m); s += wk[k]; }
+            for (int k = 0; k < 3; ++k) wk[k] = wk[k] / s;
+            for (int j = 0; j < 24; ++j)
+                bw[j] = (wk[0] * smpl_w[24 * vid[0] + j] + wk[1] * smpl_w[24 * vid[1] + j]) + wk[2] * smpl_w[24 * vid[2] + j];
+        } else {
+            for (int j = 0; j < 24; ++j)
+                bw[j] = ((smpl_w[24 * vid[0] + j] + smpl_w[24 * vid[1] + j]) + smpl_w[24 * vid[2] + j]) / 3.0f;
+        }
+        if (weights) for (int j = 0; j < 24; ++j) weights[24 * i + j] = bw[j];
+        if (pts_zero) {
+            double M[12];      /* blended [R | t], rows 0..2 of the 4x4; double accumulation, then the closed-form inverse */
+            for (int e = 0; e < 12; ++e) {
+                double acc = 0.0;
+                for (int j = 0; j < 24; ++j) acc += (double)bw[j] * (double)A[16 * j + e];
+                M[e] = (double)(float)acc;
+            }
+            const double a = M[0], b = M[1], c = M[2], d = M[4], e2 = M[5], f = M[6], g = M[8], hh = M[9], k2 = M[10];
+            const double det = a * (e2 * k2 - f * hh) - b * (d * k2 - f * g) + c * (d * hh - e2 * g);
+            const double q[3] = {(double)p[0] - M[3], (double)p[1] - M[7], (double)p[2] - M[11]};
+            const double inv[9] = {(e2 * k2 - f * hh) / det, (c * hh - b * k2) / det, (b * f - c * e2) / det,
+                                   (f * g - d * k2) / det, (a * k2 - c * g) / det, (c * d - a * f) / det,
+                                   (d * hh - e2 * g) / det, (b * g - a * hh) / det, (a * e2 - b * d) / det};
+            for (int r = 0; r < 3; ++r)
+                pts_zero[3 * i + r] = (float)(inv[3 * r] * q[0] + inv[3 * r + 1] * q[1] + inv[3 * r + 2] * q[2]);
+        }
+    }
+    free(cent);
+    if (!idx_out) free(idx);
+}
+
 /* --------------------------------------------------------------------------------------
  * network
  * ------------------------------------------------------------------------------------ */

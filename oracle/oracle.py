@@ -113,6 +113,21 @@ def warp(pts, dirs, xyz, canon, faces):
     return dict(idx=idx, uv=uv, h=h, transparent=tr.astype(bool), x_c=xc, ray_d_can=rdc)
 
 
+def lbs_warp(pts, xyz, faces, smpl_w, A, bw_type=0):
+    """nearest-face blend weights + inverse LBS (utils/render_utils.py:352-403, utils/blend_utils.py:72-81)."""
+    pts, xyz = _f(pts).reshape(-1, 3), _f(xyz)
+    faces = np.ascontiguousarray(faces, np.int32)
+    smpl_w, A = _f(smpl_w), _f(A).reshape(24, 16)
+    N = pts.shape[0]
+    idx = np.empty(N, np.int32)
+    w = np.empty((N, 24), np.float32)
+    tr = np.empty(N, np.uint8)
+    z = np.empty((N, 3), np.float32)
+    lib().orc_lbs_warp(_p(pts), C.c_int64(N), _p(xyz), _p(faces), C.c_int(faces.shape[0]), _p(smpl_w), _p(A), C.c_int(bw_type),
+                       _p(idx), _p(w), _p(tr), _p(z))
+    return dict(idx=idx, weights=w, transparent=tr.astype(bool), pts_zero=z)
+
+
 def pose_feat(poses, params: Params):
     poses = _f(poses).reshape(24, 3)
     q = np.empty(92, np.float32)

@@ -317,3 +317,29 @@ def test_sampler_bundle_cull_is_exact_at_full_size(ctx):
         o = O.sample_gg(rays["ray_o"][idx][sel], rays["ray_d"][idx][sel], n0, f0, xyz, S, t_vals=tv.numpy())
         assert np.array_equal(z.cpu().numpy()[sel], o["z_vals"]), order
         assert np.array_equal(near.cpu().numpy()[sel], o["near"]) and np.array_equal(far.cpu().numpy()[sel], o["far"]), order
+
+
+@pytest.mark.parametrize("name", ["lbs_small", "lbs_full"])
+@pytest.mark.parametrize("bw_type", ["rigid_center", "rigid_interp"])
+def test_lbs_alternate(ctx, name, bw_type):
+    """f-4: dsn_lbs_warp against the reference's (dormant) functions and the oracle; the nearest face is exact, the
+    blend weights within float rounding, the unposed point within 1e-5"""
+    import dsnerf_amd.synth as synth
+    _lib, dev = ctx["lib"], ctx["dev"]
+    g = load(name)
+    canon, faces = synth.make_small_body() if int(g["small"]) else synth.make_body()
+    xyz = synth.pose_body(canon)
+    W = synth.make_skin_weights(xyz.shape[0], int(g["seed_weights"]))
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(ctx["packed"], torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    o = O.lbs_warp(g["pts"], xyz, faces, W, g["A"], 0 if bw_type == "rigid_center" else 1)
+    for exhaustive in (False, True):
+        out = _lib.lbs_warp(sc, T(g["pts"], dev), torch.from_numpy(W), torch.from_numpy(g["A"]), bw_type, exhaustive=exhaustive)
+        assert np.array_equal(out["face_idx"].cpu().numpy(), o["idx"])
+        assert np.array_equal(out["transparent"].cpu().numpy().astype(bool), g["transparent:" + bw_type])
+        assert maxdiff(out["weights"].cpu().numpy(), g["weights:" + bw_type]) < 2e-7
+        assert maxdiff(out["pts_zero"].cpu().numpy(), g["pts_zero:" + bw_type]) < 1e-5
+        assert maxdiff(out["pts_zero"].cpu().numpy(), o["pts_zero"]) < 1e-5
+    with pytest.raises(ValueError):
+        _lib.lbs_warp(sc, T(g["pts"], dev), torch.from_numpy(W), torch.from_numpy(g["A"]), "nearest")
+

@@ -127,3 +127,20 @@ def test_train_oracle_reproduces_reference_autograd(name):
         a = a if a.size <= 20000 else a[idx(a.size)]
         b = g["grad:" + k].astype(np.float64)
         assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-12, k
+
+
+@pytest.mark.parametrize("name", ["lbs_small", "lbs_full"])
+@pytest.mark.parametrize("bw_type", ["rigid_center", "rigid_interp"])
+def test_lbs_alternate_oracle_matches_reference_functions(name, bw_type):
+    """orc_lbs_warp against utils/render_utils.py:352-403 compute_nn_mesh + utils/blend_utils.py:72-81 ppts_to_pts
+    (tests/golden/make_golden_lbs.py)"""
+    import dsnerf_amd.synth as synth
+    g = load(name)
+    canon, faces = synth.make_small_body() if int(g["small"]) else synth.make_body()
+    xyz = synth.pose_body(canon)
+    W = synth.make_skin_weights(xyz.shape[0], int(g["seed_weights"]))
+    o = O.lbs_warp(g["pts"], xyz, faces, W, g["A"], 0 if bw_type == "rigid_center" else 1)
+    assert np.array_equal(o["transparent"], g["transparent:" + bw_type])
+    assert maxdiff(o["weights"], g["weights:" + bw_type]) < 1e-7
+    assert maxdiff(o["pts_zero"], g["pts_zero:" + bw_type]) < 2e-6
+
