@@ -16,7 +16,7 @@ SOURCES = ["dsn_api.hip", "dsn_geom.hip", "dsn_nn.hip", "dsn_field.hip", "dsn_fi
 HEADERS = ["dsn_common.h", "dsn_nn.h", "dsn_kernels.h", os.path.join("..", "..", "include", "dsnerf.h")]
 LIB = os.path.join(HERE, "libdsnerf_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-Wno-inline-asm"]   # inline-asm: the declared m0 clobber of the LDS-DMA statements
 
 
 def _stale(target, deps):
