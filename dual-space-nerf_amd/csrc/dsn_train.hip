@@ -190,6 +190,23 @@ __global__ void __launch_bounds__(T_THREADS) k_t_rowdot(const float* __restrict_
     }
 }
 
+// a = (h > 0) ? a : 0 on a [N,256] matrix AND its column sums accumulated into out[256] (one pass instead of two)
+__global__ void __launch_bounds__(T_THREADS) k_t_mask_colsum256(float* __restrict__ a, const float* __restrict__ h, int64_t N,
+                                                                 int rows_per_block, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    int64_t end = base + rows_per_block;
+    if (end > N) end = N;
+    float acc = 0.0f;
+    for (int64_t n = base; n < end; ++n) {
+        const int64_t t = n * 256 + c;
+        float v = a[t];
+        if (!(h[t] > 0.0f)) { v = 0.0f; a[t] = 0.0f; }
+        acc += v;
+    }
+    atomicAdd(out + c, acc);
+}
+
 // column sums of a [N,C] matrix (C <= 256), accumulated into out[C]
 __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict__ a, int C, int64_t N, int rows_per_block,
                                                          float* __restrict__ out) {
@@ -710,7 +727,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
     hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
     for (int l = 6; l >= 0; --l) {
         float* gW = grd[kTrunkW[l]];
-        colsum(cur, 256, N64, l == 0 ? w.small : grd[kTrunkB[l]], st);
+        if (l == 6) colsum(cur, 256, N64, grd[kTrunkB[6]], st);   // the deeper layers get theirs from k_t_mask_colsum256
         if (l == 0) {
             T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W0_PE_COL, 87, st));
             break;
@@ -718,7 +735,9 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
         T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.h[l - 1], 256, cur, 256, gW, kTrunkLd[l], st));
         if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W4_PE_COL, 319, st));
         T_CHECK(lin_bwd(h, N, 256, 256, cur, 256, prm[kTrunkW[l]], kTrunkLd[l], nxt, 256, 0.0f));
-        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l - 1], tot);
+        // mask + the bias gradient of layer l-1 (= column sums of the masked adjoint) in one pass
+        hipLaunchKernelGGL(k_t_mask_colsum256, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, nxt, w.h[l - 1], N64, 64,
+                           l - 1 == 0 ? w.small : grd[kTrunkB[l - 1]]);
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
