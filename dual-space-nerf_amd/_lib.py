@@ -368,7 +368,7 @@ class GradWorkspace:
 
 
 def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, d_rgb, d_disp=None,
-                     d_acc=None, d_depth=None, d_weights=None, ws: GradWorkspace = None):
+                     d_acc=None, d_depth=None, d_weights=None, ws: GradWorkspace = None, packed: PackedParams = None):
     """Parameter gradients of render_rays' outputs (dsn_render_rays_grad; trainer.py:70-81 loss.backward()).
     params: the 33 tensors in PARAM_ORDER (name -> tensor dict or list).  Returns a list of 33 gradient tensors
     (float32, on the device, shaped like the parameters).  The scene's frame must be set with the same parameters."""
@@ -376,6 +376,8 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
     if isinstance(params, dict):
         params = [params[k] for k in PARAM_ORDER]
     prm = [_f32(p.detach(), dev) for p in params]
+    if packed is None:       # MFMA image of the same parameters (the fused forward / reverse kernel streams it)
+        packed = PackedParams(dev).update(dict(zip(PARAM_ORDER, prm)))
     grads = [torch.empty_like(p) for p in prm]
     pp = (C.c_void_p * 33)(*[p.data_ptr() for p in prm])
     gp = (C.c_void_p * 33)(*[g.data_ptr() for g in grads])
@@ -385,11 +387,11 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
     poses = _f32(poses.reshape(24, 3), dev)
     f = lambda a: None if a is None else _f32(a, dev)
     args = [f(ray_o), f(ray_d), f(z_vals), f(noise), f(d_rgb), f(d_disp), f(d_acc), f(d_depth), f(d_weights)]
-    _check(lib().dsn_render_rays_grad(_ptr(scene.buf), scene.V, scene.F, pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
+    _check(lib().dsn_render_rays_grad(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
                                       _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), int(R), int(S),
                                       _ptr(args[4]), _ptr(args[5]), _ptr(args[6]), _ptr(args[7]), _ptr(args[8]), gp,
                                       _ptr(buf), _stream()), "dsn_render_rays_grad")
-    scene._keep_grad = (prm, args, poses)
+    scene._keep_grad = (prm, args, poses, packed)
     return grads
 
 

@@ -67,7 +67,7 @@ class _RenderRays(torch.autograd.Function):
         if not hasattr(r, "_grad_ws"):
             r._grad_ws = _lib.GradWorkspace(r.device)
         grads = _lib.render_rays_grad(r.scene, sd, poses, frame, zero_code, o, d, ctx.z_vals, noise, g_color, g_disp, g_acc,
-                                      g_depth, g_weights, ws=r._grad_ws)
+                                      g_depth, g_weights, ws=r._grad_ws, packed=packed)
         grads = [g.to(device=p.device, dtype=p.dtype).reshape(p.shape) for g, p in zip(grads, ctx.params)]
         return (None, None) + tuple(grads)
 

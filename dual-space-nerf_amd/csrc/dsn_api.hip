@@ -245,19 +245,19 @@ int dsn_debug_screen(const void* scene, int V, int F, const void* packed, const 
 
 size_t dsn_grad_workspace_bytes(int R, int S) { return (R > 0 && S > 0) ? dsn_train_workspace_size((int64_t)R * S) : 0; }
 
-int dsn_render_rays_grad(const void* scene, int V, int F, const float* const* params33_host, const float* poses24x3,
+int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
                          void* stream) {
-    DSN_REQUIRE(scene && params33_host && poses24x3 && ray_o && ray_d && z_vals && d_rgb && grads33_host && workspace,
+    DSN_REQUIRE(scene && packed && params33_host && poses24x3 && ray_o && ray_d && z_vals && d_rgb && grads33_host && workspace,
                 "dsn_render_rays_grad: null argument");
     DSN_REQUIRE(R > 0 && S > 0 && V > 0 && F > 0, "dsn_render_rays_grad: bad sizes");
     DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_render_rays_grad: frame index outside the embedding table");
     for (int i = 0; i < DSN_NUM_PARAMS; ++i)
         DSN_REQUIRE(params33_host[i] && grads33_host[i], "dsn_render_rays_grad: null parameter / gradient pointer");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    const char* err = dsn_train_run(s, params33_host, poses24x3, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, R, S, d_rgb,
+    const char* err = dsn_train_run(s, (const float*)packed, params33_host, poses24x3, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, R, S, d_rgb,
                                     d_disp, d_acc, d_depth, d_weights, grads33_host, workspace, (hipStream_t)stream);
     if (err) return dsn_fail("dsn_render_rays_grad: %s failed", err);
     return dsn_check_launch("dsn_render_rays_grad");

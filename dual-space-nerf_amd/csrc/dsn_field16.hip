@@ -237,9 +237,12 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 // work of an epilogue (fold, relu / mask, hi-lo split, pack: ~12 instructions per element), so the epilogue of output
 // block m-1 is cut into 8 slices of two elements and slice kb is issued right behind the MFMAs of block (m, kb):
 // the matrix pipe stays busy while the VALU retires the previous block.
-template <bool FWD>
+// ST (training kernel only): the element values also go to `st` = this lane's row-major slot of the output block
+// ([N,256] fp32 per layer: point row, features 32 m + 8 (r >> 2) + 4 half + (r & 3)), times `stscale`.
+template <bool FWD, bool ST = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
-                                          half8 (&yh)[2], half8 (&yl)[2]) {
+                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f) {
+    float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * kb + e;
@@ -250,17 +253,30 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         } else {
             v = dsn_keep_active(v, mword, r);
         }
+        vv[e] = v;
         const _Float16 hi = (_Float16)v;
         const float res = fmaf((float)hi, -1.0f, v);
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
     }
+    if (ST && st) {
+        const int r = 2 * kb;
+        *reinterpret_cast<float2*>(st + 8 * (r >> 2) + (r & 3)) = make_float2(vv[0] * stscale, vv[1] * stscale);
+    }
+}
+// the same store for a whole block (non-pipelined epilogues)
+__device__ __forceinline__ void store16(float* st, const f32x16& v, float stscale) {
+    if (!st) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(st + 8 * q) = make_float4(v[4 * q] * stscale, v[4 * q + 1] * stscale, v[4 * q + 2] * stscale, v[4 * q + 3] * stscale);
 }
 
 // 256 -> 256 forward layer (software-pipelined epilogues)
+template <bool ST = false>
 __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const float* __restrict__ bias,
                                             const half8 (&xh)[8][2], const half8 (&xl)[8][2], half8 (&yh)[8][2],
-                                            half8 (&yl)[8][2], uint32_t (&mk)[4]) {
+                                            half8 (&yl)[8][2], uint32_t (&mk)[4], float* st = nullptr) {
     const int half = lane >> 5;
     f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
@@ -268,21 +284,22 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1]); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr); });
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true>(pM, pC, kb, 0u, bits, yh[7], yl[7]);
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], ST ? st + 32 * 7 : nullptr);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
 // 256 -> 256 reverse layer
+template <bool ST = false>
 __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const half8 (&xh)[8][2],
                                             const half8 (&xl)[8][2], half8 (&yh)[8][2], half8 (&yl)[8][2],
-                                            const uint32_t (&mk)[4]) {
+                                            const uint32_t (&mk)[4], float* st = nullptr) {
     f32x16 pM = zero16(), pC = zero16();
     uint32_t dummy = 0;
 #pragma unroll
@@ -290,12 +307,12 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1]); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr, F16_GUNSCALE); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false>(pM, pC, kb, mw, dummy, yh[7], yl[7]);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ST ? st + 32 * 7 : nullptr, F16_GUNSCALE);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
@@ -308,13 +325,16 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
 #define F16_FULL 0
 #define F16_FWD 1
 #define F16_BWD 2
+#define F16_TRAIN 3           // FULL + every layer's activations and masked sigma-adjoints stored row-major for dsn_train.hip
 #define F16_FIRST_BWD_BLOCK (OFF_L6T / DSN_BLK)   // 448
 template <int MODE>
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
           int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
           float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad,
-          uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count) {
+          uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count,
+          float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr) {
+    constexpr bool ST = MODE == F16_TRAIN;
     // LDS map: weight ring 64 KB | relu masks 7 layers x 4 words x 256 threads = 28 KB | PE operands 8 x half8 x 256 = 32 KB
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
@@ -360,6 +380,10 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
     // per-sample mask record: [half][layer] uint4, 224 B contiguous per sample
     uint4* const mrec = masks ? masks + ((size_t)pt * 2 + half) * 7 : nullptr;
+    // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
+    const int64_t tr_ls = N * 256;
+    float* const th = ST && valid ? tr_h + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : h_l
+    float* const ta = ST && valid ? tr_a + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : masked sigma-adjoint of layer l
 
   if (MODE != F16_BWD) {
     // positional encoding (fp32, accurate sincos) -> split k-steps; same slot map as k_field
@@ -392,12 +416,13 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
+        if (ST) store16(th ? th + 0 * tr_ls + 32 * m : nullptr, v, 1.0f);
         split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(0, mk)
-    layer16_fwd(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk); MK_STORE(1, mk)
-    layer16_fwd(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk); MK_STORE(2, mk)
-    layer16_fwd(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk); MK_STORE(3, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk, th ? th + 1 * tr_ls : nullptr); MK_STORE(1, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk, th ? th + 2 * tr_ls : nullptr); MK_STORE(2, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk, th ? th + 3 * tr_ls : nullptr); MK_STORE(3, mk)
     // stage2.0 : [h, pe] -> 256
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -412,10 +437,11 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
+        if (ST) store16(th ? th + 4 * tr_ls + 32 * m : nullptr, v, 1.0f);
         split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(4, mk)
-    layer16_fwd(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk); MK_STORE(5, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk, th ? th + 5 * tr_ls : nullptr); MK_STORE(5, mk)
     // stage2.4 with the density head and the seed of the reverse pass fused into its epilogue
     float sg_part = 0.0f;
 #pragma unroll
@@ -425,6 +451,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
+        if (ST) store16(th ? th + 6 * tr_ls + 32 * m : nullptr, v, 1.0f);
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
@@ -460,6 +487,12 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
             const f32x16 w0 = rows16(v_wrgb3 + 0 * 128, m, half);
             const f32x16 w1 = rows16(v_wrgb3 + 1 * 128, m, half);
             const f32x16 w2 = rows16(v_wrgb3 + 2 * 128, m, half);
+            if (ST && valid) {      // rgb_net.1 output after its relu, row-major [N,128]
+                f32x16 xr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[r] = fmaxf(v[r], 0.0f);
+                store16(tr_rr + pt * 128 + 4 * half + 32 * m, xr, 1.0f);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = fmaxf(v[r], 0.0f);
@@ -492,10 +525,11 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] *= F16_GSCALE;
         mask16(g, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        if (ST) store16(ta ? ta + 6 * tr_ls + 32 * m : nullptr, g, F16_GUNSCALE);
         split16<true>(g, ah[m], al[m]);
     }
-    MK_LOAD(5, mk) layer16_bwd(w, blk, lane, ah, al, bh, bl, mk);
-    MK_LOAD(4, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
+    MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 5 * tr_ls : nullptr);
+    MK_LOAD(4, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 4 * tr_ls : nullptr);
     MK_LOAD(3, mk)
     // stage2.0^T : 256 -> [256 h | 64 pe]
     f32x16 dpe[2];
@@ -505,6 +539,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         f32x16 v = fold16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        if (ST) store16(ta ? ta + 3 * tr_ls + 32 * m : nullptr, v, F16_GUNSCALE);
         split16<true>(v, bh[m], bl[m]);
     }
 #pragma unroll
@@ -513,9 +548,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         dpe[b] = fold16(aM, aC);
     }
-    MK_LOAD(2, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
-    MK_LOAD(1, mk) layer16_bwd(w, blk, lane, ah, al, bh, bl, mk);
-    MK_LOAD(0, mk) layer16_bwd(w, blk, lane, bh, bl, ah, al, mk);
+    MK_LOAD(2, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 2 * tr_ls : nullptr);
+    MK_LOAD(1, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 1 * tr_ls : nullptr);
+    MK_LOAD(0, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 0 * tr_ls : nullptr);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x16 aM = zero16(), aC = zero16();
@@ -557,7 +592,17 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+}
+// training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
+// layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
+void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
+                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr, tr_h, tr_a, tr_rr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -566,7 +611,8 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
-                       active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count);
+                       active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
 }
 // ... reverse pass on the sigma > 0 samples only
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -576,7 +622,7 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        pos_list, pos_count, (float*)nullptr, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -16,9 +16,10 @@
 //   u       = J^T dL/dn_w, J = d n_w / d g: projection onto the canonical nearest face and re-embedding on the posed
 //           face are affine in the point (utils/geo_utils.py:96-113,138-156,181-200), then F.normalize.
 //
-// First implementation of this row: layer-by-layer, activations of one training batch resident in HBM (16 KB per
-// sample - 8.6 GB for the 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The activation-times-weight
-// products (forward, reverse, tangent, adjoint) are plain fp32 GEMMs handed to rocBLAS; the weight-gradient
+// This round's implementation: activations of one training batch resident in HBM (16 KB per sample - 8.6 GB for the
+// 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The forward pass and the sigma reverse pass come from
+// the fused split-fp16 kernel (k_field16<train>, which stores h_l and a_l as it goes); the tangent and adjoint passes
+// are still layer-wise, their activation-times-weight products plain fp32 GEMMs handed to rocBLAS; the weight-gradient
 // products, which contract over the half-million samples of the batch, run on the hand-written exact-fp32 MFMA
 // kernel k_t_wgrad below; everything else is element-wise kernels.  Fusing these passes like k_field16 is the
 // follow-up.
@@ -618,7 +619,8 @@ size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
 #define T_CHECK(x) do { if (!(x)) return #x; } while (0)
 
 // returns nullptr on success, else a static description of the step that failed
-const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const float* poses, int frame_idx, int zero_code,
+const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* prm, const float* poses, int frame_idx,
+                          int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
                           const float* d_weights, float* const* grd, void* workspace, hipStream_t st) {
@@ -636,33 +638,12 @@ const char* dsn_train_run(const DsnSceneView& s, const float* const* prm, const 
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
                     nullptr, false, st);
     hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe);
+    // trunk + heads forward and the sigma reverse pass in ONE fused split-fp16 launch (k_field16<train>): besides sigma,
+    // essence and g = d sigma/dx it leaves every layer's activations h_l, the masked sigma-adjoints a_l and the rgb hidden
+    // layer in the row-major arrays the weight-gradient products below read
     const int64_t tot = N64 * 256;
-    for (int l = 0; l < 7; ++l) {
-        const float* W = prm[kTrunkW[l]];
-        if (l == 0) {
-            T_CHECK(lin_fwd(h, N, PE_K, 256, w.pe, PE_LD, W + W0_PE_COL, 87, w.h[0], 256, 0.0f));
-            hipLaunchKernelGGL(k_t_bias_relu, grid_for(tot), dim3(T_THREADS), 0, st, w.h[0], s.frame->bias0, 256, tot);
-        } else {
-            T_CHECK(lin_fwd(h, N, 256, 256, w.h[l - 1], 256, W, kTrunkLd[l], w.h[l], 256, 0.0f));
-            if (l == 4) T_CHECK(lin_fwd(h, N, PE_K, 256, w.pe, PE_LD, W + W4_PE_COL, 319, w.h[4], 256, 1.0f));
-            hipLaunchKernelGGL(k_t_bias_relu, grid_for(tot), dim3(T_THREADS), 0, st, w.h[l], prm[kTrunkB[l]], 256, tot);
-        }
-    }
     const dim3 wave_grid((unsigned)((N64 + 3) / 4));
-    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.h[6], 256, prm[P_DEN_W], prm[P_DEN_B], 1, N64, w.sig);
-    T_CHECK(lin_fwd(h, N, 256, 128, w.h[6], 256, prm[P_RGB1_W], 256, w.rr, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.rr, prm[P_RGB1_B], 128, N64 * 128);
-    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.rr, 128, prm[P_RGB3_W], prm[P_RGB3_B], 3, N64, w.ess);
-
-    // ---- reverse pass for g = d sigma / d x_c; the masked adjoints a_l stay resident -------------------------
-    hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], nullptr, nullptr, 256, tot, w.ap[6]);
-    for (int l = 6; l >= 1; --l) {
-        T_CHECK(lin_bwd(h, N, 256, 256, w.ap[l], 256, prm[kTrunkW[l]], kTrunkLd[l], w.ap[l - 1], 256, 0.0f));
-        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, w.ap[l - 1], w.h[l - 1], tot);
-    }
-    T_CHECK(lin_bwd(h, N, PE_K, 256, w.ap[4], 256, prm[P_S2_0W] + W4_PE_COL, 319, w.tpe, PE_LD, 0.0f));
-    T_CHECK(lin_bwd(h, N, PE_K, 256, w.ap[0], 256, prm[P_S1_0W] + W0_PE_COL, 87, w.tpe, PE_LD, 1.0f));
-    hipLaunchKernelGGL(k_t_pe_reverse, grid_for(N64 * 3), dim3(T_THREADS), 0, st, w.x_c, w.tpe, N64, w.g);
+    dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, st);
 
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
     dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);

@@ -169,10 +169,10 @@ DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* pac
  * (frame_idx / zero_code / poses repeated here for the embedding and pose_mlp gradients).  params33_host / grads33_host
  * are HOST arrays of 33 device pointers in state_dict order with torch Linear layouts; every gradient is overwritten.
  * Includes the second-order path through d sigma/dx -> normal -> lighting (model/spacenet.py:251-265) as a forward
- * tangent pass.  Evaluates the networks layer by layer in fp32 (rocBLAS GEMMs) with activations resident in
- * `workspace` (dsn_grad_workspace_bytes(R,S), 16 KB per sample). */
+ * tangent pass.  `packed` = dsn_pack_params image of the same parameters.  Activations stay resident in `workspace`
+ * (dsn_grad_workspace_bytes(R,S), 16 KB per sample). */
 DSN_EXPORT size_t dsn_grad_workspace_bytes(int R, int S);
-DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const float* const* params33_host, const float* poses24x3,
+DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
