@@ -460,14 +460,17 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     sg_part += __shfl_xor(sg_part, 32);
     const float sg = sg_part + v_scal[0];
     if (valid && half == 0) sigma[pt] = sg;
-    if (MODE == F16_FWD) {
-        // masks of all 7 layers -> the sample's record; samples with positive density -> the reverse-pass list
+    if (MODE == F16_FWD || MODE == F16_TRAIN) {
+        // masks of all 7 layers -> the sample's record (read back by k_field16<reverse> / k_tangent16)
         MK_STORE(6, mk)
         if (valid) {
 #pragma unroll
             for (int L = 0; L < 7; ++L)
                 mrec[L] = make_uint4(s_mask[L][0][tid], s_mask[L][1][tid], s_mask[L][2][tid], s_mask[L][3][tid]);
         }
+    }
+    if (MODE == F16_FWD) {
+        // samples with positive density -> the reverse-pass list
         const bool pos = valid && half == 0 && sg > 0.0f;
         const unsigned long long bm = __ballot(pos);
         const int cnt = __popcll(bm);
@@ -597,11 +600,11 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
 // training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
-                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, hipStream_t st) {
+                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
                        (int32_t*)nullptr, tr_h, tr_a, tr_rr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
@@ -623,6 +626,141 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        pos_list, pos_count, (float*)nullptr, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
                        (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tangent16 : forward TANGENT pass of the trunk for the training backward (dsn_train.hip): hdot_l = m_l * (W_l hdot_{l-1}),
+// hdot_0 = m_0 * (W_0[:,pe] J_pe u) with u = dL/d(d sigma/dx) per sample and m_l the relu patterns the training forward
+// recorded.  The network is linear in u, so every sample is evaluated on u / max|u| (O(1) operands for the split-fp16
+// products, forward flavour of dense16) and its outputs are stored times max|u|: row-major hdot_l [7][N,256].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, half8 (&yh)[2],
+                                              half8 (&yl)[2], float* st, float stscale) {
+    float vv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * kb + e;
+        const float v = dsn_keep_active((pM[r] + pC[r]) * F16_FWD_INV, mword, r);
+        vv[e] = v;
+        const _Float16 hi = (_Float16)v;
+        yh[r >> 3][r & 7] = hi;
+        yl[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, v);
+    }
+    if (st) {
+        const int r = 2 * kb;
+        *reinterpret_cast<float2*>(st + 8 * (r >> 2) + (r & 3)) = make_float2(vv[0] * stscale, vv[1] * stscale);
+    }
+}
+__device__ __forceinline__ void layer16_tan(W16& w, int& blk, int lane, const half8 (&xh)[8][2], const half8 (&xl)[8][2],
+                                            half8 (&yh)[8][2], half8 (&yl)[8][2], const uint32_t (&mk)[4], float* st, float stscale) {
+    f32x16 pM = zero16(), pC = zero16();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = zero16(), aC = zero16();
+        const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
+        if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice_tan(pM, pC, kb, mw, yh[m - 1], yl[m - 1], st ? st + 32 * (m - 1) : nullptr, stscale); });
+        pM = aM; pC = aC;
+    }
+    const uint32_t mw = (mk[3] >> 16) & 0xffffu;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) epi_slice_tan(pM, pC, kb, mw, yh[7], yl[7], st ? st + 32 * 7 : nullptr, stscale);
+}
+
+__global__ void __launch_bounds__(F16_THREADS, 1)
+k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, const float* __restrict__ u, int64_t N,
+            const uint4* __restrict__ masks, float* __restrict__ tr_t) {
+    __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
+    __shared__ uint32_t s_mask[7][4][F16_THREADS];
+    __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
+    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    int64_t pt = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool valid = pt < N;
+    if (!valid) pt = N - 1;
+    const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+    float ua[3] = {u[3 * pt], u[3 * pt + 1], u[3 * pt + 2]};
+    const float sc = fmaxf(fmaxf(fabsf(ua[0]), fabsf(ua[1])), fabsf(ua[2]));
+    const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
+    for (int c = 0; c < 3; ++c) ua[c] *= inv;
+    {
+        const uint4* mrec = masks + ((size_t)pt * 2 + half) * 7;
+#pragma unroll
+        for (int L = 0; L < 7; ++L) {
+            const uint4 q = mrec[L];
+            s_mask[L][0][tid] = q.x; s_mask[L][1][tid] = q.y; s_mask[L][2][tid] = q.z; s_mask[L][3][tid] = q.w;
+        }
+    }
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
+    w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    w.wave = wave;
+    w16_begin(w, lane, 0);
+    int blk = 0;
+    const int64_t ls = N * 256;
+    float* const tt = valid ? tr_t + pt * 256 + 4 * half : nullptr;
+#define TMK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
+    uint32_t mk[4];
+    half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
+    half8 ph[2][2], pl[2][2];
+    {   // tangent of the encoding in the forward slot map: slot t holds (half ? cos : sin)(2^j x_a) -> (half ? -sin : cos) 2^j u_a
+        f32x16 pe[2];
+#pragma unroll
+        for (int t = 0; t < 30; ++t) {
+            float s, c;
+            const float f = (float)(1 << (t / 3));
+            dsn_sincos(xa[t % 3] * f, s, c);
+            pe[t >> 4][t & 15] = (half ? -s : c) * f * ua[t % 3];
+        }
+        pe[1][14] = half ? ua[1] : ua[0];
+        pe[1][15] = half ? 0.0f : ua[2];
+        split16<false>(pe[0], ph[0], pl[0]);
+        split16<false>(pe[1], ph[1], pl[1]);
+        s_pe[0][tid] = ph[0][0]; s_pe[1][tid] = ph[0][1]; s_pe[2][tid] = ph[1][0]; s_pe[3][tid] = ph[1][1];
+        s_pe[4][tid] = pl[0][0]; s_pe[5][tid] = pl[0][1]; s_pe[6][tid] = pl[1][0]; s_pe[7][tid] = pl[1][1];
+    }
+    TMK_LOAD(0, mk)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<2, false>(w, blk, lane, ph, pl, aM, aC);
+        f32x16 v = unscale16(aM, aC);
+        mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        store16(tt ? tt + 0 * ls + 32 * m : nullptr, v, sc);
+        split16<false>(v, ah[m], al[m]);
+    }
+    TMK_LOAD(1, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 1 * ls : nullptr, sc);
+    TMK_LOAD(2, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 2 * ls : nullptr, sc);
+    TMK_LOAD(3, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 3 * ls : nullptr, sc);
+    TMK_LOAD(4, mk)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8, false>(w, blk, lane, bh, bl, aM, aC);
+        {
+            half8 qh[2][2], ql[2][2];
+            qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
+            ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
+            dense16<2, false>(w, blk, lane, qh, ql, aM, aC);
+        }
+        f32x16 v = unscale16(aM, aC);
+        mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        store16(tt ? tt + 4 * ls + 32 * m : nullptr, v, sc);
+        split16<false>(v, ah[m], al[m]);
+    }
+    TMK_LOAD(5, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 5 * ls : nullptr, sc);
+    TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 6 * ls : nullptr, sc);
+#undef TMK_LOAD
+}
+
+void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
+                          hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -58,7 +58,9 @@ void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float*
 // dsn_train.hip: parameter gradients of Renderer.render (layer-wise, rocBLAS GEMMs + element-wise kernels)
 size_t dsn_train_workspace_size(int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
-                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, hipStream_t st);
+                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st);
+void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
+                          hipStream_t st);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,

@@ -16,13 +16,12 @@
 //   u       = J^T dL/dn_w, J = d n_w / d g: projection onto the canonical nearest face and re-embedding on the posed
 //           face are affine in the point (utils/geo_utils.py:96-113,138-156,181-200), then F.normalize.
 //
-// This round's implementation: activations of one training batch resident in HBM (16 KB per sample - 8.6 GB for the
-// 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The forward pass and the sigma reverse pass come from
-// the fused split-fp16 kernel (k_field16<train>, which stores h_l and a_l as it goes); the tangent and adjoint passes
-// are still layer-wise, their activation-times-weight products plain fp32 GEMMs handed to rocBLAS; the weight-gradient
-// products, which contract over the half-million samples of the batch, run on the hand-written exact-fp32 MFMA
-// kernel k_t_wgrad below; everything else is element-wise kernels.  Fusing these passes like k_field16 is the
-// follow-up.
+// This round's implementation: activations of one training batch resident in HBM (23 KB per sample - 12 GB for the
+// 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The forward pass, the sigma reverse pass and the tangent
+// pass are fused split-fp16 kernels of dsn_field16.hip (k_field16<train> stores h_l, a_l and the relu records as it
+// goes; k_tangent16 stores hdot_l); the adjoint pass is still layer-wise, its activation-times-weight products plain
+// fp32 GEMMs handed to rocBLAS; the weight-gradient products, which contract over the half-million samples of the
+// batch, run on the hand-written exact-fp32 MFMA kernel k_t_wgrad below; everything else is element-wise kernels.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
 #include <rocblas/rocblas.h>
@@ -562,7 +561,8 @@ bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ld
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
-    float *x_c, *pe, *h[7], *ap[7], *rr, *ess, *sig, *g, *t0, *t1, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
+    float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *t1, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
+    void* masks;
     float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
     size_t bytes;
 };
@@ -578,6 +578,8 @@ TrainWs carve(void* base, int64_t N) {
     w.pe = (float*)take(4 * PE_LD * n);
     for (int l = 0; l < 7; ++l) w.h[l] = (float*)take(1024 * n);
     for (int l = 0; l < 7; ++l) w.ap[l] = (float*)take(1024 * n);
+    for (int l = 0; l < 7; ++l) w.tn[l] = (float*)take(1024 * n);
+    w.masks = (void*)take(224 * n);
     w.rr = (float*)take(512 * n);
     w.ess = (float*)take(12 * n);
     w.sig = (float*)take(4 * n);
@@ -643,7 +645,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // layer in the row-major arrays the weight-gradient products below read
     const int64_t tot = N64 * 256;
     const dim3 wave_grid((unsigned)((N64 + 3) / 4));
-    dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, st);
+    dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, w.masks, st);
 
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
     dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
@@ -678,22 +680,15 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_normal_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, s.face_world, s.face_canon, w.x_c, w.g, w.idx_c,
                        w.d_xl, N64, w.u);
     hipLaunchKernelGGL(k_t_pe_tangent, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe);
-    float *cur = w.t0, *nxt = w.t1;
-    T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, prm[P_S1_0W] + W0_PE_COL, 87, cur, 256, 0.0f));
-    hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, cur, w.h[0], tot);
+    // all seven tangent layers in one fused split-fp16 launch (k_tangent16, relu patterns from the training forward's records),
+    // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
+    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], st);
     T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87, st));
-    for (int l = 1; l < 7; ++l) {
-        const float* W = prm[kTrunkW[l]];
-        T_CHECK(lin_fwd(h, N, 256, 256, cur, 256, W, kTrunkLd[l], nxt, 256, 0.0f));
-        T_CHECK(wgrad_mfma(N64, 256, 256, 256, cur, 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l], st));
-        if (l == 4) {
-            T_CHECK(lin_fwd(h, N, PE_K, 256, w.tpe, PE_LD, W + W4_PE_COL, 319, nxt, 256, 1.0f));
-            T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
-        }
-        hipLaunchKernelGGL(k_t_mask, grid_for(tot), dim3(T_THREADS), 0, st, nxt, w.h[l], tot);
-        float* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    colsum(cur, 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
+    for (int l = 1; l < 7; ++l)
+        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.tn[l - 1], 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l], st));
+    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
+    colsum(w.tn[6], 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
+    float *cur = w.t0, *nxt = w.t1;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
     T_CHECK(lin_wgrad(h, N, 128, 3, w.rr, 128, w.d_ess, 3, grd[P_RGB3_W], 128));

@@ -170,7 +170,7 @@ DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* pac
  * are HOST arrays of 33 device pointers in state_dict order with torch Linear layouts; every gradient is overwritten.
  * Includes the second-order path through d sigma/dx -> normal -> lighting (model/spacenet.py:251-265) as a forward
  * tangent pass.  `packed` = dsn_pack_params image of the same parameters.  Activations stay resident in `workspace`
- * (dsn_grad_workspace_bytes(R,S), 16 KB per sample). */
+ * (dsn_grad_workspace_bytes(R,S), 23 KB per sample). */
 DSN_EXPORT size_t dsn_grad_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
