@@ -299,7 +299,7 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
 template <bool ST = false>
 __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const half8 (&xh)[8][2],
                                             const half8 (&xl)[8][2], half8 (&yh)[8][2], half8 (&yl)[8][2],
-                                            const uint32_t (&mk)[4], float* st = nullptr) {
+                                            const uint32_t (&mk)[4], float* st = nullptr, float stscale = F16_GUNSCALE) {
     f32x16 pM = zero16(), pC = zero16();
     uint32_t dummy = 0;
 #pragma unroll
@@ -307,12 +307,12 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr, F16_GUNSCALE); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr, stscale); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ST ? st + 32 * 7 : nullptr, F16_GUNSCALE);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ST ? st + 32 * 7 : nullptr, stscale);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
@@ -761,6 +761,93 @@ void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u,
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_adjoint16 : the ADJOINT pass of the training backward below its seed: given ahat_6 (the masked adjoint of
+// dL/dsigma * sigma + dL/dessence . essence at stage2.4, row-major [N,256]) it runs the transposed layers with the recorded
+// relu patterns and stores ahat_5 ... ahat_0.  Linear in the seed, so every sample runs on seed / max|seed| and its outputs
+// are stored times that maximum.  Same weight images and reverse flavour of dense16 as k_field16<reverse>.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(F16_THREADS, 1)
+k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict__ masks, const float* __restrict__ a_in,
+            float* __restrict__ tr_a) {
+    __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
+    __shared__ uint32_t s_mask[7][4][F16_THREADS];
+    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    int64_t pt = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const bool valid = pt < N;
+    if (!valid) pt = N - 1;
+    {
+        const uint4* mrec = masks + ((size_t)pt * 2 + half) * 7;
+#pragma unroll
+        for (int L = 0; L < 6; ++L) {
+            const uint4 q = mrec[L];
+            s_mask[L][0][tid] = q.x; s_mask[L][1][tid] = q.y; s_mask[L][2][tid] = q.z; s_mask[L][3][tid] = q.w;
+        }
+    }
+    // the seed, row-major -> accumulator layout, and its magnitude
+    const float* in = a_in + pt * 256 + 4 * half;
+    f32x16 v[8];
+    float sc = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(in + 32 * m + 8 * q);
+            v[m][4 * q] = x.x; v[m][4 * q + 1] = x.y; v[m][4 * q + 2] = x.z; v[m][4 * q + 3] = x.w;
+            sc = fmaxf(sc, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+        }
+    sc = fmaxf(sc, __shfl_xor(sc, 32));
+    const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
+    half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[m][r] *= inv;
+        split16<true>(v[m], ah[m], al[m]);
+    }
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
+    w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    w.wave = wave;
+    w16_begin(w, lane, F16_FIRST_BWD_BLOCK);
+    int blk = F16_FIRST_BWD_BLOCK;
+    const int64_t ls = N * 256;
+    float* const ta = valid ? tr_a + pt * 256 + 4 * half : nullptr;
+#define AMK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
+    uint32_t mk[4];
+    AMK_LOAD(5, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 5 * ls : nullptr, sc);
+    AMK_LOAD(4, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 4 * ls : nullptr, sc);
+    AMK_LOAD(3, mk)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {       // stage2.0^T, h part
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8, true>(w, blk, lane, ah, al, aM, aC);
+        f32x16 x = fold16(aM, aC);
+        mask16(x, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        store16(ta ? ta + 3 * ls + 32 * m : nullptr, x, sc);
+        split16<true>(x, bh[m], bl[m]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {       // its positional-encoding rows: not needed here, consumed to stay on the stream
+        f32x16 aM = zero16(), aC = zero16();
+        dense16<8, true>(w, blk, lane, ah, al, aM, aC);
+    }
+    AMK_LOAD(2, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 2 * ls : nullptr, sc);
+    AMK_LOAD(1, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 1 * ls : nullptr, sc);
+    AMK_LOAD(0, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 0 * ls : nullptr, sc);
+#undef AMK_LOAD
+}
+
+void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, hipStream_t st) {
+    int64_t blocks = (N + 127) / 128;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_adjoint16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, N, (const uint4*)masks, a_in, tr_a);
 }
 
 // ---------------------------------------------------------------------------------------------

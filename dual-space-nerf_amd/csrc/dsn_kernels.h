@@ -59,6 +59,7 @@ void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float*
 size_t dsn_train_workspace_size(int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st);
+void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, hipStream_t st);
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
                           hipStream_t st);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,

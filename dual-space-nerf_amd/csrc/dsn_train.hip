@@ -18,9 +18,9 @@
 //
 // This round's implementation: activations of one training batch resident in HBM (23 KB per sample - 12 GB for the
 // 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The forward pass, the sigma reverse pass and the tangent
-// pass are fused split-fp16 kernels of dsn_field16.hip (k_field16<train> stores h_l, a_l and the relu records as it
-// goes; k_tangent16 stores hdot_l); the adjoint pass is still layer-wise, its activation-times-weight products plain
-// fp32 GEMMs handed to rocBLAS; the weight-gradient products, which contract over the half-million samples of the
+// pass and the adjoint pass are fused split-fp16 kernels of dsn_field16.hip (k_field16<train> stores h_l, a_l and the relu
+// records as it goes; k_tangent16 stores hdot_l; k_adjoint16 stores ahat_l below its seed); rocBLAS is left with the small
+// lighting / rgb-head GEMMs; the weight-gradient products, which contract over the half-million samples of the
 // batch, run on the hand-written exact-fp32 MFMA kernel k_t_wgrad below; everything else is element-wise kernels.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
@@ -701,21 +701,18 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     colsum(w.d_sig, 1, N64, grd[P_DEN_B], st);
     T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
     hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
-    for (int l = 6; l >= 0; --l) {
-        float* gW = grd[kTrunkW[l]];
-        if (l == 6) colsum(cur, 256, N64, grd[kTrunkB[6]], st);   // the deeper layers get theirs from k_t_mask_colsum256
-        if (l == 0) {
-            T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W0_PE_COL, 87, st));
-            break;
-        }
-        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.h[l - 1], 256, cur, 256, gW, kTrunkLd[l], st));
-        if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, cur, 256, gW + W4_PE_COL, 319, st));
-        T_CHECK(lin_bwd(h, N, 256, 256, cur, 256, prm[kTrunkW[l]], kTrunkLd[l], nxt, 256, 0.0f));
-        // mask + the bias gradient of layer l-1 (= column sums of the masked adjoint) in one pass
-        hipLaunchKernelGGL(k_t_mask_colsum256, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, nxt, w.h[l - 1], N64, 64,
-                           l - 1 == 0 ? w.small : grd[kTrunkB[l - 1]]);
-        float* tmp = cur; cur = nxt; nxt = tmp;
+    // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
+    // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
+    float* const* an = w.tn;
+    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], st);
+    for (int l = 6; l >= 1; --l) {
+        const float* A = l == 6 ? cur : an[l];
+        colsum(A, 256, N64, grd[kTrunkB[l]], st);
+        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.h[l - 1], 256, A, 256, grd[kTrunkW[l]], kTrunkLd[l], st));
+        if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, A, 256, grd[kTrunkW[4]] + W4_PE_COL, 319, st));
     }
+    colsum(an[0], 256, N64, w.small, st);
+    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, an[0], 256, grd[kTrunkW[0]] + W0_PE_COL, 87, st));
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
     if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
     hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,
