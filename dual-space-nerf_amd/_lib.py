@@ -36,7 +36,7 @@ EXPORTS = [
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
-    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -319,7 +319,7 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True):
+                fp32=False, uniform=False, screen=True, train_cache=None):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -343,6 +343,16 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     if not screen:
         flags |= NO_SCREEN
     buf = ws.get(R, S)
+    if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
+        flags &= ~SKIP_TRANSPARENT
+        gbuf = train_cache.get(R, S)
+        _check(lib().dsn_render_rays_train(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
+                                           _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
+                                           _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
+                                           _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
+                                           _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _ptr(gbuf), _stream()),
+               "dsn_render_rays_train")
+        return out
     _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
                                  _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
                                  _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
@@ -368,7 +378,8 @@ class GradWorkspace:
 
 
 def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, d_rgb, d_disp=None,
-                     d_acc=None, d_depth=None, d_weights=None, ws: GradWorkspace = None, packed: PackedParams = None):
+                     d_acc=None, d_depth=None, d_weights=None, ws: GradWorkspace = None, packed: PackedParams = None,
+                     cached: bool = False):
     """Parameter gradients of render_rays' outputs (dsn_render_rays_grad; trainer.py:70-81 loss.backward()).
     params: the 33 tensors in PARAM_ORDER (name -> tensor dict or list).  Returns a list of 33 gradient tensors
     (float32, on the device, shaped like the parameters).  The scene's frame must be set with the same parameters."""
@@ -390,7 +401,7 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
     _check(lib().dsn_render_rays_grad(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
                                       _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), int(R), int(S),
                                       _ptr(args[4]), _ptr(args[5]), _ptr(args[6]), _ptr(args[7]), _ptr(args[8]), gp,
-                                      _ptr(buf), _stream()), "dsn_render_rays_grad")
+                                      _ptr(buf), 1 if cached else 0, _stream()), "dsn_render_rays_grad")
     scene._keep_grad = (prm, args, poses, packed)
     return grads
 

@@ -45,9 +45,13 @@ class _RenderRays(torch.autograd.Function):
     @staticmethod
     def forward(ctx, renderer, call, *params):
         o, d, near, far, S, jitter, noise, uniform, frame_args = call
+        if not hasattr(renderer, "_grad_ws"):
+            renderer._grad_ws = _lib.GradWorkspace(renderer.device)
+        renderer._cache_gen = getattr(renderer, "_cache_gen", 0) + 1      # whose activations the cache holds
         out = _lib.render_rays(renderer.scene, renderer.net.packed(renderer.device), renderer._ws, o, d, near, far, S,
-                               renderer._t_vals(S), jitter, noise, skip_transparent=False, uniform=uniform)
-        ctx.renderer, ctx.call, ctx.params = renderer, (o, d, noise, frame_args), params
+                               renderer._t_vals(S), jitter, noise, skip_transparent=False, uniform=uniform,
+                               train_cache=renderer._grad_ws)
+        ctx.renderer, ctx.call, ctx.params, ctx.gen = renderer, (o, d, noise, frame_args), params, renderer._cache_gen
         ctx.z_vals = out["z_vals"]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out["z_vals"])
@@ -67,7 +71,8 @@ class _RenderRays(torch.autograd.Function):
         if not hasattr(r, "_grad_ws"):
             r._grad_ws = _lib.GradWorkspace(r.device)
         grads = _lib.render_rays_grad(r.scene, sd, poses, frame, zero_code, o, d, ctx.z_vals, noise, g_color, g_disp, g_acc,
-                                      g_depth, g_weights, ws=r._grad_ws, packed=packed)
+                                      g_depth, g_weights, ws=r._grad_ws, packed=packed,
+                                      cached=(ctx.gen == getattr(r, "_cache_gen", -1)))
         grads = [g.to(device=p.device, dtype=p.dtype).reshape(p.shape) for g, p in zip(grads, ctx.params)]
         return (None, None) + tuple(grads)
 

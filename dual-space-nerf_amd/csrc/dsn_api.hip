@@ -249,7 +249,7 @@ int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, co
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
-                         void* stream) {
+                         int flags, void* stream) {
     DSN_REQUIRE(scene && packed && params33_host && poses24x3 && ray_o && ray_d && z_vals && d_rgb && grads33_host && workspace,
                 "dsn_render_rays_grad: null argument");
     DSN_REQUIRE(R > 0 && S > 0 && V > 0 && F > 0, "dsn_render_rays_grad: bad sizes");
@@ -258,7 +258,8 @@ int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, co
         DSN_REQUIRE(params33_host[i] && grads33_host[i], "dsn_render_rays_grad: null parameter / gradient pointer");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
     const char* err = dsn_train_run(s, (const float*)packed, params33_host, poses24x3, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, R, S, d_rgb,
-                                    d_disp, d_acc, d_depth, d_weights, grads33_host, workspace, (hipStream_t)stream);
+                                    d_disp, d_acc, d_depth, d_weights, grads33_host, workspace, (hipStream_t)stream,
+                                    (flags & DSN_GRAD_CACHED) != 0);
     if (err) return dsn_fail("dsn_render_rays_grad: %s failed", err);
     return dsn_check_launch("dsn_render_rays_grad");
 }
@@ -406,6 +407,32 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st);
     return dsn_check_launch("dsn_render_rays");
+}
+
+int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                          float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
+                          float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
+                          void* workspace, void* grad_workspace, void* stream) {
+    DSN_REQUIRE(scene && packed && ray_o && ray_d && near && far && t_vals && workspace && grad_workspace,
+                "dsn_render_rays_train: null argument");
+    DSN_REQUIRE(out_rgb && out_disp && out_acc && out_depth, "dsn_render_rays_train: null output");
+    DSN_REQUIRE(R > 0 && S > 0 && V > 0 && F > 0, "dsn_render_rays_train: bad sizes");
+    DSN_REQUIRE(!(flags & (DSN_SKIP_TRANSPARENT | DSN_FIELD_FP32)), "dsn_render_rays_train: dense split-fp16 evaluation only");
+    hipStream_t st = (hipStream_t)stream;
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    DsnWorkspace w = dsn_carve(workspace, R, S);
+    const int64_t N = (int64_t)R * S;
+    const DsnTrainCache c = dsn_train_cache(grad_workspace, N);
+    float* z = out_z ? out_z : w.z;
+    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
+    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
+    dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st);
+    dsn_launch_normal(s, c.x_c, c.grad, N, nullptr, nullptr, c.idx_c, c.n_w, exh, st);
+    dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, nullptr, nullptr, w.colour, st);
+    dsn_launch_composite(w.colour, c.sigma, c.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc, out_weights,
+                         out_depth, st);
+    return dsn_check_launch("dsn_render_rays_train");
 }
 
 }  // extern "C"

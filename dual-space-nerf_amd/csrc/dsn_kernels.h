@@ -57,6 +57,11 @@ void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float*
 
 // dsn_train.hip: parameter gradients of Renderer.render (layer-wise, rocBLAS GEMMs + element-wise kernels)
 size_t dsn_train_workspace_size(int64_t N);
+// the part of that workspace a training FORWARD fills for its backward (dsn_render_rays_train -> dsn_render_rays_grad)
+struct DsnTrainCache {
+    uint8_t* transparent; int32_t* idx_c; float *x_c, *sigma, *essence, *grad, *n_w, *h0, *a0, *rr; void* masks;
+};
+DsnTrainCache dsn_train_cache(void* workspace, int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st);
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, hipStream_t st);
@@ -66,7 +71,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
-                          const float* d_weights, float* const* grads33, void* workspace, hipStream_t st);
+                          const float* d_weights, float* const* grads33, void* workspace, hipStream_t st, bool cached = false);
 
 // dsn_image.hip: image epilogue on the device (post_process scatter, clamp, mse / psnr)
 size_t dsn_image_workspace_size(int H, int W);

@@ -618,6 +618,12 @@ void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st) {
 
 size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
 
+DsnTrainCache dsn_train_cache(void* workspace, int64_t N) {
+    const TrainWs w = carve(workspace, N);
+    DsnTrainCache c = {w.transparent, w.idx_c, w.x_c, w.sig, w.ess, w.g, w.n_w, w.h[0], w.ap[0], w.rr, w.masks};
+    return c;
+}
+
 #define T_CHECK(x) do { if (!(x)) return #x; } while (0)
 
 // returns nullptr on success, else a static description of the step that failed
@@ -625,7 +631,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
-                          const float* d_weights, float* const* grd, void* workspace, hipStream_t st) {
+                          const float* d_weights, float* const* grd, void* workspace, hipStream_t st, bool cached) {
     const int64_t N64 = (int64_t)R * S;
     if (N64 > (int64_t)1 << 30) return "batch too large for the 32-bit GEMM interface";
     const int N = (int)N64;
@@ -637,18 +643,20 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     if (hipMemsetAsync(w.small, 0, 4 * 1024, st) != hipSuccess) return "zeroing scratch";
 
     // ---- forward: warp, encoding, trunk, heads ------------------------------------------------------------
-    dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
-                    nullptr, false, st);
+    // (skipped when dsn_render_rays_train has just left all of it in this workspace)
+    if (!cached)
+        dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
+                        nullptr, false, st);
     hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe);
     // trunk + heads forward and the sigma reverse pass in ONE fused split-fp16 launch (k_field16<train>): besides sigma,
     // essence and g = d sigma/dx it leaves every layer's activations h_l, the masked sigma-adjoints a_l and the rgb hidden
     // layer in the row-major arrays the weight-gradient products below read
     const int64_t tot = N64 * 256;
     const dim3 wave_grid((unsigned)((N64 + 3) / 4));
-    dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, w.masks, st);
+    if (!cached) dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, w.masks, st);
 
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
-    dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
+    if (!cached) dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
     hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl);
     T_CHECK(lin_fwd(h, N, 9, 128, w.xl, 9, prm[P_L0_W], 9, w.hl1, 128, 0.0f));
     hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl1, prm[P_L0_B], 128, N64 * 128);

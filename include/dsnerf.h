@@ -172,11 +172,20 @@ DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* pac
  * tangent pass.  `packed` = dsn_pack_params image of the same parameters.  Activations stay resident in `workspace`
  * (dsn_grad_workspace_bytes(R,S), 23 KB per sample). */
 DSN_EXPORT size_t dsn_grad_workspace_bytes(int R, int S);
+/* Renderer.render in train mode (can_render.py:137-168 with net.training): dsn_render_rays (dense evaluation, jitter / noise
+ * as given) that also leaves what its backward needs in `grad_workspace` (dsn_grad_workspace_bytes(R,S)): canonical points,
+ * transparency, per-layer activations, sigma-adjoints, relu records, normals.  A following dsn_render_rays_grad on the same
+ * inputs with DSN_GRAD_CACHED skips the recomputation of all of it. */
+#define DSN_GRAD_CACHED 1
+DSN_EXPORT int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                    float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
+                    float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
+                    void* workspace, void* grad_workspace, void* stream);
 DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
-                         void* stream);
+                         int flags, void* stream);
 
 /* ---- fused path: can_render.py:137-168 Renderer.render on R rays --------------------------
  * flags: DSN_SKIP_TRANSPARENT evaluates the networks only on non-transparent samples (exact in

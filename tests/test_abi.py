@@ -65,7 +65,8 @@ def test_every_entry_point_rejects_null_arguments(lib):
         "dsn_camera_rays": lambda: lib.dsn_camera_rays(z, z, z, z, 0, 0, z, z, z, z, z, z),
         "dsn_image_scatter": lambda: lib.dsn_image_scatter(z, z, z, z, 1, z, 0, 0, 0, z, z, z, z, z, z),
         "dsn_image_psnr": lambda: lib.dsn_image_psnr(z, z, z, z, 0, 0, z, z, z),
-        "dsn_render_rays_grad": lambda: lib.dsn_render_rays_grad(z, 1, 1, z, z, z, 0, 0, z, z, z, z, 0, 0, z, z, z, z, z, z, z, z),
+        "dsn_render_rays_grad": lambda: lib.dsn_render_rays_grad(z, 1, 1, z, z, z, 0, 0, z, z, z, z, 0, 0, z, z, z, z, z, z, z, 0, z),
+        "dsn_render_rays_train": lambda: lib.dsn_render_rays_train(z, 1, 1, z, z, z, z, z, 0, 0, z, z, z, 0, z, z, z, z, z, z, z, z, z),
     }
     for name, call in calls.items():
         assert call() != 0, name
