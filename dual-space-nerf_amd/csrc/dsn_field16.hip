@@ -284,14 +284,14 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr); });
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], ST ? st + 32 * 7 : nullptr);
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
@@ -307,12 +307,12 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ST ? st + 32 * (m - 1) : nullptr, stscale); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ST ? st + 32 * 7 : nullptr, stscale);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).

@@ -63,12 +63,15 @@ def test_backward_matches_reference_autograd(name):
     print({k: "%.1e" % v[0] for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("name", ["small_train_grads", "full_train_grads"])
-def test_backward_matches_oracle_all_cotangents(name):
+@pytest.mark.parametrize("name,nrays", [("small_train_grads", None), ("full_train_grads", None), ("full_train_grads", 37)])
+def test_backward_matches_oracle_all_cotangents(name, nrays):
     """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) == autograd of the
     CPU oracle on the same inputs, full tensors."""
     from dsnerf_amd import _lib
-    g = load(name)
+    g = dict(load(name).items())
+    if nrays is not None:                      # a ray count that is no multiple of the 32-point wave tiles / 128-point blocks
+        for k in ("ray_o", "ray_d", "near", "far", "render:z_vals", "noise", "jitter"):
+            g[k] = g[k][:nrays]
     sd = state()
     r = make_renderer(g)
     z = g["render:z_vals"]
