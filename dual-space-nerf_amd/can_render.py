@@ -146,10 +146,16 @@ class Renderer:
         """Train-mode random draws from the CPU default generator in the reference's order:
         torch.rand([1,R,S]) (utils/pts_utils.py:12) then torch.randn([R,S]) (utils/nerf_net_utils.py:31)."""
         jitter = noise = None
+        # both tensors are drawn on the host first and uploaded afterwards: a pageable .to(device) waits for the stream, so
+        # drawing the second one after the first upload would leave the GPU idle for the length of a 0.5 M-sample randn
         if self.net.training and self.cfg.MODEL.perturb > 0.0:
-            jitter = torch.rand(1, R, S).reshape(R, S).to(self.device)
+            jitter = torch.rand(1, R, S).reshape(R, S)
         if self.net.training and self.cfg.MODEL.raw_noise_std > 0.0:
-            noise = (torch.randn(R, S) * self.cfg.MODEL.raw_noise_std).to(self.device)
+            noise = torch.randn(R, S) * self.cfg.MODEL.raw_noise_std
+        if jitter is not None:
+            jitter = jitter.to(self.device)
+        if noise is not None:
+            noise = noise.to(self.device)
         return jitter, noise
 
     # ---- sampling (reference :40-63) ----

@@ -669,7 +669,7 @@ __device__ __forceinline__ void layer16_tan(W16& w, int& blk, int lane, const ha
 
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, const float* __restrict__ u, int64_t N,
-            const uint4* __restrict__ masks, float* __restrict__ tr_t) {
+            const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax) {
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
@@ -685,6 +685,12 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
     const float sc = fmaxf(fmaxf(fabsf(ua[0]), fabsf(ua[1])), fabsf(ua[2]));
     const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
     for (int c = 0; c < 3; ++c) ua[c] *= inv;
+    if (gmax) {      // batch-wide magnitude of the outputs (bit pattern of a non-negative float orders like the float)
+        float wm = valid ? sc : 0.0f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        if (lane == 0) atomicMax(gmax, __float_as_uint(wm));
+    }
     {
         const uint4* mrec = masks + ((size_t)pt * 2 + half) * 7;
 #pragma unroll
@@ -757,10 +763,11 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
 }
 
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          hipStream_t st) {
+                          float* gmax, hipStream_t st) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t);
+    hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t,
+                       (uint32_t*)gmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -771,7 +778,7 @@ void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict__ masks, const float* __restrict__ a_in,
-            float* __restrict__ tr_a) {
+            float* __restrict__ tr_a, uint32_t* __restrict__ gmax) {
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     const int tid = threadIdx.x;
@@ -803,6 +810,12 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
         }
     sc = fmaxf(sc, __shfl_xor(sc, 32));
     const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
+    if (gmax) {
+        float wm = valid ? sc : 0.0f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        if (lane == 0) atomicMax(gmax, __float_as_uint(wm));
+    }
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -844,10 +857,12 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
 #undef AMK_LOAD
 }
 
-void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, hipStream_t st) {
+void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
+                          hipStream_t st) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_adjoint16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, N, (const uint4*)masks, a_in, tr_a);
+    hipLaunchKernelGGL(k_adjoint16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, N, (const uint4*)masks, a_in, tr_a,
+                       (uint32_t*)gmax);
 }
 
 // ---------------------------------------------------------------------------------------------

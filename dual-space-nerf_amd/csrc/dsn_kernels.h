@@ -64,9 +64,10 @@ struct DsnTrainCache {
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st);
-void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, hipStream_t st);
-void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
+void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
                           hipStream_t st);
+void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
+                          float* gmax, hipStream_t st);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,

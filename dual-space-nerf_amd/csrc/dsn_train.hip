@@ -558,6 +558,120 @@ bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ld
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same product for the twelve 256 x 256 trunk terms on the f16 matrix pipe: dW += dY^T X with both operands split
+// v = hi + lo on the fly (three products hi*hi + hi*lo + lo*hi per accumulator, plain fp16 residuals), 5.3x fewer matrix
+// cycles than the exact-fp32 kernel above.  Operand layout from the SAME row-major arrays: for the 32x32x16 MFMA lane l
+// supplies 8 consecutive contraction indices (samples n + 8 (l >> 5) + j) of ITS row / column (feature o0 + (l & 31)), i.e.
+// eight loads that are each two coalesced 128-byte rows, exactly the traffic of the fp32 kernel.  The residual split needs
+// O(1) operands: each operand is divided by a power of two >= its batch-wide magnitude (device scalars left by
+// k_tangent16 / k_adjoint16; forward activations and sigma-adjoints are O(1) already) and the product is multiplied back in
+// the epilogue.  fp32 accumulation throughout.
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 t_half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest power of two >= s (1 for s <= 0 or non-finite)
+    if (!(s > 0.0f) || !(s < 3.0e38f)) return 1.0f;
+    int e;
+    const float m = frexpf(s, &e);                                // s = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+}
+template <int OT, int IT, int WO, int WI>
+__global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY, int ldy, const float* __restrict__ sy_ptr,
+                                                    const float* __restrict__ X, int ldx, const float* __restrict__ sx_ptr, int64_t N,
+                                                    int rows_per_wg, float* __restrict__ dW, int ldw) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wo = wave / WI, wi = wave % WI;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t n1 = n0 + rows_per_wg;
+    if (n1 > N) n1 = N;
+    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    t_f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const float* pa = dY + (wo * OT) * 32 + col;
+    const float* pb = X + (wi * IT) * 32 + col;
+    float fa[OT][8], fb[IT][8], na[OT][8], nb[IT][8];
+    auto load = [&](int64_t n, float (*A)[8], float (*B)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = n + 8 * half + j;
+            const bool ok = row < n1;
+#pragma unroll
+            for (int a = 0; a < OT; ++a) A[a][j] = ok ? pa[row * ldy + a * 32] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < IT; ++b) B[b][j] = ok ? pb[row * ldx + b * 32] : 0.0f;
+        }
+    };
+    if (n0 < n1) load(n0, fa, fb);
+    for (int64_t n = n0; n < n1; n += 16) {
+        load(n + 16, na, nb);                   // next 16 samples in flight under this step's MFMAs
+        t_half8 ah[OT], al[OT], bh[IT], bl[IT];
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = fa[a][j] * iy;
+                const _Float16 h = (_Float16)v;
+                ah[a][j] = h;
+                al[a][j] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = fb[b][j] * ix;
+                const _Float16 h = (_Float16)v;
+                bh[b][j] = h;
+                bl[b][j] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int b = 0; b < IT; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[a][j] = na[a][j];
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[b][j] = nb[b][j];
+    }
+    const float back = sy * sx;
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b) {
+            const int j = (wi * IT + b) * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (wo * OT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r] * back);
+            }
+        }
+}
+
+// dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand)
+void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st) {
+    int groups = 512;
+    int rows = (int)((N + groups - 1) / groups);
+    if (rows < 64) rows = 64;
+    rows = (rows + 15) & ~15;
+    groups = (int)((N + rows - 1) / rows);
+    hipLaunchKernelGGL((k_t_wgrad16<4, 4, 2, 2>), dim3((unsigned)groups), dim3(256), 0, st, dY, 256, sy, X, 256, sx, N, rows, dW, ldw);
+}
+
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
@@ -690,10 +804,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_pe_tangent, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe);
     // all seven tangent layers in one fused split-fp16 launch (k_tangent16, relu patterns from the training forward's records),
     // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
-    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], st);
+    float* const g_tan = w.small + 300;        // batch-wide magnitudes of the tangent / adjoint arrays (zeroed with w.small)
+    float* const g_adj = w.small + 301;
+    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st);
     T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87, st));
-    for (int l = 1; l < 7; ++l)
-        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.tn[l - 1], 256, w.ap[l], 256, grd[kTrunkW[l]], kTrunkLd[l], st));
+    for (int l = 1; l < 7; ++l) wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
     T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
     colsum(w.tn[6], 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
     float *cur = w.t0, *nxt = w.t1;
@@ -712,11 +827,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;
-    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], st);
+    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
         colsum(A, 256, N64, grd[kTrunkB[l]], st);
-        T_CHECK(wgrad_mfma(N64, 256, 256, 256, w.h[l - 1], 256, A, 256, grd[kTrunkW[l]], kTrunkLd[l], st));
+        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st);
         if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, A, 256, grd[kTrunkW[4]] + W4_PE_COL, 319, st));
     }
     colsum(an[0], 256, N64, w.small, st);
