@@ -145,17 +145,41 @@ class Renderer:
     def _draws(self, R, S):
         """Train-mode random draws from the CPU default generator in the reference's order:
         torch.rand([1,R,S]) (utils/pts_utils.py:12) then torch.randn([R,S]) (utils/nerf_net_utils.py:31)."""
-        jitter = noise = None
-        # both tensors are drawn on the host first and uploaded afterwards: a pageable .to(device) waits for the stream, so
-        # drawing the second one after the first upload would leave the GPU idle for the length of a 0.5 M-sample randn
-        if self.net.training and self.cfg.MODEL.perturb > 0.0:
-            jitter = torch.rand(1, R, S).reshape(R, S)
-        if self.net.training and self.cfg.MODEL.raw_noise_std > 0.0:
-            noise = torch.randn(R, S) * self.cfg.MODEL.raw_noise_std
-        if jitter is not None:
-            jitter = jitter.to(self.device)
-        if noise is not None:
-            noise = noise.to(self.device)
+        want_j = self.net.training and self.cfg.MODEL.perturb > 0.0
+        want_n = self.net.training and self.cfg.MODEL.raw_noise_std > 0.0
+        if not (want_j or want_n):
+            return None, None
+        if self.device.type != "cuda":
+            raise RuntimeError("dsnerf_amd renders on the GPU only")
+        # The draws go straight into a small ring of persistent page-locked staging buffers (out=: same generator
+        # stream as a fresh tensor) and are uploaded with one asynchronous copy.  Fresh 2 MB host tensors cost 10-80 ms
+        # per step on the GPU boxes (page faults of newly mapped memory + the runtime pinning them for the pageable
+        # copy, which also blocks until the stream has drained): scripts/train_host_probe.py.
+        n = 2 * R * S
+        ring = getattr(self, "_draw_ring", None)
+        if ring is None or ring["n"] < n:
+            ring = self._draw_ring = {"n": n, "i": 0, "slots": [
+                {"host": torch.empty(n, dtype=torch.float32).pin_memory(), "dev": torch.empty(n, device=self.device),
+                 "done": torch.cuda.Event()} for _ in range(3)]}
+        slot = ring["slots"][ring["i"]]
+        ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        slot["done"].synchronize()            # the copy that last read this staging buffer (three draws ago) has finished
+        k = 0
+        if want_j:
+            torch.rand(1, R, S, out=slot["host"][:R * S].view(1, R, S))
+            k = R * S
+        m = k
+        if want_n:
+            hn = slot["host"][k:k + R * S].view(R, S)
+            torch.randn(R, S, out=hn)
+            if float(self.cfg.MODEL.raw_noise_std) != 1.0:
+                hn.mul_(self.cfg.MODEL.raw_noise_std)
+            m = k + R * S
+        slot["dev"][:m].copy_(slot["host"][:m], non_blocking=True)
+        slot["done"].record()
+        # device-side clones (two 5 us copies): autograd may keep the draws alive for longer than the ring does
+        jitter = slot["dev"][:R * S].view(R, S).clone() if want_j else None
+        noise = slot["dev"][k:k + R * S].view(R, S).clone() if want_n else None
         return jitter, noise
 
     # ---- sampling (reference :40-63) ----
