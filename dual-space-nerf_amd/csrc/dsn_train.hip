@@ -216,8 +216,16 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
     int64_t end = base + rows_per_block;
     if (end > N) end = N;
     float acc = 0.0f;
-    if (r0 < rs)
-        for (int64_t n = base + r0; n < end; n += rs) acc += a[n * C + c];
+    if (r0 < rs) {
+        int64_t n = base + r0;
+        for (; n + 7 * (int64_t)rs < end; n += 8 * (int64_t)rs) {      // eight independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a[(n + k * (int64_t)rs) * C + c];
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; n < end; n += rs) acc += a[n * C + c];
+    }
     s[threadIdx.x] = acc;
     __syncthreads();
     if (r0 == 0) {
@@ -578,7 +586,8 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
 template <int OT, int IT, int WO, int WI>
 __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY, int ldy, const float* __restrict__ sy_ptr,
                                                     const float* __restrict__ X, int ldx, const float* __restrict__ sx_ptr, int64_t N,
-                                                    int rows_per_wg, float* __restrict__ dW, int ldw) {
+                                                    int rows_per_wg, float* __restrict__ dW, int ldw,
+                                                    float* __restrict__ dbias) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wo = wave / WI, wi = wave % WI;
@@ -586,6 +595,10 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
     if (n1 > N) n1 = N;
+    const bool want_bias = dbias != nullptr && wi == 0;      // column sums of dY (the bias gradient) ride on the loads
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.0f;
     const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
     const float iy = 1.0f / sy, ix = 1.0f / sx;
     t_f32x16 acc[OT][IT];
@@ -613,6 +626,11 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
     for (int64_t n = n0; n < n1; n += 16) {
         load(n + 16, na, nb);                   // next 16 samples in flight under this step's MFMAs
         t_half8 ah[OT], al[OT], bh[IT], bl[IT];
+        if (want_bias) {
+#pragma unroll
+            for (int a = 0; a < OT; ++a)
+                bsum[a] += ((fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3])) + ((fa[a][4] + fa[a][5]) + (fa[a][6] + fa[a][7]));
+        }
 #pragma unroll
         for (int a = 0; a < OT; ++a)
 #pragma unroll
@@ -660,16 +678,25 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
                 atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r] * back);
             }
         }
+    if (want_bias) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+            const float t = bsum[a] + __shfl_xor(bsum[a], 32);
+            if (half == 0) atomicAdd(dbias + (wo * OT + a) * 32 + col, t);
+        }
+    }
 }
 
-// dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand)
-void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st) {
+// dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
+// dbias (optional) [256] += column sums of dY
+void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
+                  float* dbias = nullptr) {
     int groups = 512;
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL((k_t_wgrad16<4, 4, 2, 2>), dim3((unsigned)groups), dim3(256), 0, st, dY, 256, sy, X, 256, sx, N, rows, dW, ldw);
+    hipLaunchKernelGGL((k_t_wgrad16<4, 4, 2, 2>), dim3((unsigned)groups), dim3(256), 0, st, dY, 256, sy, X, 256, sx, N, rows, dW, ldw, dbias);
 }
 
 struct TrainWs {
@@ -830,8 +857,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
-        colsum(A, 256, N64, grd[kTrunkB[l]], st);
-        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st);
+        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]]);
         if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, A, 256, grd[kTrunkW[4]] + W4_PE_COL, 319, st));
     }
     colsum(an[0], 256, N64, w.small, st);
