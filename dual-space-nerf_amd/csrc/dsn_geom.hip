@@ -107,27 +107,31 @@ void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_id
 // ---------------------------------------------------------------------------------------------
 #define GG_TILE 2048
 #define GG_THREADS 256
-__global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restrict__ xyz, int V,
-                                                           const float* __restrict__ ray_o,
-                                                           const float* __restrict__ ray_d, float* __restrict__ near,
-                                                           float* __restrict__ far, int R, int S,
-                                                           const float* __restrict__ t_vals,
-                                                           const float* __restrict__ jitter, float* __restrict__ z_vals,
-                                                           float* __restrict__ pts) {
+// order-preserving int key of a float (for atomicMin / atomicMax on intervals found by different vertex slices)
+__device__ __forceinline__ int gg_key(float f) {
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float gg_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+// the vertex sweep of utils/pts_utils.py:27-47 over [v_begin, v_end): interval of ray r (thread) in units of |d| = 1
+__device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_begin, int v_end, const float* __restrict__ ray_o,
+                                         const float* __restrict__ ray_d, int R, float& zmin, float& zmax, bool& any,
+                                         float& nrm) {
     __shared__ float4 sv[GG_TILE];
-    __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
     const float gamma2 = (float)(0.05 * 0.05);
     const int tid = threadIdx.x;
     const int r = blockIdx.x * GG_THREADS + tid;
     const float o0x = ray_o[0], o0y = ray_o[1], o0z = ray_o[2];
-    float du[3] = {0.f, 0.f, 1.f}, nrm = 1.f;
+    float du[3] = {0.f, 0.f, 1.f};
+    nrm = 1.f;
     if (r < R) {
         float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
         nrm = dsn_norm3(d);
         du[0] = dsn_div(d[0], nrm); du[1] = dsn_div(d[1], nrm); du[2] = dsn_div(d[2], nrm);
     }
-    float zmin = 99999.f, zmax = -99999.f;
-    bool any = false;
+    zmin = 99999.f; zmax = -99999.f;
+    any = false;
     // Per-wave conservative cull: the 64 rays of a wave (consecutive pixels) form a narrow bundle around the axis a with
     // half-angle theta = max angle(a, du_r).  A vertex w (relative to the common origin) at angle phi from the axis is at
     // distance >= |w| sin(phi' - theta), phi' = min(phi, pi - phi), from every line of the bundle; when that exceeds
@@ -155,8 +159,8 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
         sin_t = sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
     }
     const float keep_r = 0.05f * 1.10f + 1e-4f;
-    for (int base = 0; base < V; base += GG_TILE) {
-        int n = min(GG_TILE, V - base);
+    for (int base = v_begin; base < v_end; base += GG_TILE) {
+        int n = min(GG_TILE, v_end - base);
         __syncthreads();
         for (int j = tid; j < n; j += GG_THREADS) {
             float dx = xyz[3 * (base + j)] - o0x, dy = xyz[3 * (base + j) + 1] - o0y, dz = xyz[3 * (base + j) + 2] - o0z;
@@ -194,15 +198,13 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
             }
         }
     }
-    float n_ = 0.f, f_ = 0.f;
-    if (r < R) {
-        zmin = dsn_div(zmin, nrm);
-        zmax = dsn_div(zmax, nrm);
-        n_ = near[r]; f_ = far[r];
-        if (any && zmin < zmax) { n_ = zmin; f_ = zmax; near[r] = n_; far[r] = f_; }
-    }
-    s_near[tid] = n_; s_far[tid] = f_;
-    __syncthreads();
+}
+
+// z_vals (and pts) of the block's rays from their [near, far] in s_near / s_far (utils/pts_utils.py:3-16, 55-58)
+__device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far, const float* __restrict__ ray_o,
+                                        const float* __restrict__ ray_d, int R, int S, const float* __restrict__ t_vals,
+                                        const float* __restrict__ jitter, float* __restrict__ z_vals, float* __restrict__ pts) {
+    const int tid = threadIdx.x;
     const int rays_here = min(GG_THREADS, R - blockIdx.x * GG_THREADS);
     const int total = rays_here * S;
     for (int e = tid; e < total; e += GG_THREADS) {
@@ -227,10 +229,99 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
     }
 }
 
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restrict__ xyz, int V,
+                                                           const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, float* __restrict__ near,
+                                                           float* __restrict__ far, int R, int S,
+                                                           const float* __restrict__ t_vals,
+                                                           const float* __restrict__ jitter, float* __restrict__ z_vals,
+                                                           float* __restrict__ pts) {
+    __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * GG_THREADS + tid;
+    float zmin, zmax, nrm;
+    bool any;
+    gg_sweep(xyz, 0, V, ray_o, ray_d, R, zmin, zmax, any, nrm);
+    float n_ = 0.f, f_ = 0.f;
+    if (r < R) {
+        zmin = dsn_div(zmin, nrm);
+        zmax = dsn_div(zmax, nrm);
+        n_ = near[r]; f_ = far[r];
+        if (any && zmin < zmax) { n_ = zmin; f_ = zmax; near[r] = n_; far[r] = f_; }
+    }
+    s_near[tid] = n_; s_far[tid] = f_;
+    __syncthreads();
+    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts);
+}
+
+// Few rays (a training batch, a 3072-ray chunk): the sweep of one block of rays is split over blockIdx.y vertex slices so the
+// launch fills the chip; the slices meet in two int keys per ray kept in the ray's first two z_vals slots (min / max do
+// not depend on the order: bit-identical to the single sweep), and k_sample_gg_finish turns them into near / far / z_vals.
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_init(int R, int S, float* __restrict__ z_vals) {
+    const int r = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (r < R) {
+        reinterpret_cast<int*>(z_vals)[(int64_t)r * S] = 0x7fffffff;
+        reinterpret_cast<int*>(z_vals)[(int64_t)r * S + 1] = (int)0x80000000;
+    }
+}
+
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_slice(const float* __restrict__ xyz, int V, int slice,
+                                                                 const float* __restrict__ ray_o,
+                                                                 const float* __restrict__ ray_d, int R, int S,
+                                                                 float* __restrict__ z_vals) {
+    const int r = blockIdx.x * GG_THREADS + threadIdx.x;
+    const int v0 = blockIdx.y * slice, v1 = min(V, v0 + slice);
+    float zmin, zmax, nrm;
+    bool any;
+    gg_sweep(xyz, v0, v1, ray_o, ray_d, R, zmin, zmax, any, nrm);
+    if (r < R && any) {
+        atomicMin(reinterpret_cast<int*>(z_vals) + (int64_t)r * S, gg_key(zmin));
+        atomicMax(reinterpret_cast<int*>(z_vals) + (int64_t)r * S + 1, gg_key(zmax));
+    }
+}
+
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_finish(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                  float* __restrict__ near, float* __restrict__ far, int R, int S,
+                                                                  const float* __restrict__ t_vals,
+                                                                  const float* __restrict__ jitter, float* __restrict__ z_vals,
+                                                                  float* __restrict__ pts) {
+    __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * GG_THREADS + tid;
+    float n_ = 0.f, f_ = 0.f;
+    if (r < R) {
+        const int kmin = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S];
+        const int kmax = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S + 1];
+        const bool any = kmin != 0x7fffffff;
+        const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+        const float nrm = dsn_norm3(d);
+        const float zmin = dsn_div(any ? gg_unkey(kmin) : 99999.f, nrm);
+        const float zmax = dsn_div(any ? gg_unkey(kmax) : -99999.f, nrm);
+        n_ = near[r]; f_ = far[r];
+        if (any && zmin < zmax) { n_ = zmin; f_ = zmax; near[r] = n_; far[r] = f_; }
+    }
+    s_near[tid] = n_; s_far[tid] = f_;
+    __syncthreads();       // every key of the block has been read before the first z_vals store below
+    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts);
+}
+
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
                           hipStream_t st) {
-    hipLaunchKernelGGL(k_sample_gg, dim3((R + GG_THREADS - 1) / GG_THREADS), dim3(GG_THREADS), 0, st, xyz, V, ray_o,
+    const int blocks = (R + GG_THREADS - 1) / GG_THREADS;
+    int slices = blocks > 0 ? 1024 / blocks : 1;           // aim at ~4 workgroups per CU
+    if (slices > V / 256) slices = V / 256;                // at least 256 vertices per slice
+    if (slices >= 2 && S >= 2) {
+        const int slice = (((V + slices - 1) / slices) + 63) & ~63;
+        slices = (V + slice - 1) / slice;
+        hipLaunchKernelGGL(k_sample_gg_init, dim3(blocks), dim3(GG_THREADS), 0, st, R, S, z_vals);
+        hipLaunchKernelGGL(k_sample_gg_slice, dim3(blocks, slices), dim3(GG_THREADS), 0, st, xyz, V, slice, ray_o, ray_d, R, S,
+                           z_vals);
+        hipLaunchKernelGGL(k_sample_gg_finish, dim3(blocks), dim3(GG_THREADS), 0, st, ray_o, ray_d, near, far, R, S, t_vals,
+                           jitter, z_vals, pts);
+        return;
+    }
+    hipLaunchKernelGGL(k_sample_gg, dim3(blocks), dim3(GG_THREADS), 0, st, xyz, V, ray_o,
                        ray_d, near, far, R, S, t_vals, jitter, z_vals, pts);
 }
 

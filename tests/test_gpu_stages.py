@@ -319,6 +319,31 @@ def test_sampler_bundle_cull_is_exact_at_full_size(ctx):
         assert np.array_equal(near.cpu().numpy()[sel], o["near"]) and np.array_equal(far.cpu().numpy()[sel], o["far"]), order
 
 
+@pytest.mark.parametrize("R", [8192, 3072, 601])
+def test_sampler_vertex_slices_are_exact(ctx, R):
+    """few rays (a training batch, a 3072-ray chunk): the vertex sweep is split over blockIdx.y slices that meet in
+    atomicMin / atomicMax keys - near / far / z_vals (with jitter) must equal the oracle's single sweep bit for bit, for
+    strided (incoherent) rays and a ragged count"""
+    import dsnerf_amd.synth as synth
+    _lib, dev = ctx["lib"], ctx["dev"]
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(512, 512, xyz, fit_box=True)
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(ctx["packed"], torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    S = 64
+    tv = torch.linspace(0.0, 1.0, steps=S)
+    idx = np.linspace(0, 512 * 512 - 1, R).astype(np.int64)
+    jit = synth.hash_uniform(R * S, 91).reshape(R, S).astype(np.float32)
+    near, far = T(rays["near"][idx], dev), T(rays["far"][idx], dev)
+    pts, z = _lib.sample(sc, T(rays["ray_o"][idx], dev), T(rays["ray_d"][idx], dev), near, far, S, tv.to(dev), T(jit, dev))
+    n0, f0 = rays["near"][idx].copy(), rays["far"][idx].copy()
+    o = O.sample_gg(rays["ray_o"][idx], rays["ray_d"][idx], n0, f0, xyz, S, jit, tv.numpy())
+    assert np.array_equal(z.cpu().numpy(), o["z_vals"])
+    assert np.array_equal(near.cpu().numpy(), o["near"]) and np.array_equal(far.cpu().numpy(), o["far"])
+    assert np.array_equal(pts.cpu().numpy(), o["pts"])
+
+
 @pytest.mark.parametrize("name", ["lbs_small", "lbs_full"])
 @pytest.mark.parametrize("bw_type", ["rigid_center", "rigid_interp"])
 def test_lbs_alternate(ctx, name, bw_type):
