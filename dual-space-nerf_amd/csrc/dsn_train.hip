@@ -234,6 +234,108 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
     }
 }
 
+// Weight gradient of a layer with 1 or 3 outputs: dW[o][c] += sum_n dY[n,o] X[n,c] (C = 128 or 256), and its bias gradient
+// db[o] += sum_n dY[n,o] - a weighted column sum at the HBM rate (rocBLAS runs these K = 524 288, M <= 3 shapes at 0.23 ms)
+template <int OUT>
+__global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict__ X, int C, const float* __restrict__ dY, int64_t N,
+                                                          int rows_per_block, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float s[OUT][T_THREADS];
+    const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    const int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    int64_t end = base + rows_per_block;
+    if (end > N) end = N;
+    float acc[OUT], bs[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) { acc[o] = 0.0f; bs[o] = 0.0f; }
+    int64_t n = base + r0;
+    for (; n + 3 * (int64_t)rs < end; n += 4 * (int64_t)rs) {            // four rows in flight per thread
+        float x[4], y[4][OUT];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t row = n + k * (int64_t)rs;
+            x[k] = X[row * C + c];
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) y[k][o] = dY[row * OUT + o];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) { acc[o] = fmaf(x[k], y[k][o], acc[o]); bs[o] += y[k][o]; }
+    }
+    for (; n < end; n += rs) {
+        const float x = X[n * C + c];
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) { const float y = dY[n * OUT + o]; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
+    }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) s[o][threadIdx.x] = acc[o];
+    __syncthreads();
+    if (r0 == 0) {
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) {
+            float t = acc[o];
+            for (int k = 1; k < rs; ++k) t += s[o][k * C + c];
+            atomicAdd(dW + o * C + c, t);
+        }
+    }
+    if (db && c == 0) {                  // one thread per row group saw every row of its group
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) atomicAdd(db + o, bs[o]);
+    }
+}
+
+// first lighting layer fused with its bias and ReLU: hl1[n,f] = relu(b0[f] + sum_j W0[f,j] xl[n,j]), 9 -> 128
+// (model/spacenet.py:174-188); thread = feature, two samples per block iteration, rows written coalesced
+__global__ void __launch_bounds__(T_THREADS) k_t_light_first(const float* __restrict__ xl, const float* __restrict__ W0,
+                                                              const float* __restrict__ b0, int64_t N, int rows_per_block,
+                                                              float* __restrict__ hl1) {
+    const int f = threadIdx.x & 127, r0 = threadIdx.x >> 7;
+    float w[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w[j] = W0[f * 9 + j];
+    const float b = b0[f];
+    const int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    int64_t end = base + rows_per_block;
+    if (end > N) end = N;
+    for (int64_t n = base + r0; n < end; n += 2) {
+        const float* x = xl + n * 9;          // wave-uniform address: nine scalar / broadcast loads
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc = fmaf(x[j], w[j], acc);
+        hl1[n * 128 + f] = fmaxf(acc + b, 0.0f);
+    }
+}
+
+// data gradient of the first lighting layer: d_xl[n,j] = sum_k d_hl1[n,k] W0[k,j], 128 -> 9.  A 64-sample tile goes through
+// LDS (coalesced rows in, padded rows out) so that thread (sample, quarter of k) reads its own row slice conflict-free.
+__global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __restrict__ d_hl1, const float* __restrict__ W0,
+                                                                  int64_t N, float* __restrict__ d_xl) {
+    __shared__ float tile[64][129];
+    __shared__ float part[4][64][9];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 128; e += T_THREADS) {
+        const int r = e >> 7, k = e & 127;
+        tile[r][k] = (n0 + r < N) ? d_hl1[(n0 + r) * 128 + k] : 0.0f;
+    }
+    __syncthreads();
+    const int sm = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.0f;
+    for (int k = 32 * q; k < 32 * q + 32; ++k) {
+        const float v = tile[sm][k];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] = fmaf(v, W0[k * 9 + j], acc[j]);     // uniform address: scalar loads
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) part[q][sm][j] = acc[j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 9; e += T_THREADS) {
+        const int r = e / 9, j = e - 9 * r;
+        if (n0 + r < N) d_xl[(n0 + r) * 9 + j] = (part[0][r][j] + part[1][r][j]) + (part[2][r][j] + part[3][r][j]);
+    }
+}
+
 // lighting input rows [n_w, x_w (rotated / shifted, model/spacenet.py:254-263), d/|d|]
 __global__ void __launch_bounds__(T_THREADS) k_t_light_in(const float* __restrict__ n_w, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, const float* __restrict__ z_vals,
@@ -771,6 +873,12 @@ void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_t_colsum, dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, a, C, N, rows, out);
 }
 
+template <int OUT>
+void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st) {
+    const int rows = 256;
+    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db);
+}
+
 }  // namespace
 
 size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
@@ -815,8 +923,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
     if (!cached) dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
     hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl);
-    T_CHECK(lin_fwd(h, N, 9, 128, w.xl, 9, prm[P_L0_W], 9, w.hl1, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl1, prm[P_L0_B], 128, N64 * 128);
+    hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
+                       N64, 256, w.hl1);
     T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
     hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
     hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
@@ -829,8 +937,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                        w.d_pre);
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
-    T_CHECK(lin_wgrad(h, N, 128, 1, w.hl2, 128, w.d_pre, 1, grd[P_L4_W], 128));
-    colsum(w.d_pre, 1, N64, grd[P_L4_B], st);
+    wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st);
     hipLaunchKernelGGL(k_t_seed, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                        w.d_hl2);
     T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st));
@@ -839,7 +946,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_mask, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st));
     colsum(w.d_hl1, 128, N64, grd[P_L0_B], st);
-    T_CHECK(lin_bwd(h, N, 9, 128, w.d_hl1, 128, prm[P_L0_W], 9, w.d_xl, 9, 0.0f));
+    hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
+                       w.d_xl);
 
     // ---- u = dL/dg through the normal map, then the tangent pass (second-order term) ---------------------------
     hipLaunchKernelGGL(k_t_normal_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, s.face_world, s.face_canon, w.x_c, w.g, w.idx_c,
@@ -857,14 +965,12 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float *cur = w.t0, *nxt = w.t1;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
-    T_CHECK(lin_wgrad(h, N, 128, 3, w.rr, 128, w.d_ess, 3, grd[P_RGB3_W], 128));
-    colsum(w.d_ess, 3, N64, grd[P_RGB3_B], st);
+    wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st);
     hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                        w.d_rr);
     T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st));
     colsum(w.d_rr, 128, N64, grd[P_RGB1_B], st);
-    T_CHECK(lin_wgrad(h, N, 256, 1, w.h[6], 256, w.d_sig, 1, grd[P_DEN_W], 256));
-    colsum(w.d_sig, 1, N64, grd[P_DEN_B], st);
+    wcolsum<1>(w.h[6], 256, w.d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
     T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
     hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
