@@ -363,7 +363,7 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
 
 
 class GradWorkspace:
-    """Scratch of the training backward (grown on demand; 23 KB per sample)."""
+    """Scratch of the training backward (grown on demand; 22 KB per sample)."""
 
     def __init__(self, device):
         self.device = torch.device(device)

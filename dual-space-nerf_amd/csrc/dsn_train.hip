@@ -671,9 +671,8 @@ bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ld
 // ------------------------------------------------------------------------------------------------------------
 // The same product for the twelve 256 x 256 trunk terms on the f16 matrix pipe: dW += dY^T X with both operands split
 // v = hi + lo on the fly (three products hi*hi + hi*lo + lo*hi per accumulator, plain fp16 residuals), 5.3x fewer matrix
-// cycles than the exact-fp32 kernel above.  Operand layout from the SAME row-major arrays: for the 32x32x16 MFMA lane l
-// supplies 8 consecutive contraction indices (samples n + 8 (l >> 5) + j) of ITS row / column (feature o0 + (l & 31)), i.e.
-// eight loads that are each two coalesced 128-byte rows, exactly the traffic of the fp32 kernel.  The residual split needs
+// cycles than the exact-fp32 kernel above.  Operand layout: for the 32x32x16 MFMA lane l supplies 8 consecutive contraction
+// indices (samples n + 8 (l >> 5) + j) of ITS row / column (feature o0 + (l & 31)).  The residual split needs
 // O(1) operands: each operand is divided by a power of two >= its batch-wide magnitude (device scalars left by
 // k_tangent16 / k_adjoint16; forward activations and sigma-adjoints are O(1) already) and the product is multiplied back in
 // the epilogue.  fp32 accumulation throughout.
@@ -685,23 +684,33 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
     const float m = frexpf(s, &e);                                // s = m 2^e, m in [0.5, 1)
     return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
 }
-template <int OT, int IT, int WO, int WI>
-__global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
-                                                    const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
-                                                    int rows_per_wg, float* __restrict__ dW, int ldw,
-                                                    float* __restrict__ dbias) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// The kernel: operand rows are staged through LDS by the DMA engine (global_load_lds_dwordx4, one 1 KB row per
+// wave-instruction, no staging registers; W16S_STAGES - 1 steps of 16 rows x 2 operands = 32 KB each in flight per CU, every
+// row fetched once per workgroup).  Every value is split ONCE per workgroup: thread f converts feature f of both operands for
+// the 16 rows of a step out of the fp32 ring (column reads, conflict-free) and leaves packed (hi, lo) halves in an operand
+// buffer laid out [operand][hi|lo][8-sample group][feature] x 16 B, from which a lane fetches each MFMA operand with one
+// conflict-free ds_read_b128.  LDS: 4 stages x 32 KB fp32 ring + 32 KB operand buffer = all 160 KB.
+// History on the 256 x 256 x 524 288 product: fp32 MFMA 0.80 ms -> split-fp16 with per-lane global loads and in-register
+// splits 0.44 -> LDS-DMA staging 0.345 -> convert-once 0.33 -> one workgroup per CU (256 instead of 512 groups) 0.28.  (Storing
+// per-workgroup tiles and reducing them in a second kernel instead of the atomicAdd epilogue measured the same: 0.24 + 0.04.)
+#define W16S_STAGES 4
+__global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
+                                                     const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
+                                                     int rows_per_wg, float* __restrict__ dW, int ldw,
+                                                     float* __restrict__ dbias) {
+    constexpr int OT = 4, IT = 4, WI = 2;
+    __shared__ __attribute__((aligned(16))) float ring[W16S_STAGES][2][16][256];
+    __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / WI, wi = wave % WI;
     const int col = lane & 31, half = lane >> 5;
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
     if (n1 > N) n1 = N;
-    constexpr int ldy = 256, ldx = 256;                       // both operands are dense [N,256] arrays (immediate offsets)
-    const bool want_bias = dbias != nullptr && wi == 0;      // column sums of dY (the bias gradient) ride on the loads
-    float bsum[OT];
-#pragma unroll
-    for (int a = 0; a < OT; ++a) bsum[a] = 0.0f;
+    const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
+    const bool tail = n0 + 16 * (int64_t)full < n1;
+    float bsum = 0.0f;                                   // column sum of dY feature tid (bias gradient)
     const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
     const float iy = 1.0f / sy, ix = 1.0f / sx;
     t_f32x16 acc[OT][IT];
@@ -711,62 +720,57 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
         for (int b = 0; b < IT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const float* pa = dY + (wo * OT) * 32 + col;
-    const float* pb = X + (wi * IT) * 32 + col;
-    float fa[OT][8], fb[IT][8], na[OT][8], nb[IT][8];
-    // guarded loads (rows beyond the chunk read as zero) for the first and the last step of a chunk ...
-    auto load = [&](int64_t n, float (*A)[8], float (*B)[8]) {
+    const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ring[0][0][0][0];
+    auto stage = [&](int t) {
+        const int slot = t % W16S_STAGES;
+        const int64_t row = n0 + 16 * (int64_t)t + 4 * wave;
+        const char* ga = reinterpret_cast<const char*>(dY + row * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(X + row * 256) + lane * 16;
+        const unsigned da = ring_off + (unsigned)(((slot * 2 + 0) * 16 + 4 * wave) * 1024);
+        const unsigned db = ring_off + (unsigned)(((slot * 2 + 1) * 16 + 4 * wave) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(ga), "s"(da) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(gb), "s"(db) : "memory", "m0");
+    };
+    // split the 16 values v[op][row] of feature tid and publish them
+    auto publish = [&](const float (&v)[2][16]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t row = n + 8 * half + j;
-            const bool ok = row < n1;
+        for (int j = 0; j < 16; ++j) bsum += v[0][j];
 #pragma unroll
-            for (int a = 0; a < OT; ++a) A[a][j] = ok ? pa[row * ldy + a * 32] : 0.0f;
+        for (int op = 0; op < 2; ++op) {
+            const float inv = op == 0 ? iy : ix;
 #pragma unroll
-            for (int b = 0; b < IT; ++b) B[b][j] = ok ? pb[row * ldx + b * 32] : 0.0f;
+            for (int g = 0; g < 2; ++g) {
+                t_half8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = v[op][8 * g + j] * inv;
+                    const _Float16 h = (_Float16)x;
+                    hi[j] = h;
+                    lo[j] = (_Float16)(x - (float)h);
+                }
+                opbuf[op][0][g][tid] = hi;
+                opbuf[op][1][g][tid] = lo;
+            }
         }
     };
-    // ... and plain ones off two running pointers for every step whose 16 rows are inside it (no per-load guard, no 64-bit
-    // row * ld products: the guarded form spent ~6 address / branch instructions per load)
-    auto load_fast = [&](const float* qa, const float* qb, float (*A)[8], float (*B)[8]) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int a = 0; a < OT; ++a) A[a][j] = qa[(int64_t)j * ldy + a * 32];
-#pragma unroll
-            for (int b = 0; b < IT; ++b) B[b][j] = qb[(int64_t)j * ldx + b * 32];
-        }
-    };
-    if (n0 < n1) load(n0, fa, fb);
-    const float* qa = pa + (n0 + 16 + 8 * half) * ldy;       // rows of the NEXT step for this lane
-    const float* qb = pb + (n0 + 16 + 8 * half) * ldx;
-    for (int64_t n = n0; n < n1; n += 16, qa += 16 * (int64_t)ldy, qb += 16 * (int64_t)ldx) {
-        if (n + 32 <= n1) load_fast(qa, qb, na, nb);          // next 16 samples in flight under this step's MFMAs
-        else load(n + 16, na, nb);
+    auto multiply = [&]() {
         t_half8 ah[OT], al[OT], bh[IT], bl[IT];
-        if (want_bias) {
 #pragma unroll
-            for (int a = 0; a < OT; ++a)
-                bsum[a] += ((fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3])) + ((fa[a][4] + fa[a][5]) + (fa[a][6] + fa[a][7]));
+        for (int a = 0; a < OT; ++a) {
+            ah[a] = opbuf[0][0][half][(wo * OT + a) * 32 + col];
+            al[a] = opbuf[0][1][half][(wo * OT + a) * 32 + col];
         }
 #pragma unroll
-        for (int a = 0; a < OT; ++a)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = fa[a][j] * iy;
-                const _Float16 h = (_Float16)v;
-                ah[a][j] = h;
-                al[a][j] = (_Float16)(v - (float)h);
-            }
-#pragma unroll
-        for (int b = 0; b < IT; ++b)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = fb[b][j] * ix;
-                const _Float16 h = (_Float16)v;
-                bh[b][j] = h;
-                bl[b][j] = (_Float16)(v - (float)h);
-            }
+        for (int b = 0; b < IT; ++b) {
+            bh[b] = opbuf[1][0][half][(wi * IT + b) * 32 + col];
+            bl[b] = opbuf[1][1][half][(wi * IT + b) * 32 + col];
+        }
 #pragma unroll
         for (int a = 0; a < OT; ++a)
 #pragma unroll
@@ -775,14 +779,41 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
             }
+    };
+    const int pre = full < W16S_STAGES - 1 ? full : W16S_STAGES - 1;
+    for (int t = 0; t < pre; ++t) stage(t);
+    for (int t = 0; t < full; ++t) {
+        const int issued = (t + W16S_STAGES - 1 < full) ? t + W16S_STAGES - 1 : full;
+        const int ahead = issued - (t + 1);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A: step t has landed for everyone; everyone has fetched the operands of step t - 1 (opbuf and ring slot t - 1 are free)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + W16S_STAGES - 1 < full) stage(t + W16S_STAGES - 1);
+        const int slot = t % W16S_STAGES;
+        float v[2][16];
 #pragma unroll
-        for (int a = 0; a < OT; ++a)
+        for (int op = 0; op < 2; ++op)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fa[a][j] = na[a][j];
+            for (int j = 0; j < 16; ++j) v[op][j] = ring[slot][op][j][tid];
+        publish(v);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // B: operands of step t published
+        multiply();
+    }
+    if (tail) {
+        float v[2][16];
 #pragma unroll
-        for (int b = 0; b < IT; ++b)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fb[b][j] = nb[b][j];
+        for (int j = 0; j < 16; ++j) {
+            const int64_t row = n0 + 16 * (int64_t)full + j;
+            const bool ok = row < n1;
+            v[0][j] = ok ? dY[row * 256 + tid] : 0.0f;
+            v[1][j] = ok ? X[row * 256 + tid] : 0.0f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // operands of the last full step fetched
+        publish(v);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        multiply();
     }
     const float back = sy * sx;
 #pragma unroll
@@ -796,31 +827,25 @@ __global__ void __launch_bounds__(256) k_t_wgrad16(const float* __restrict__ dY,
                 atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r] * back);
             }
         }
-    if (want_bias) {
-#pragma unroll
-        for (int a = 0; a < OT; ++a) {
-            const float t = bsum[a] + __shfl_xor(bsum[a], 32);
-            if (half == 0) atomicAdd(dbias + (wo * OT + a) * 32 + col, t);
-        }
-    }
+    if (dbias) atomicAdd(dbias + tid, bsum);
 }
 
 // dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
 // dbias (optional) [256] += column sums of dY
 void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
                   float* dbias = nullptr) {
-    int groups = 512;
+    int groups = 256;                 // one workgroup per CU, one round (with 512 the launch ran 0.33 instead of 0.28 ms)
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL((k_t_wgrad16<4, 4, 2, 2>), dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias);
+    hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias);
 }
 
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
-    float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *t1, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
+    float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
     void* masks;
     float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
     size_t bytes;
@@ -844,7 +869,6 @@ TrainWs carve(void* base, int64_t N) {
     w.sig = (float*)take(4 * n);
     w.g = (float*)take(12 * n);
     w.t0 = (float*)take(1024 * n);
-    w.t1 = (float*)take(1024 * n);
     w.tpe = (float*)take(4 * PE_LD * n);
     w.n_w = (float*)take(12 * n);
     w.xl = (float*)take(36 * n);
@@ -959,10 +983,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* const g_adj = w.small + 301;
     dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st);
     T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87, st));
-    for (int l = 1; l < 7; ++l) wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
+    for (int l = 1; l < 7; ++l)
+        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
     T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
     colsum(w.tn[6], 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
-    float *cur = w.t0, *nxt = w.t1;
+    float* cur = w.t0;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
     wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st);
