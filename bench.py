@@ -67,15 +67,30 @@ def parse():
     return ap.parse_args()
 
 
+def _flush_c_stdio():
+    """RCCL prints its banner through C stdio; push it (and ours) out so that the JSON line really is the last line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    # DSN_BENCH_FORCE_DIST=1 (debug): take the RCCL path (process group, per-frame all-gather, barriers) with ONE rank too, so the
+    # multi-GPU code can be exercised on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("DSN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists for the product path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -84,7 +99,7 @@ def main():
     from dsnerf_amd import _lib, synth
 
     if args.train:
-        return train_bench(args, dsnerf_amd, synth, dev, world, rank)
+        return train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist)
     if args.eager_baseline:
         return eager_baseline(args, _lib, synth, dev)
     H = W = args.hw
@@ -112,7 +127,7 @@ def main():
     nears = [near0.clone() for _ in range(depth)]
     fars = [far0.clone() for _ in range(depth)]
     outs = [None] * depth
-    gathered = [torch.empty(world * R, 6, dtype=torch.float32, device=dev) if world > 1 else None for _ in range(depth)]
+    gathered = [torch.empty(world * R, 6, dtype=torch.float32, device=dev) if use_dist else None for _ in range(depth)]
     packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
     torch.cuda.synchronize()
     k_step = 0
@@ -130,7 +145,7 @@ def main():
             outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                        skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
                                        screen=not args.no_screen)
-            if world > 1:
+            if use_dist:
                 packed_px[j][:, 0:3] = outs[j]["color"]
                 packed_px[j][:, 3] = outs[j]["disp_map"]
                 packed_px[j][:, 4] = outs[j]["acc_map"]
@@ -139,7 +154,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +174,7 @@ def main():
         step()
         torch.cuda.synchronize()
     ms_serial = 1e3 * (time.perf_counter() - t1) / 3
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -190,7 +205,7 @@ def main():
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
-            "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if world > 1 else "none",
+            "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if use_dist else "none",
         },
     }
 
@@ -198,14 +213,15 @@ def main():
         result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        _flush_c_stdio()
+        print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
 
 
-def train_bench(args, dsnerf_amd, synth, dev, world, rank):
+def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
     """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
     backward (dsn_render_rays_grad), Adam step.  With N>1 every rank renders its own 8192-ray batch of the step and
     the 33 gradients are averaged with ONE 2 MB RCCL all-reduce (parallel.RayParallel.average_gradients) before the
@@ -246,7 +262,7 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank):
         opt.step()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,23 +274,25 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    final_loss = float(loss)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         ms = 1e3 * dt / args.steps
         flop = 6.0 * FLOP_FIELD_PER_SAMPLE / 2.0 * R * S     # fwd, reverse, tangent, adjoint, 2 weight-gradient products
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "training rays/sec (64 samples/ray, forward + backward + Adam step)", "value": world * R * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"training step on {R} rays x {S} samples per GPU (BASELINE configs[2]), dense evaluation "
-                                   f"(jitter + noise), synthetic body V=6890/F=13776", "final_loss": float(loss),
-                       "approx_algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+                                   f"(jitter + noise), synthetic body V=6890/F=13776", "final_loss": final_loss,
+                       "approx_algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}), flush=True)
 
 
 def eager_baseline(args, _lib, synth, dev):
