@@ -141,32 +141,46 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe_reverse(const float* __restr
     g[t] = acc;
 }
 
+// (the element-wise kernels below move float4 per thread: C and the totals are multiples of 4)
 __global__ void __launch_bounds__(T_THREADS) k_t_bias_relu(float* __restrict__ z, const float* __restrict__ bias, int C,
                                                             int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
     if (t >= total) return;
-    const float v = z[t] + bias[t % C];
-    z[t] = v > 0.0f ? v : 0.0f;
+    float4 v = *reinterpret_cast<const float4*>(z + t);
+    const float* bp = bias + (int)(t % C);         // parameters come from the caller: no alignment assumed
+    const float4 bb = make_float4(bp[0], bp[1], bp[2], bp[3]);
+    v.x = fmaxf(v.x + bb.x, 0.0f); v.y = fmaxf(v.y + bb.y, 0.0f); v.z = fmaxf(v.z + bb.z, 0.0f); v.w = fmaxf(v.w + bb.w, 0.0f);
+    *reinterpret_cast<float4*>(z + t) = v;
 }
 
 // a = (h > 0) ? a : 0
 __global__ void __launch_bounds__(T_THREADS) k_t_mask(float* __restrict__ a, const float* __restrict__ h, int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
     if (t >= total) return;
-    if (!(h[t] > 0.0f)) a[t] = 0.0f;
+    float4 v = *reinterpret_cast<const float4*>(a + t);
+    const float4 hh = *reinterpret_cast<const float4*>(h + t);
+    v.x = hh.x > 0.0f ? v.x : 0.0f; v.y = hh.y > 0.0f ? v.y : 0.0f; v.z = hh.z > 0.0f ? v.z : 0.0f; v.w = hh.w > 0.0f ? v.w : 0.0f;
+    *reinterpret_cast<float4*>(a + t) = v;
 }
 
 // out[n,c] = (h[n,c] > 0) ? base[n,c] (optional) + scale[n] (optional, else 1) * w[c] : 0
 __global__ void __launch_bounds__(T_THREADS) k_t_seed(const float* __restrict__ h, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* base, int C,
                                                        int64_t total, float* out) {   // base may alias out
-    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
     if (t >= total) return;
     const int64_t n = t / C;
     const int c = (int)(t % C);
-    float v = (scale ? scale[n] : 1.0f) * w[c];
-    if (base) v += base[t];
-    out[t] = h[t] > 0.0f ? v : 0.0f;
+    const float sc = scale ? scale[n] : 1.0f;
+    const float4 ww = make_float4(w[c], w[c + 1], w[c + 2], w[c + 3]);
+    float4 v = make_float4(sc * ww.x, sc * ww.y, sc * ww.z, sc * ww.w);
+    if (base) {
+        const float4 bb = *reinterpret_cast<const float4*>(base + t);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    const float4 hh = *reinterpret_cast<const float4*>(h + t);
+    v.x = hh.x > 0.0f ? v.x : 0.0f; v.y = hh.y > 0.0f ? v.y : 0.0f; v.z = hh.z > 0.0f ? v.z : 0.0f; v.w = hh.w > 0.0f ? v.w : 0.0f;
+    *reinterpret_cast<float4*>(out + t) = v;
 }
 
 __device__ __forceinline__ float t_wave_sum(float v) {
@@ -447,12 +461,21 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colour_adjoint(const float* __r
 __global__ void __launch_bounds__(T_THREADS) k_t_rgb_hidden_adjoint(const float* __restrict__ d_ess, const float* __restrict__ w3,
                                                                      const float* __restrict__ rr, int64_t total,
                                                                      float* __restrict__ d_rr) {
-    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
     if (t >= total) return;
     const int64_t n = t >> 7;
     const int c = (int)(t & 127);
-    const float v = d_ess[3 * n] * w3[c] + d_ess[3 * n + 1] * w3[128 + c] + d_ess[3 * n + 2] * w3[256 + c];
-    d_rr[t] = rr[t] > 0.0f ? v : 0.0f;
+    const float e0 = d_ess[3 * n], e1 = d_ess[3 * n + 1], e2 = d_ess[3 * n + 2];
+    const float4 a0 = make_float4(w3[c], w3[c + 1], w3[c + 2], w3[c + 3]);
+    const float4 a1 = make_float4(w3[128 + c], w3[129 + c], w3[130 + c], w3[131 + c]);
+    const float4 a2 = make_float4(w3[256 + c], w3[257 + c], w3[258 + c], w3[259 + c]);
+    const float4 r = *reinterpret_cast<const float4*>(rr + t);
+    float4 v;
+    v.x = r.x > 0.0f ? e0 * a0.x + e1 * a1.x + e2 * a2.x : 0.0f;
+    v.y = r.y > 0.0f ? e0 * a0.y + e1 * a1.y + e2 * a2.y : 0.0f;
+    v.z = r.z > 0.0f ? e0 * a0.z + e1 * a1.z + e2 * a2.z : 0.0f;
+    v.w = r.w > 0.0f ? e0 * a0.w + e1 * a1.w + e2 * a2.w : 0.0f;
+    *reinterpret_cast<float4*>(d_rr + t) = v;
 }
 
 // u = (d n_w / d g)^T d_n_w   (model/spacenet.py:278-298; the two projections share the canonical face)
@@ -950,7 +973,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
                        N64, 256, w.hl1);
     T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_bias_relu, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
+    hipLaunchKernelGGL(k_t_bias_relu, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
     hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
     hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
 
@@ -962,12 +985,12 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
     wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st);
-    hipLaunchKernelGGL(k_t_seed, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
+    hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                        w.d_hl2);
     T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st));
     colsum(w.d_hl2, 128, N64, grd[P_L2_B], st);
     T_CHECK(lin_bwd(h, N, 128, 128, w.d_hl2, 128, prm[P_L2_W], 128, w.d_hl1, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_mask, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
+    hipLaunchKernelGGL(k_t_mask, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st));
     colsum(w.d_hl1, 128, N64, grd[P_L0_B], st);
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
@@ -991,13 +1014,13 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
     wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st);
-    hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for(N64 * 128), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
+    hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                        w.d_rr);
     T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st));
     colsum(w.d_rr, 128, N64, grd[P_RGB1_B], st);
     wcolsum<1>(w.h[6], 256, w.d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
     T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
-    hipLaunchKernelGGL(k_t_seed, grid_for(tot), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
+    hipLaunchKernelGGL(k_t_seed, grid_for((tot) / 4), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;
