@@ -689,7 +689,7 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
         float wm = valid ? sc : 0.0f;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
-        if (lane == 0) atomicMax(gmax, __float_as_uint(wm));
+        if (lane == 0 && __float_as_uint(wm) > __atomic_load_n(gmax, __ATOMIC_RELAXED)) atomicMax(gmax, __float_as_uint(wm));
     }
     {
         const uint4* mrec = masks + ((size_t)pt * 2 + half) * 7;
@@ -814,7 +814,7 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
         float wm = valid ? sc : 0.0f;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
-        if (lane == 0) atomicMax(gmax, __float_as_uint(wm));
+        if (lane == 0 && __float_as_uint(wm) > __atomic_load_n(gmax, __ATOMIC_RELAXED)) atomicMax(gmax, __float_as_uint(wm));
     }
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
 #pragma unroll

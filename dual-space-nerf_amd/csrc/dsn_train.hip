@@ -106,10 +106,11 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_
 }
 
 // tangent of the encoding along u: [u, 2^j cos(2^j x) u, -2^j sin(2^j x) u]
+// (gmax: batch-wide max |tpe| as float bits, for the split-fp16 weight-gradient product; zeroed by the caller)
 __global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restrict__ x_c, const float* __restrict__ u,
-                                                             int64_t N, float* __restrict__ tpe) {
+                                                             int64_t N, float* __restrict__ tpe, unsigned* __restrict__ gmax) {
     const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (t >= N * PE_LD) return;
+    if (t >= N * PE_LD) return;           // (N * 64 is a multiple of the block size: whole blocks leave together)
     const int64_t n = t >> 6;
     const int c = (int)(t & 63);
     float v = 0.0f;
@@ -121,6 +122,13 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restr
         v = (r < 3 ? cosf(arg) : -sinf(arg)) * f * u[3 * n + a];
     }
     tpe[t] = v;
+    float m = fabsf(v);
+    if (!(m < 3.0e38f)) m = 0.0f;          // non-finite values do not set the scale
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // same-address atomics serialise in L2 (524 288 of them cost 3.8 ms): look first, only a new maximum goes through
+    if ((threadIdx.x & 63) == 0 && m > 0.0f && __float_as_uint(m) > __atomic_load_n(gmax, __ATOMIC_RELAXED))
+        atomicMax(gmax, __float_as_uint(m));
 }
 
 // g = J_pe^T dpe  (model/spacenet.py:301-311 through the encoding)
@@ -853,6 +861,161 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
     if (dbias) atomicAdd(dbias + tid, bsum);
 }
 
+// The 256 x 64 sibling for the positional-encoding columns: dW[256, 63] += dY[N,256]^T X[N,64] (X = pe or its tangent).  Same
+// machinery with smaller pieces - 3 stages of (16 KB + 4 KB), 20 KB of operands, 80 KB of LDS = two workgroups per CU; wave w
+// owns output rows 64 w .. 64 w + 63 and all 64 columns (2 x 2 tiles).  Column 63 is the zero pad and is not written.
+#define W16P_STAGES 3
+__global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
+                                                        const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
+                                                        int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
+                                                        float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
+    __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
+    __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
+    __shared__ __attribute__((aligned(16))) t_half8 opX[2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t n1 = n0 + rows_per_wg;
+    if (n1 > N) n1 = N;
+    const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
+    const bool tail = n0 + 16 * (int64_t)full < n1;
+    float bsum = 0.0f;
+    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    t_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned offY = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringY[0][0][0];
+    const unsigned offX = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringX[0][0][0];
+    // DMA of step t: rows 4 wave .. + 3 of dY (1 KB each) and KB `wave` of the 4 KB the 16 rows of X occupy
+    auto stage = [&](int t) {
+        const int slot = t % W16P_STAGES;
+        const int64_t row = n0 + 16 * (int64_t)t;
+        const char* ga = reinterpret_cast<const char*>(dY + (row + 4 * wave) * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(X + row * 64) + wave * 1024 + lane * 16;
+        const unsigned da = offY + (unsigned)((slot * 16 + 4 * wave) * 1024);
+        const unsigned db = offX + (unsigned)(slot * 4096 + wave * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(ga), "s"(da) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db) : "memory", "m0");
+    };
+    auto split8 = [&](const float* v, float inv, t_half8& hi, t_half8& lo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j] * inv;
+            const _Float16 h = (_Float16)x;
+            hi[j] = h;
+            lo[j] = (_Float16)(x - (float)h);
+        }
+    };
+    // thread f splits feature f of dY (16 rows); threads 0..127 split feature f & 63 of X for the 8-row group f >> 6
+    auto publish = [&](const float (&vy)[16], const float (&vx)[8]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bsum += vy[j];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            t_half8 hi, lo;
+            split8(vy + 8 * g, iy, hi, lo);
+            opY[0][g][tid] = hi;
+            opY[1][g][tid] = lo;
+        }
+        if (tid < 128) {
+            t_half8 hi, lo;
+            split8(vx, ix, hi, lo);
+            opX[0][tid >> 6][tid & 63] = hi;
+            opX[1][tid >> 6][tid & 63] = lo;
+        }
+    };
+    auto multiply = [&]() {
+        t_half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            ah[a] = opY[0][half][64 * wave + 32 * a + col];
+            al[a] = opY[1][half][64 * wave + 32 * a + col];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            bh[b] = opX[0][half][32 * b + col];
+            bl[b] = opX[1][half][32 * b + col];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+    const int pre = full < W16P_STAGES - 1 ? full : W16P_STAGES - 1;
+    for (int t = 0; t < pre; ++t) stage(t);
+    for (int t = 0; t < full; ++t) {
+        const int issued = (t + W16P_STAGES - 1 < full) ? t + W16P_STAGES - 1 : full;
+        if (issued - (t + 1) >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // one later step (5 pieces) may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + W16P_STAGES - 1 < full) stage(t + W16P_STAGES - 1);
+        const int slot = t % W16P_STAGES;
+        float vy[16], vx[8];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vy[j] = ringY[slot][j][tid];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vx[j] = ringX[slot][8 * ((tid >> 6) & 1) + j][tid & 63];
+        publish(vy, vx);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        multiply();
+    }
+    if (tail) {
+        float vy[16], vx[8];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t row = n0 + 16 * (int64_t)full + j;
+            vy[j] = row < n1 ? dY[row * 256 + tid] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = n0 + 16 * (int64_t)full + 8 * ((tid >> 6) & 1) + j;
+            vx[j] = row < n1 ? X[row * 64 + (tid & 63)] : 0.0f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        publish(vy, vx);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        multiply();
+    }
+    const float back = sy * sx;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = 32 * b + col;
+            if (j >= in_valid) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 64 * wave + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r] * back);
+            }
+        }
+    if (dbias) atomicAdd(dbias + tid, bsum);
+}
+
+void wgrad_mfma16p(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, int in_valid,
+                   hipStream_t st, float* dbias = nullptr) {
+    int groups = 512;                 // two workgroups per CU
+    int rows = (int)((N + groups - 1) / groups);
+    if (rows < 64) rows = 64;
+    rows = (rows + 15) & ~15;
+    groups = (int)((N + rows - 1) / rows);
+    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias);
+}
+
 // dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
 // dbias (optional) [256] += column sums of dY
 void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
@@ -999,16 +1162,17 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // ---- u = dL/dg through the normal map, then the tangent pass (second-order term) ---------------------------
     hipLaunchKernelGGL(k_t_normal_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, s.face_world, s.face_canon, w.x_c, w.g, w.idx_c,
                        w.d_xl, N64, w.u);
-    hipLaunchKernelGGL(k_t_pe_tangent, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe);
+    float* const g_tpe = w.small + 302;        // batch-wide max |tpe| (float bits; zeroed with w.small)
+    hipLaunchKernelGGL(k_t_pe_tangent, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe, (unsigned*)g_tpe);
     // all seven tangent layers in one fused split-fp16 launch (k_tangent16, relu patterns from the training forward's records),
     // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
     float* const g_tan = w.small + 300;        // batch-wide magnitudes of the tangent / adjoint arrays (zeroed with w.small)
     float* const g_adj = w.small + 301;
     dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st);
-    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[0], 256, grd[P_S1_0W] + W0_PE_COL, 87, st));
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st);
     for (int l = 1; l < 7; ++l)
         wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
-    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.tpe, PE_LD, w.ap[4], 256, grd[P_S2_0W] + W4_PE_COL, 319, st));
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st);
     colsum(w.tn[6], 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
     float* cur = w.t0;
 
@@ -1028,10 +1192,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
         wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]]);
-        if (l == 4) T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, A, 256, grd[kTrunkW[4]] + W4_PE_COL, 319, st));
+        if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st);
     }
-    colsum(an[0], 256, N64, w.small, st);
-    T_CHECK(wgrad_mfma(N64, PE_LD, PE_K, 256, w.pe, PE_LD, an[0], 256, grd[kTrunkW[0]] + W0_PE_COL, 87, st));
+    // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
+    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small);
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
     if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
     hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,
