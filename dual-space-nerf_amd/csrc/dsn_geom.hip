@@ -567,7 +567,19 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const flo
     if (valid) { p[0] = x_c[3 * i]; p[1] = x_c[3 * i + 1]; p[2] = x_c[3 * i + 2]; }
     int fi = 0;
     if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
-    else if (valid) fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_canon, F, p[0], p[1], p[2]);
+    else {
+        if (valid) fi = dsn_nearest_lists_try(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_canon, F, p[0], p[1], p[2]);
+        // canonical points outside both grids (dense training batches: transparent samples far from the body): the wave sweeps
+        // all F centroids together for one such point at a time instead of every lane looping over F on its own
+        unsigned long long far = __ballot(valid && fi < 0);
+        while (far) {
+            const int src = __ffsll((long long)far) - 1;
+            far &= far - 1;
+            const float qx = __shfl(p[0], src), qy = __shfl(p[1], src), qz = __shfl(p[2], src);
+            const int r = dsn_nearest_sweep_wave(cent_canon, F, qx, qy, qz);
+            if ((int)(threadIdx.x & 63) == src) fi = r;
+        }
+    }
     if (!valid) return;
     DsnFaceRec fc = dsn_load_face(face_canon, fi);
     DsnFaceRec fw = dsn_load_face(face_world, fi);

@@ -109,7 +109,8 @@ __device__ __forceinline__ int dsn_grid_cell(const DsnGrid& g, float px, float p
 // exact nearest centroid through the two-level lists; exhaustive scan (global memory) beyond them.
 // Fine lists carry the centroid inline (one 16-byte load per candidate, sequential addresses, lanes in the
 // same cell share them) and are scanned four at a time in list order, which keeps first-index-wins.
-__device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
+// nearest centroid through the fine / coarse candidate lists; -1 when the point lies outside both grids
+__device__ __forceinline__ int dsn_nearest_lists_try(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
                                                  const float4* __restrict__ list_f, const DsnGrid* __restrict__ gc,
                                                  const int32_t* __restrict__ off_c, const int32_t* __restrict__ list_c,
                                                  const float4* __restrict__ cent, int F, float px, float py, float pz) {
@@ -157,10 +158,42 @@ __device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf,
         }
         return bi;
     }
+    return -1;      // outside both grids
+}
+
+// ... and the full function: points outside both grids sweep all F centroids (ascending, strict '<': first index wins)
+__device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
+                                                 const float4* __restrict__ list_f, const DsnGrid* __restrict__ gc,
+                                                 const int32_t* __restrict__ off_c, const int32_t* __restrict__ list_c,
+                                                 const float4* __restrict__ cent, int F, float px, float py, float pz) {
+    const int r = dsn_nearest_lists_try(gf, off_f, list_f, gc, off_c, list_c, cent, F, px, py, pz);
+    if (r >= 0) return r;
+    float best = INFINITY;
+    int bi = 0;
     for (int f = 0; f < F; ++f) {
         const float d = dsn_d2(px, py, pz, cent[f]);
         if (d < best) { best = d; bi = f; }
     }
     return bi;
+}
+
+// The same sweep done by the whole wave for ONE point (wave-uniform px, py, pz): lane l looks at f = l, l + 64, ... in
+// ascending order, then the wave keeps the smallest distance and, among equal distances, the smallest index - the
+// index the serial sweep returns, from the same dsn_d2 values.  Must be called by all 64 lanes.
+__device__ __forceinline__ int dsn_nearest_sweep_wave(const float4* __restrict__ cent, int F, float px, float py, float pz) {
+    const int lane = threadIdx.x & 63;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int f = lane; f < F; f += 64) {
+        const float d = dsn_d2(px, py, pz, cent[f]);
+        if (d < best) { best = d; bi = f; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float od = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    return bi == 0x7fffffff ? 0 : bi;
 }
 #endif

@@ -180,6 +180,34 @@ def test_shade(ctx, name, exhaustive, fp32):
     assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5
 
 
+def test_normals_of_points_outside_the_grids(ctx):
+    """canonical points far from the body (transparent samples of a dense training batch) lie outside both candidate grids:
+    the wave-cooperative sweep of all centroids must return the index of the exhaustive search, mixed with in-grid points
+    in the same wave"""
+    import dsnerf_amd.synth as synth
+    _lib, dev = ctx["lib"], ctx["dev"]
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(ctx["packed"], torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    rng = np.random.default_rng(11)
+    N, S = 4096 + 37, 1
+    x_c = (canon[rng.integers(0, canon.shape[0], N)] + 0.02 * rng.standard_normal((N, 3))).astype(np.float32)
+    far = rng.random(N) < 0.3                               # 30 % of the lanes, scattered: 1 .. 60 m away
+    x_c[far] += (rng.standard_normal((int(far.sum()), 3)) * rng.uniform(1.0, 60.0, (int(far.sum()), 1))).astype(np.float32)
+    x_c[5] = x_c[4]                                         # duplicates / exact ties between lanes
+    grad = rng.standard_normal((N, 3)).astype(np.float32)
+    x_w = rng.standard_normal((N, 3)).astype(np.float32)
+    ray_d = rng.standard_normal((N, 3)).astype(np.float32)
+    ess = rng.random((N, 3)).astype(np.float32)
+    a = _lib.shade(sc, ctx["packed"], T(x_c, dev), T(grad, dev), T(x_w, dev), T(ray_d, dev), T(ess, dev), S, exhaustive=False)
+    b = _lib.shade(sc, ctx["packed"], T(x_c, dev), T(grad, dev), T(x_w, dev), T(ray_d, dev), T(ess, dev), S, exhaustive=True)
+    cent = O.centroids(canon, faces)
+    want = O.nearest_face(x_c, cent)
+    assert np.array_equal(a[0].cpu().numpy(), want) and np.array_equal(b[0].cpu().numpy(), want)
+    assert torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_composite(ctx, name):
     g = load(name)
