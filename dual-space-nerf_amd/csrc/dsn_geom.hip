@@ -568,16 +568,46 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const flo
     int fi = 0;
     if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
     else {
-        if (valid) fi = dsn_nearest_lists_try(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_canon, F, p[0], p[1], p[2]);
-        // canonical points outside both grids (dense training batches: transparent samples far from the body): the wave sweeps
-        // all F centroids together for one such point at a time instead of every lane looping over F on its own
-        unsigned long long far = __ballot(valid && fi < 0);
-        while (far) {
-            const int src = __ffsll((long long)far) - 1;
-            far &= far - 1;
-            const float qx = __shfl(p[0], src), qy = __shfl(p[1], src), qz = __shfl(p[2], src);
-            const int r = dsn_nearest_sweep_wave(cent_canon, F, qx, qy, qz);
-            if ((int)(threadIdx.x & 63) == src) fi = r;
+        if (valid) fi = dsn_nearest_fine_try(nn.gf, nn.off_f, nn.list_f, p[0], p[1], p[2]);
+        // Canonical points outside the fine grid (dense training batches: transparent samples away from the body) scan a coarse
+        // list (hundreds to thousands of gathered centroids) or all F centroids.  When only a few lanes of the wave are in that
+        // position, the wave takes them one at a time and scans each list together (64 candidates per step, then an argmin with
+        // the serial tie rule) instead of a few lanes looping alone while the rest wait; when most lanes are, every lane scans
+        // its own list as before.  Same candidates, same dsn_d2 values, same index either way.
+        const bool pending = valid && fi < 0;
+        const unsigned long long pend = __ballot(pending);
+        if (pend) {
+            int my_n = 0;
+            if (pending) {
+                const int c = dsn_grid_cell(*nn.gc, p[0], p[1], p[2]);
+                my_n = c >= 0 ? nn.off_c[c + 1] - nn.off_c[c] : F;
+            }
+            int coop = pending ? my_n / 64 + 25 : 0, alone = my_n;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { coop += __shfl_xor(coop, o); alone = max(alone, __shfl_xor(alone, o)); }
+            if (coop < alone) {
+                // scalar copies of the mask drive the loop (wave-uniform control flow around the cross-lane operations)
+                const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pend);
+                const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pend >> 32));
+                for (int src = 0; src < 64; ++src) {
+                    const unsigned bit = src < 32 ? (plo >> src) & 1u : (phi >> (src - 32)) & 1u;
+                    if (!bit) continue;
+                    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0]), src));
+                    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[1]), src));
+                    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[2]), src));
+                    const int cc = dsn_grid_cell(*nn.gc, qx, qy, qz);
+                    int r;
+                    if (cc >= 0) {
+                        const int o = nn.off_c[cc];
+                        r = dsn_nearest_idlist_wave(nn.list_c + o, nn.off_c[cc + 1] - o, cent_canon, qx, qy, qz);
+                    } else {
+                        r = dsn_nearest_sweep_wave(cent_canon, F, qx, qy, qz);
+                    }
+                    if ((int)(threadIdx.x & 63) == src) fi = r;
+                }
+            } else if (pending) {
+                fi = dsn_nearest_lists(nn.gf, nn.off_f, nn.list_f, nn.gc, nn.off_c, nn.list_c, cent_canon, F, p[0], p[1], p[2]);
+            }
         }
     }
     if (!valid) return;

@@ -177,17 +177,35 @@ __device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf,
     return bi;
 }
 
-// The same sweep done by the whole wave for ONE point (wave-uniform px, py, pz): lane l looks at f = l, l + 64, ... in
-// ascending order, then the wave keeps the smallest distance and, among equal distances, the smallest index - the
-// index the serial sweep returns, from the same dsn_d2 values.  Must be called by all 64 lanes.
-__device__ __forceinline__ int dsn_nearest_sweep_wave(const float4* __restrict__ cent, int F, float px, float py, float pz) {
-    const int lane = threadIdx.x & 63;
+// fine level only: -1 when the point is outside the fine grid
+__device__ __forceinline__ int dsn_nearest_fine_try(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
+                                                    const float4* __restrict__ list_f, float px, float py, float pz) {
+    const int c = dsn_grid_cell(*gf, px, py, pz);
+    if (c < 0) return -1;
     float best = INFINITY;
-    int bi = 0x7fffffff;
-    for (int f = lane; f < F; f += 64) {
-        const float d = dsn_d2(px, py, pz, cent[f]);
-        if (d < best) { best = d; bi = f; }
+    int bi = 0;
+    const int o = off_f[c], n = off_f[c + 1] - o;
+    const float4* e = list_f + o;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float4 a = e[i], b = e[i + 1], cc = e[i + 2], d = e[i + 3];
+        const float da = dsn_d2(px, py, pz, a), db = dsn_d2(px, py, pz, b);
+        const float dc = dsn_d2(px, py, pz, cc), dd = dsn_d2(px, py, pz, d);
+        if (da < best) { best = da; bi = __float_as_int(a.w); }
+        if (db < best) { best = db; bi = __float_as_int(b.w); }
+        if (dc < best) { best = dc; bi = __float_as_int(cc.w); }
+        if (dd < best) { best = dd; bi = __float_as_int(d.w); }
     }
+    for (; i < n; ++i) {
+        const float4 a = e[i];
+        const float da = dsn_d2(px, py, pz, a);
+        if (da < best) { best = da; bi = __float_as_int(a.w); }
+    }
+    return bi;
+}
+
+// wave-level (distance, index) minimum with the serial sweeps' tie rule: equal distances keep the smaller index
+__device__ __forceinline__ int dsn_wave_argmin(float best, int bi) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const float od = __shfl_xor(best, o);
@@ -195,5 +213,31 @@ __device__ __forceinline__ int dsn_nearest_sweep_wave(const float4* __restrict__
         if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
     }
     return bi == 0x7fffffff ? 0 : bi;
+}
+
+// one coarse-level candidate list (ascending face indices) scanned by the whole wave for ONE point (wave-uniform arguments)
+__device__ __forceinline__ int dsn_nearest_idlist_wave(const int32_t* __restrict__ lst, int n, const float4* __restrict__ cent,
+                                                       float px, float py, float pz) {
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) {
+        const int f = lst[i];
+        const float d = dsn_d2(px, py, pz, cent[f]);
+        if (d < best) { best = d; bi = f; }
+    }
+    return dsn_wave_argmin(best, bi);
+}
+
+// The same sweep done by the whole wave for ONE point (wave-uniform px, py, pz): lane l looks at f = l, l + 64, ... in
+// ascending order, then the wave keeps the smallest distance and, among equal distances, the smallest index - the
+// index the serial sweep returns, from the same dsn_d2 values.  Must be called by all 64 lanes.
+__device__ __forceinline__ int dsn_nearest_sweep_wave(const float4* __restrict__ cent, int F, float px, float py, float pz) {
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int f = (int)(threadIdx.x & 63); f < F; f += 64) {
+        const float d = dsn_d2(px, py, pz, cent[f]);
+        if (d < best) { best = d; bi = f; }
+    }
+    return dsn_wave_argmin(best, bi);
 }
 #endif
