@@ -892,20 +892,27 @@ void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, con
 
 // hi quarters only: quarter q = 0 (k-step 0) and 2 (k-step 1) of every block; the 16 pieces of a chunk are shared out as
 // (quarter, half of the chunk's blocks) per wave - 4 contiguous KB each
+template <int NW>
 __device__ __forceinline__ void w16s_stage(const W16& w, int c) {
     const char* src = w.g + (size_t)c * 32768;
-    // compact ring of the screen: [chunk parity][k-step][block in chunk][1 KB] = 2 x 16 KB
-    const unsigned dst = w.ring_off + (c & 1) * 16384 + (w.wave & 1) * 8192 + (w.wave >> 1) * 4096;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
-                 : : "v"(src), "s"(dst) : "memory", "m0");
+    // compact ring of the screen: [chunk parity][k-step][block in chunk][1 KB] = 2 x 16 KB; NW = 4: 4 KB per wave, 8: 2 KB
+    const unsigned dst = w.ring_off + (c & 1) * 16384 + (w.wave & 1) * 8192 + (w.wave >> 1) * (16384 / NW);
+    if (NW == 4)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(src), "s"(dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                     : : "v"(src), "s"(dst) : "memory", "m0");
 }
+template <int NW>
 __device__ __forceinline__ void w16s_boundary(const W16& w, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int c = b / F16_CHUNK;
-    if (c + 1 < F16_SCREEN_BLOCKS / F16_CHUNK) w16s_stage(w, c + 1);
+    if (c + 1 < F16_SCREEN_BLOCKS / F16_CHUNK) w16s_stage<NW>(w, c + 1);
 }
 __device__ __forceinline__ void w16s_read(const W16& w, int b, int lane, half8& h0, half8& h1) {
     const char* s = w.ring + ((b >> 3) & 1) * 16384 + (b & 7) * 1024 + lane * 16;
@@ -914,14 +921,14 @@ __device__ __forceinline__ void w16s_read(const W16& w, int b, int lane, half8& 
 }
 // a0 += 64 Wh[32 rows][32*KB k] xh.  F16_SCREEN_ACC = 1: one accumulator (the second wave of the SIMD covers the
 // dependent MFMA pair, and the epilogue saves an accumulator read and an add per element); 2: one per k-step
-template <int KB, class Hook = NoHook>
+template <int NW, int KB, class Hook = NoHook>
 __device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8 (&xh)[KB][2], f32x16& a0, f32x16& a1,
                                          Hook&& hook = NoHook()) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         half8 n0 = w.h0, n1 = w.h1;
         if (blk + 1 < F16_SCREEN_BLOCKS) {
-            if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16s_boundary(w, blk + 1);
+            if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16s_boundary<NW>(w, blk + 1);
             w16s_read(w, blk + 1, lane, n0, n1);
         }
         a0 = MFMA16(w.h0, xh[kb][0], a0);
@@ -958,6 +965,7 @@ __device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, ha
         y[r >> 3][(r & 7) + 1] = h[1];
     }
 }
+template <int NW>
 __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&xh)[8][2],
                                          half8 (&yh)[8][2]) {
     const int half = lane >> 5;
@@ -965,8 +973,8 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 a0 = rows16(bias, m, half), a1 = zero16();
-        if (m == 0) dense16s<8>(w, blk, lane, xh, a0, a1);
-        else dense16s<8>(w, blk, lane, xh, a0, a1, [&](int kb) {
+        if (m == 0) dense16s<NW, 8>(w, blk, lane, xh, a0, a1);
+        else dense16s<NW, 8>(w, blk, lane, xh, a0, a1, [&](int kb) {
             const int r = 2 * kb;
             const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(p0[r], p0[r + 1]) : relu_pair16(p0[r] + p1[r], p0[r + 1] + p1[r + 1]);
             yh[m - 1][r >> 3][r & 7] = h[0];
@@ -977,39 +985,42 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
     relu_half16(p0, p1, yh[7]);
 }
 
-__global__ void __launch_bounds__(F16_THREADS, 2)   // 241 registers, 58 KB of LDS: two workgroups per CU
+// NW = 4: 256 threads, two workgroups per CU (58 KB of LDS each).  NW = 8: ONE workgroup of 512 threads per CU - the same eight
+// waves per CU share one weight ring, i.e. half the L2 -> LDS weight traffic per sample (DSN_SCREEN_WAVES selects).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
            const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
            int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
            float* __restrict__ dbg_s1) {
     __shared__ __attribute__((aligned(16))) char ring[2 * 16384];
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
-    __shared__ __attribute__((aligned(16))) half8 s_pe[4][F16_THREADS];
-    __shared__ int s_cnt[F16_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) half8 s_pe[4][64 * NW];
+    __shared__ int s_cnt[NW];
     __shared__ int s_base;
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
     const int64_t count = active_list ? (int64_t)(*active_count) : N;
-    if ((int64_t)blockIdx.x * 128 >= count) return;
-    int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    if ((int64_t)blockIdx.x * (32 * NW) >= count) return;
+    int64_t slot = ((int64_t)blockIdx.x * NW + wave) * 32 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
     const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
-    for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
+    for (int i = tid; i < 256 + 2304 + 8; i += 64 * NW)
         s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
-    for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += F16_THREADS) s_vec[i] *= F16_FWD_SCALE;
+    for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += 64 * NW) s_vec[i] *= F16_FWD_SCALE;
     const float* const v_b1 = s_vec + 256;
     const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
     W16 w;
-    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + (wave & 1) * 16384 + (wave >> 1) * 4096 + lane * 16;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + (wave & 1) * 16384 + (wave >> 1) * (16384 / NW) + lane * 16;
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
-    w16s_stage(w, 0);
-    w16s_boundary(w, 0);
+    w16s_stage<NW>(w, 0);
+    w16s_boundary<NW>(w, 0);
     w16s_read(w, 0, lane, w.h0, w.h1);
     int blk = 0;
     half8 ah[8][2], bh[8][2];
@@ -1034,29 +1045,29 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 a0 = rows16(s_vec, m, half), a1 = zero16();
-        dense16s<2>(w, blk, lane, ph, a0, a1);
+        dense16s<NW, 2>(w, blk, lane, ph, a0, a1);
         relu_half16(a0, a1, ah[m]);
     }
-    layer16s(w, blk, lane, v_b1 + 0 * 256, ah, bh);
-    layer16s(w, blk, lane, v_b1 + 1 * 256, bh, ah);
-    layer16s(w, blk, lane, v_b1 + 2 * 256, ah, bh);
+    layer16s<NW>(w, blk, lane, v_b1 + 0 * 256, ah, bh);
+    layer16s<NW>(w, blk, lane, v_b1 + 1 * 256, bh, ah);
+    layer16s<NW>(w, blk, lane, v_b1 + 2 * 256, ah, bh);
     // stage2.0 : [h, pe] -> 256
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 a0 = rows16(v_b1 + 3 * 256, m, half), a1 = zero16();
-        dense16s<8>(w, blk, lane, bh, a0, a1);
+        dense16s<NW, 8>(w, blk, lane, bh, a0, a1);
         half8 qh[2][2];
         qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
-        dense16s<2>(w, blk, lane, qh, a0, a1);
+        dense16s<NW, 2>(w, blk, lane, qh, a0, a1);
         relu_half16(a0, a1, ah[m]);
     }
-    layer16s(w, blk, lane, v_b1 + 4 * 256, ah, bh);
+    layer16s<NW>(w, blk, lane, v_b1 + 4 * 256, ah, bh);
     // stage2.4 + density head: sigma~ and the magnitude of its terms
     float sg = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 a0 = rows16(v_b1 + 5 * 256, m, half), a1 = zero16();
-        dense16s<8>(w, blk, lane, bh, a0, a1);
+        dense16s<NW, 8>(w, blk, lane, bh, a0, a1);
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1083,7 +1094,9 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     if (lane == 0) s_cnt[wave] = __popcll(bm);
     __syncthreads();
     if (tid == 0) {
-        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tot += s_cnt[k];
         s_base = tot ? atomicAdd(keep_count, tot) : 0;
     }
     __syncthreads();
@@ -1097,10 +1110,14 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
                          float* dbg_s1, hipStream_t st) {
-    int64_t blocks = (N + 127) / 128;
-    if (blocks == 0) return;
-    hipLaunchKernelGGL(k_screen16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, active_list, active_count,
-                       sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
+    if (N == 0) return;
+    static const bool four = getenv("DSN_SCREEN_WAVES") && atoi(getenv("DSN_SCREEN_WAVES")) == 4;
+    if (four)
+        hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, st, packed, fs, x_c, N, active_list,
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
+    else
+        hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)((N + 255) / 256)), dim3(512), 0, st, packed, fs, x_c, N, active_list,
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
 }
 
 // ---------------------------------------------------------------------------------------------
