@@ -241,7 +241,8 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 // ([N,256] fp32 per layer: point row, features 32 m + 8 (r >> 2) + 4 half + (r & 3)), times `stscale`.
 template <bool FWD, bool ST = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
-                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f) {
+                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f,
+                                          float* carry = nullptr) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -259,9 +260,9 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
     }
-    if (ST && st) {
-        const int r = 2 * kb;
-        *reinterpret_cast<float2*>(st + 8 * (r >> 2) + (r & 3)) = make_float2(vv[0] * stscale, vv[1] * stscale);
+    if (ST) {      // slices 2 j and 2 j + 1 are four consecutive features: one 16-byte store on the odd slice
+        if ((kb & 1) == 0) { carry[0] = vv[0] * stscale; carry[1] = vv[1] * stscale; }
+        else if (st) *reinterpret_cast<float4*>(st + 8 * (kb >> 1)) = make_float4(carry[0], carry[1], vv[0] * stscale, vv[1] * stscale);
     }
 }
 // the same store for a whole block (non-pipelined epilogues)
@@ -279,19 +280,20 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
                                             half8 (&yl)[8][2], uint32_t (&mk)[4], float* st = nullptr) {
     const int half = lane >> 5;
     f32x16 pM = zero16(), pC = zero16();
+    float carry[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, 1.0f, carry); });
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr);
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, 1.0f, carry);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
@@ -302,17 +304,18 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
                                             const uint32_t (&mk)[4], float* st = nullptr, float stscale = F16_GUNSCALE) {
     f32x16 pM = zero16(), pC = zero16();
     uint32_t dummy = 0;
+    float carry[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale, carry); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale, carry);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
