@@ -241,8 +241,7 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 // ([N,256] fp32 per layer: point row, features 32 m + 8 (r >> 2) + 4 half + (r & 3)), times `stscale`.
 template <bool FWD, bool ST = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
-                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f,
-                                          float* carry = nullptr) {
+                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -260,9 +259,23 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
     }
-    if (ST) {      // slices 2 j and 2 j + 1 are four consecutive features: one 16-byte store on the odd slice
-        if ((kb & 1) == 0) { carry[0] = vv[0] * stscale; carry[1] = vv[1] * stscale; }
-        else if (st) *reinterpret_cast<float4*>(st + 8 * (kb >> 1)) = make_float4(carry[0], carry[1], vv[0] * stscale, vv[1] * stscale);
+    // Training stores.  The chunk boundary (w16_boundary: s_waitcnt vmcnt(0) for the LDS-DMA pieces) also waits for every
+    // store in flight, and it sits right in front of slice 7 (blocks per output tile = blocks per chunk).  Stores issued slice
+    // by slice were 1-3 blocks old at that wait and cost a full write latency per chunk (3.84 ms vs 2.34 ms without stores);
+    // issued together on slice 7 they have a whole chunk to drain.  The 16 values are recomputed from the accumulators.
+    if (ST && kb == 7 && st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * q + e;
+                float v = FWD ? (pM[r] + pC[r]) * F16_FWD_INV : fmaf(pC[r], DSN_LO_INV, pM[r]);
+                v = FWD ? fmaxf(v, 0.0f) : dsn_keep_active(v, mword, r);
+                o[e] = v * stscale;
+            }
+            *reinterpret_cast<float4*>(st + 8 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 // the same store for a whole block (non-pipelined epilogues)
@@ -280,20 +293,19 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
                                             half8 (&yl)[8][2], uint32_t (&mk)[4], float* st = nullptr) {
     const int half = lane >> 5;
     f32x16 pM = zero16(), pC = zero16();
-    float carry[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, 1.0f, carry); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr); });
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, 1.0f, carry);
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
@@ -304,18 +316,17 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
                                             const uint32_t (&mk)[4], float* st = nullptr, float stscale = F16_GUNSCALE) {
     f32x16 pM = zero16(), pC = zero16();
     uint32_t dummy = 0;
-    float carry[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale, carry); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale, carry);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
