@@ -123,3 +123,42 @@ def test_training_steps_reduce_the_loss():
         losses.append(float(loss))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses
+
+
+def test_full_batch_gradients_are_additive_and_linear():
+    """BASELINE configs[2] size (8192 rays x 64 samples, dense): the gradient of a batch is the sum of the gradients of its
+    two halves, and doubling every cotangent doubles it - size-independent properties that exercise the large-N code paths
+    (one workgroup per CU in the weight-gradient kernels, LDS-DMA rings, batch-wide magnitudes) against the small-N ones"""
+    import dsnerf_amd
+    from dsnerf_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    R, S = 8192, 64
+    canon, faces = synth.make_body()
+    sd = synth.make_state_dict()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(512, 512, xyz, fit_box=True)
+    sel = np.linspace(0, 512 * 512 - 1, R).astype(np.int64)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    params = {k: T(v) for k, v in sd.items()}
+    packed = _lib.PackedParams(dev).update(params)
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    poses = T(synth.make_poses())
+    sc.set_frame(packed, T(xyz), poses, 5)
+    o, d = T(rays["ray_o"][sel]), T(rays["ray_d"][sel])
+    near, far = T(rays["near"][sel]), T(rays["far"][sel])
+    jit = T(synth.hash_uniform(R * S, 21).reshape(R, S).astype(np.float32))
+    _, z = _lib.sample(sc, o, d, near, far, S, torch.linspace(0.0, 1.0, steps=S).to(dev), jit, want_pts=False)
+    noise = T((synth.hash_uniform(R * S, 22).reshape(R, S).astype(np.float32) - 0.5) * 2.0)
+    d_rgb = T(synth.hash_uniform(R * 3, 23).reshape(R, 3).astype(np.float32) - 0.5)
+    d_acc = T(synth.hash_uniform(R, 24).astype(np.float32) - 0.5)
+
+    def grads(lo, hi, scale=1.0):
+        g = _lib.render_rays_grad(sc, params, poses, 5, False, o[lo:hi].contiguous(), d[lo:hi].contiguous(), z[lo:hi].contiguous(),
+                                  noise[lo:hi].contiguous(), (d_rgb[lo:hi] * scale).contiguous(), None, (d_acc[lo:hi] * scale).contiguous())
+        return [x.double().cpu().numpy() for x in g]
+
+    whole, a, b, twice = grads(0, R), grads(0, R // 2), grads(R // 2, R), grads(0, R, 2.0)
+    for k, w, x, y, t in zip(_lib.PARAM_ORDER, whole, a, b, twice):
+        n = max(np.linalg.norm(w), 1e-30)
+        assert np.linalg.norm(w - (x + y)) / n < 2e-5, (k, np.linalg.norm(w - (x + y)) / n)
+        assert np.linalg.norm(t - 2.0 * w) / n < 2e-5, (k, np.linalg.norm(t - 2.0 * w) / n)
