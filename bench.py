@@ -403,24 +403,42 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
     screen = split and not args.no_screen
     ms_screen = None
     n_all = n_eval
-    if screen:
-        # the density screen runs first, on every non-transparent sample; the accurate forward sees what it keeps
+    if split:
+        # The field kernels of a frame - screen -> accurate forward -> reverse - are enqueued back to back, exactly as
+        # dsn_render_rays does, with an event between them and NO host synchronisation inside a repetition: a kernel timed
+        # alone after an idle gap starts on a cool, fully clocked chip and reads ~4 % faster than it runs inside a frame.
         keep = torch.zeros(N, dtype=torch.int32, device=dev)
         kcnt = torch.zeros(64, dtype=torch.int32, device=dev)
-        ms_screen = timed(lambda: L.dsn_field_screen(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(keep),
-                                                     _lib._ptr(kcnt), _lib._stream()), pre=lambda: kcnt.zero_())
-        lst, cnt = keep, kcnt
-        n_eval = int(kcnt[0])
-    if split:
         rec = torch.empty(L.dsn_field_record_bytes(C.c_int64(N)), dtype=torch.uint8, device=dev)
         pos = torch.zeros(N, dtype=torch.int32, device=dev)
         pcnt = torch.zeros(64, dtype=torch.int32, device=dev)
-        ms = timed(lambda: L.dsn_field_forward(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess),
-                                               _lib._ptr(rec), _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream()),
-                   pre=lambda: pcnt.zero_())
+        f_lst, f_cnt = (keep, kcnt) if screen else (lst, cnt)
+        t_s, t_f, t_r = [], [], []
+        for i in range(reps + 2):                      # 2 untimed warm-up repetitions
+            kcnt.zero_()
+            pcnt.zero_()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            if screen:
+                rc = L.dsn_field_screen(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(keep), _lib._ptr(kcnt),
+                                        _lib._stream())
+                assert rc == 0, L.dsn_last_error()
+            ev[1].record()
+            rc = L.dsn_field_forward(*a0, _lib._ptr(f_lst), _lib._ptr(f_cnt), _lib._ptr(sig), _lib._ptr(ess), _lib._ptr(rec),
+                                     _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream())
+            assert rc == 0, L.dsn_last_error()
+            ev[2].record()
+            rc = L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g), _lib._stream())
+            assert rc == 0, L.dsn_last_error()
+            ev[3].record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                t_s.append(ev[0].elapsed_time(ev[1])); t_f.append(ev[1].elapsed_time(ev[2])); t_r.append(ev[2].elapsed_time(ev[3]))
+        if screen:
+            ms_screen = float(np.mean(t_s))
+            n_eval = int(kcnt[0])
+        ms, ms_rev = float(np.mean(t_f)), float(np.mean(t_r))
         n_pos = int(pcnt[0])
-        ms_rev = timed(lambda: L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g),
-                                                   _lib._stream()))
         flop_per, kern = FLOP_FIELD_FWD_PER_SAMPLE, "k_field16<forward>"
     else:
         ms = timed(lambda: L.dsn_field(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess), _lib._ptr(g),
