@@ -481,3 +481,45 @@ def test_density_screen_margin_other_weights(seed, gain):
     assert 0.01 >= 5 * dev_rel, dev_rel
     print(f"seed {seed} gain {gain}: {int(act.numel())} samples, {float(empty.float().mean()):.3f} declared empty, "
           f"max dev/S1 {dev_rel:.2e}, |sigma| max {float(sig.abs().max()):.1f}")
+
+
+def test_config4_share_131072_rays_x_128_samples():
+    """BASELINE configs[3] (1024 x 1024 x 128 over 8 GPUs): one GPU's share, 131 072 rays x 128 samples = 16.8 M samples.
+    Size-independent properties: weights sum to acc, acc in [0, 1], depth inside [near, far] of the ray, the frame is
+    bit-identical with the density screen on / off, and 4096 rays rendered on their own (rays are independent; that call is
+    below the cell-major threshold, i.e. the per-lane nearest-face search) give the same pixels bit for bit"""
+    from dsnerf_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(1024, 1024, xyz, fit_box=True)
+    S, R = 128, 131072
+    sel = np.arange(R) + 3 * R                    # the fourth of eight contiguous blocks of the frame
+    sd = synth.make_state_dict()
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(packed, torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    o, d = T(rays["ray_o"][sel]), T(rays["ray_d"][sel])
+    tv = torch.linspace(0.0, 1.0, steps=S).to(dev)
+
+    def render(idx=slice(None), **kw):
+        n, f = T(rays["near"][sel][idx]), T(rays["far"][sel][idx])
+        out = _lib.render_rays(sc, packed, _lib.RenderWorkspace(dev), o[idx].contiguous(), d[idx].contiguous(), n, f, S, tv, **kw)
+        return out, n, f
+
+    a, n, f = render()
+    acc, w, dep = a["acc_map"], a["weights"], a["depth_map"]
+    assert torch.isfinite(a["color"]).all() and torch.isfinite(w).all()
+    assert float((w.sum(-1) - acc).abs().max()) < 1e-5
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    hit = acc > 1e-3
+    zz = dep[hit] / acc[hit]
+    assert bool(((zz >= n[hit] - 1e-4) & (zz <= f[hit] + 1e-4)).all())
+    b, _, _ = render(screen=False)
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(a[k], b[k]), k
+    sub = slice(70000, 74096)
+    c, _, _ = render(sub)
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(a[k][sub], c[k]), k
