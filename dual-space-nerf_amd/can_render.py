@@ -133,12 +133,33 @@ class Renderer:
         return self._tvals[S]
 
     def _dev(self, t, dtype=torch.float32):
-        return t.to(device=self.device, dtype=dtype).contiguous()
+        """Tensor on the device.  Host tensors of a batch (the reference's DataLoader hands over pageable CPU tensors and calls
+        .cuda() on them, can_render.py:100-103,138-141) go through a small ring of persistent page-locked staging buffers and an
+        asynchronous copy: a pageable .to(device) of a few MB costs 10-20 ms on the GPU boxes (the runtime pins and unpins the
+        pages and waits for the stream), 70 ms per 512 x 512 batch (scripts/render_view_probe.py)."""
+        if t.is_cuda or t.numel() * t.element_size() < (1 << 16) or t.is_pinned() or self.device.type != "cuda":
+            return t.to(device=self.device, dtype=dtype).contiguous()
+        n = t.numel()
+        ring = getattr(self, "_stage_ring", None)
+        if ring is None:
+            ring = self._stage_ring = {"i": 0, "slots": [{"host": None, "done": torch.cuda.Event()} for _ in range(8)]}
+        slot = ring["slots"][ring["i"]]
+        ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        slot["done"].synchronize()                       # the copy that last read this staging buffer has finished
+        nbytes = n * dtype.itemsize
+        if slot["host"] is None or slot["host"].numel() < nbytes:
+            slot["host"] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8).pin_memory()
+        stage = slot["host"][:nbytes].view(dtype).view(t.shape)
+        stage.copy_(t)                                   # host memcpy (with the dtype conversion, if any)
+        out = torch.empty(t.shape, dtype=dtype, device=self.device)
+        out.copy_(stage, non_blocking=True)
+        slot["done"].record()
+        return out
 
     def _set_frame(self, batch):
         frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
         zero_code, ls, rot, rc = self.net.frame_args(batch)
-        self.scene.set_frame(self.net.packed(self.device), batch["xyz"][0], batch["poses"][0], frame, zero_code, ls,
+        self.scene.set_frame(self.net.packed(self.device), self._dev(batch["xyz"][0]), batch["poses"][0], frame, zero_code, ls,
                              rot, rc)
         return frame
 
@@ -316,13 +337,15 @@ class Renderer:
         (novel_pose_vis.py:41-66) and on-device metrics (`image_metrics`)."""
         coarse, _ = self.batchify_rays_view(batch["ray_o"], batch["ray_d"], batch["near"], batch["far"], batch, chunk)
         _, H, W, _ = batch["img"].shape
-        # utils/render_utils.py:466-472 post_process, done on the device (dsn_image_scatter); ONE device->host copy
-        img = _lib.image_scatter(coarse, batch["mask_at_box"][0], H, W)
+        # utils/render_utils.py:466-472 post_process, done on the device (dsn_image_scatter)
+        img = _lib.image_scatter(coarse, self._dev(batch["mask_at_box"][0], torch.uint8), H, W)
         if device_output:
             return img
-        packed = torch.cat([img["coarse_color"], img["coarse_disp"], img["coarse_acc"], img["coarse_depth"]], dim=-1).cpu()
-        return {"coarse_color": packed[..., 0:3].contiguous(), "coarse_disp": packed[..., 3:4].contiguous(),
-                "coarse_acc": packed[..., 4:5].contiguous(), "coarse_depth": packed[..., 5:6].contiguous()}
+        # four contiguous device images -> four device->host copies (0.1-0.3 ms each).  Packing them into one [H,W,6] copy and
+        # splitting the channels on the host cost 19-25 ms per frame on the GPU boxes (strided CPU copies; scripts/d2h_probe.py)
+        # (fresh host tensors like the reference's; on the GPU boxes first-touch page faults of new host memory make this step
+        # vary between 1 and 20 ms per frame - `device_output=True` avoids it)
+        return {k: img[k].contiguous().cpu() for k in ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")}
 
     def image_metrics(self, color_img, batch, clamp=True):
         """test.py:62-71 on the device: clamp to [0,1], psnr with and without mask_at_box against batch["img"].
