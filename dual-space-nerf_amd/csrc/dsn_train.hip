@@ -623,7 +623,8 @@ typedef float t_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int OT, int IT, int WO, int WI>
 __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
-                                                  int64_t N, int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid) {
+                                                  int64_t N, int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
+                                                  float* __restrict__ dbias) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wo = wave / WI, wi = wave % WI;
@@ -631,6 +632,10 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
     if (n1 > N) n1 = N;
+    const bool want_bias = dbias != nullptr && wi == 0;      // column sums of dY (the bias gradient) ride on the loads
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.0f;
     t_f32x16 acc[OT][IT];
 #pragma unroll
     for (int a = 0; a < OT; ++a)
@@ -658,6 +663,12 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
     if (n0 < n1) load(n0, af, bf);
     for (int64_t n = n0; n < n1; n += 2 * DEPTH) {
         load(n + 2 * DEPTH, an, bn);   // rows beyond the chunk read as zero
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s)
+#pragma unroll
+                for (int a = 0; a < OT; ++a) bsum[a] += af[s][a];
+        }
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s)
 #pragma unroll
@@ -685,23 +696,30 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
                 atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r]);
             }
         }
+    if (want_bias) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+            const float t = bsum[a] + __shfl_xor(bsum[a], 32);
+            if (half == 0) atomicAdd(dbias + (wo * OT + a) * 32 + col, t);
+        }
+    }
 }
 
 // dW [out,in] += dY[N,out]^T X[N,in]; out in {128,256}, padded in (multiple of 32) in {32,64,128,256}, in_valid <= in
 // (columns >= in_valid are neither read nor written)
 bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ldx, const float* dY, int ldy, float* dW, int ldw,
-                hipStream_t st) {
+                hipStream_t st, float* dbias = nullptr) {
     int groups = (out == 256 && in == 256) ? 256 : 768;   // the smaller tiles leave room for 3 workgroups per CU
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 1) & ~1;
     groups = (int)((N + rows - 1) / rows);
     const dim3 g((unsigned)groups), b(256);
-    if (out == 256 && in == 256) hipLaunchKernelGGL((k_t_wgrad<4, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
-    else if (out == 256 && in == 64) hipLaunchKernelGGL((k_t_wgrad<2, 2, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
-    else if (out == 128 && in == 256) hipLaunchKernelGGL((k_t_wgrad<2, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
-    else if (out == 128 && in == 128) hipLaunchKernelGGL((k_t_wgrad<2, 2, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
-    else if (out == 128 && in == 32) hipLaunchKernelGGL((k_t_wgrad<1, 1, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid);
+    if (out == 256 && in == 256) hipLaunchKernelGGL((k_t_wgrad<4, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
+    else if (out == 256 && in == 64) hipLaunchKernelGGL((k_t_wgrad<2, 2, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
+    else if (out == 128 && in == 256) hipLaunchKernelGGL((k_t_wgrad<2, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
+    else if (out == 128 && in == 128) hipLaunchKernelGGL((k_t_wgrad<2, 2, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
+    else if (out == 128 && in == 32) hipLaunchKernelGGL((k_t_wgrad<1, 1, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
     else return false;
     return true;
 }
@@ -1168,12 +1186,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st);
     hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                        w.d_hl2);
-    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st));
-    colsum(w.d_hl2, 128, N64, grd[P_L2_B], st);
+    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B]));
     T_CHECK(lin_bwd(h, N, 128, 128, w.d_hl2, 128, prm[P_L2_W], 128, w.d_hl1, 128, 0.0f));
     hipLaunchKernelGGL(k_t_mask, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
-    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st));
-    colsum(w.d_hl1, 128, N64, grd[P_L0_B], st);
+    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B]));
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
                        w.d_xl);
 
@@ -1202,8 +1218,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st);
     hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                        w.d_rr);
-    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st));
-    colsum(w.d_rr, 128, N64, grd[P_RGB1_B], st);
+    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B]));
     wcolsum<1>(w.h[6], 256, w.d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
     T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
     hipLaunchKernelGGL(k_t_seed, grid_for((tot) / 4), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
