@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
            const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
            int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
-           float* __restrict__ dbg_s1) {
+           float* __restrict__ dbg_s1, float margin) {
     __shared__ __attribute__((aligned(16))) char ring[2 * 16384];
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
     __shared__ __attribute__((aligned(16))) half8 s_pe[4][64 * NW];
@@ -1097,7 +1097,7 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     sg += bd;
     s1 += fabsf(bd);
     const bool mine = valid && half == 0;
-    const bool empty = sg < -(F16_SCREEN_REL * s1 + F16_SCREEN_ABS);
+    const bool empty = sg < -(margin * s1 + margin);      // margin = F16_SCREEN_REL = F16_SCREEN_ABS unless DSN_SCREEN_MARGIN overrides
     if (mine) {
         if (empty) sigma[pt] = sg;
         if (dbg_sigma) { dbg_sigma[pt] = sg; dbg_s1[pt] = s1; }
@@ -1126,12 +1126,15 @@ void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const flo
                          float* dbg_s1, hipStream_t st) {
     if (N == 0) return;
     static const bool four = getenv("DSN_SCREEN_WAVES") && atoi(getenv("DSN_SCREEN_WAVES")) == 4;
+    // tuning / experiment switch: the relative and absolute safety margin of the empty test (default 0.01)
+    static const float margin = getenv("DSN_SCREEN_MARGIN") ? (float)atof(getenv("DSN_SCREEN_MARGIN")) : F16_SCREEN_REL;
+    static_assert(F16_SCREEN_REL == F16_SCREEN_ABS, "one margin constant");
     if (four)
         hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, st, packed, fs, x_c, N, active_list,
-                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin);
     else
         hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)((N + 255) / 256)), dim3(512), 0, st, packed, fs, x_c, N, active_list,
-                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1);
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin);
 }
 
 // ---------------------------------------------------------------------------------------------
