@@ -340,9 +340,9 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
                     float* out_weights, float* out_z, void* workspace, void* stream) {
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays: empty ray batch");      // (first: empty tensors come with null pointers)
     DSN_REQUIRE(scene && packed && ray_o && ray_d && near && far && t_vals && workspace, "dsn_render_rays: null argument");
     DSN_REQUIRE(out_rgb && out_disp && out_acc && out_depth, "dsn_render_rays: null output");
-    DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays: empty ray batch");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_render_rays: bad V/F");
     const bool skip = (flags & DSN_SKIP_TRANSPARENT) != 0;
     DSN_REQUIRE(!(skip && noise), "dsn_render_rays: DSN_SKIP_TRANSPARENT is only exact without noise (eval mode)");
@@ -413,10 +413,11 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
                           float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
                           float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
                           void* workspace, void* grad_workspace, void* stream) {
+    DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays_train: empty ray batch");
     DSN_REQUIRE(scene && packed && ray_o && ray_d && near && far && t_vals && workspace && grad_workspace,
                 "dsn_render_rays_train: null argument");
     DSN_REQUIRE(out_rgb && out_disp && out_acc && out_depth, "dsn_render_rays_train: null output");
-    DSN_REQUIRE(R > 0 && S > 0 && V > 0 && F > 0, "dsn_render_rays_train: bad sizes");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_render_rays_train: bad V/F");
     DSN_REQUIRE(!(flags & (DSN_SKIP_TRANSPARENT | DSN_FIELD_FP32)), "dsn_render_rays_train: dense split-fp16 evaluation only");
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);

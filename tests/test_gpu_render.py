@@ -523,3 +523,30 @@ def test_config4_share_131072_rays_x_128_samples():
     c, _, _ = render(sub)
     for k in ("color", "acc_map", "depth_map", "weights"):
         assert torch.equal(a[k][sub], c[k]), k
+
+
+def test_empty_and_degenerate_ray_batches():
+    """R = 0 is rejected with the library's 'empty ray batch' message (a RuntimeError, like every bad argument); R = 1 and
+    S = 1 / 2 (below every tile size, S < 2 takes the sampler's single-sweep path) render finite values"""
+    from dsnerf_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    sd = synth.make_state_dict()
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    sc = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    sc.set_frame(packed, torch.from_numpy(xyz), torch.from_numpy(synth.make_poses()), 5)
+    rays = synth.make_rays(64, 64, xyz, fit_box=True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def render(R, S):
+        o, d, n, f = T(rays["ray_o"][:R]), T(rays["ray_d"][:R]), T(rays["near"][:R]), T(rays["far"][:R])
+        return _lib.render_rays(sc, packed, _lib.RenderWorkspace(dev), o, d, n, f, S, torch.linspace(0.0, 1.0, steps=S).to(dev))
+
+    with pytest.raises(RuntimeError, match="empty ray batch"):
+        render(0, 64)
+    for R, S in ((1, 64), (1, 1), (3, 2), (5, 1)):
+        out = render(R, S)
+        assert out["color"].shape == (R, 3) and out["weights"].shape == (R, S)
+        assert torch.isfinite(out["color"]).all() and torch.isfinite(out["weights"]).all()
+        assert float((out["weights"].sum(-1) - out["acc_map"]).abs().max()) < 1e-6
