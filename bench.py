@@ -129,6 +129,8 @@ def main():
     outs = [None] * depth
     gathered = [torch.empty(world * R, 6, dtype=torch.float32, device=dev) if use_dist else None for _ in range(depth)]
     packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
+    for j in range(depth):          # allocate every slot's workspace up front (setup, not a step: W may be smaller than the depth)
+        wss[j].get(R, S)
     torch.cuda.synchronize()
     k_step = 0
 
