@@ -12,11 +12,11 @@ import json
 import re
 import sys
 
-MODES = {"0": "full", "1": "forward", "2": "reverse"}
+MODES = {"0": "full", "1": "forward", "2": "reverse", "3": "train"}
 
 
 def kname(raw):
-    k = raw.split("(")[0].replace("void ", "").strip()
+    k = raw.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
     m = re.match(r"k_field16<(\d)>", k)
     return f"k_field16<{MODES[m.group(1)]}>" if m else k
 
