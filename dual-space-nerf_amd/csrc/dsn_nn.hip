@@ -164,26 +164,48 @@ __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ c
 }
 
 // exclusive scan of the counts (single block), capacity check
+// exclusive prefix of one value per thread over a 1024-thread block (wave shuffles + one LDS hop); total in *tot
+#define SCAN_PER 11                       // cells per thread and tile: 11 264-cell tiles, LDS stride 11 is conflict-free
+__device__ __forceinline__ int dsn_block_exscan(int v, int* s_w, int& tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+    __syncthreads();                      // (s_w may still be read from the previous call)
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int wp = 0, t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int x = s_w[k]; if (k < wave) wp += x; t += x; }
+    tot = t;
+    return wp + inc - v;
+}
+
+// Single-workgroup exclusive scan of the per-cell counts (offsets[i + 1] holds count(i) on entry).  The cells go through LDS in
+// tiles with coalesced global accesses; the earlier version walked the array with a stride of `per` cells per thread and
+// scanned the 1024 partial sums with 20 barriers.
 __global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int32_t* __restrict__ offsets) {
-    __shared__ int s_part[1024];
+    __shared__ int s_n[1024 * SCAN_PER];
+    __shared__ int s_w[16];
     const int n = g->ncell;
     const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int a = min(n, t * per), b = min(n, a + per);
-    int sum = 0;
-    for (int i = a; i < b; ++i) sum += offsets[i + 1];
-    s_part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-        int v = (t >= o) ? s_part[t - o] : 0;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024 * SCAN_PER) {
+        for (int i = t; i < 1024 * SCAN_PER; i += 1024) s_n[i] = base + i < n ? offsets[base + i + 1] : 0;
         __syncthreads();
-        s_part[t] += v;
+        int v[SCAN_PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; sum += v[k]; }
+        int tot;
+        int run = carry + dsn_block_exscan(sum, s_w, tot);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { run += v[k]; s_n[t * SCAN_PER + k] = run; }      // inclusive, as before
+        __syncthreads();
+        for (int i = t; i < 1024 * SCAN_PER; i += 1024) if (base + i < n) offsets[base + i + 1] = s_n[i];
+        carry += tot;
         __syncthreads();
     }
-    int run = s_part[t] - sum;   // exclusive prefix of this thread's chunk
-    for (int i = a; i < b; ++i) { int c = offsets[i + 1]; run += c; offsets[i + 1] = run; }
-    if (t == 0) offsets[0] = 0;
-    if (t == 1023) { g->total = s_part[1023]; g->ok = (s_part[1023] <= g->cap) ? 1 : 0; }
+    if (t == 0) { offsets[0] = 0; g->total = carry; g->ok = (carry <= g->cap) ? 1 : 0; }
 }
 
 // pass 3: write the lists in ascending face order (ballot compaction keeps the order)
@@ -307,38 +329,38 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
 }
 
 // exclusive scans over the cells: sample offsets and wave offsets (ceil(count / 64) waves per cell); counts are
-// cleared for their second life as scatter cursors.  Single workgroup, 64 cells per thread.
+// cleared for their second life as scatter cursors.  Single workgroup, LDS-staged tiles (see k_grid_scan).
 __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
                                                     int32_t* __restrict__ totals) {
-    __shared__ int s_a[1024], s_b[1024];
+    __shared__ int s_n[1024 * SCAN_PER];
+    __shared__ int s_w[16];
     const int ncell = gf->ok ? gf->ncell : 0;
-    const int per = (ncell + 1023) / 1024;
-    const int t = threadIdx.x, c0 = t * per;
-    int a = 0, b = 0;
-    for (int k = 0; k < per; ++k) {
-        const int c = c0 + k;
-        if (c < ncell) { const int n = counts[c]; a += n; b += (n + 63) >> 6; }
-    }
-    s_a[t] = a; s_b[t] = b;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int xa = t >= off ? s_a[t - off] : 0, xb = t >= off ? s_b[t - off] : 0;
+    const int t = threadIdx.x;
+    int carry_a = 0, carry_b = 0;
+    for (int base = 0; base < ncell; base += 1024 * SCAN_PER) {
+        for (int i = t; i < 1024 * SCAN_PER; i += 1024) s_n[i] = base + i < ncell ? counts[base + i] : 0;
         __syncthreads();
-        s_a[t] += xa; s_b[t] += xb;
+        int v[SCAN_PER], a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; a += v[k]; b += (v[k] + 63) >> 6; }
+        int tot_a, tot_b;
+        int ra = carry_a + dsn_block_exscan(a, s_w, tot_a);
+        int rb = carry_b + dsn_block_exscan(b, s_w, tot_b);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = ra; ra += v[k]; }
+        __syncthreads();
+        for (int i = t; i < 1024 * SCAN_PER; i += 1024) if (base + i < ncell) offs[base + i] = s_n[i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += (v[k] + 63) >> 6; }
+        __syncthreads();
+        for (int i = t; i < 1024 * SCAN_PER; i += 1024)
+            if (base + i < ncell) { wave_offs[base + i] = s_n[i]; counts[base + i] = 0; }
+        carry_a += tot_a; carry_b += tot_b;
         __syncthreads();
     }
-    int ra = s_a[t] - a, rb = s_b[t] - b;
-    for (int k = 0; k < per; ++k) {
-        const int c = c0 + k;
-        if (c < ncell) {
-            const int n = counts[c];
-            offs[c] = ra; wave_offs[c] = rb;
-            ra += n; rb += (n + 63) >> 6;
-            counts[c] = 0;
-        }
-    }
-    if (t == 1023) { totals[0] = s_b[1023]; totals[1] = s_a[1023]; }
+    if (t == 0) { totals[0] = carry_b; totals[1] = carry_a; }
 }
 
 // wave w -> its cell (cells with many samples own several consecutive waves)
