@@ -353,7 +353,9 @@ class Renderer:
         img = color_img.to(self.device)
         if clamp:
             img = torch.clamp(img, min=0.0, max=1.0)
-        m = _lib.image_psnr(img, batch["img"][0], batch["mask_at_box"][0]).cpu()
+        gt = batch["img"][0]
+        gt = self._dev(gt, gt.dtype if gt.dtype in (torch.float32, torch.float64) else torch.float32)   # staged upload (6 MB of float64)
+        m = _lib.image_psnr(img, gt, self._dev(batch["mask_at_box"][0], torch.uint8)).cpu()
         return {"mse": float(m[0]), "mse_wMask": float(m[1]), "psnr_woMask": float(m[2]), "psnr_wMask": float(m[3])}
 
     # ---- density query for marching cubes (reference :280-296) ----
