@@ -430,7 +430,8 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
     dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st);
     dsn_launch_normal(s, c.x_c, c.grad, N, nullptr, nullptr, c.idx_c, c.n_w, exh, st);
-    dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, nullptr, nullptr, w.colour, st);
+    dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, nullptr, nullptr, w.colour, st,
+                       c.hl1, c.hl2, c.pre);
     dsn_launch_composite(w.colour, c.sigma, c.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc, out_weights,
                          out_depth, st);
     return dsn_check_launch("dsn_render_rays_train");

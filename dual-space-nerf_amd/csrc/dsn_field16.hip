@@ -1163,7 +1163,9 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
           const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
           const float* __restrict__ z_vals, const float* __restrict__ essence, int64_t N, int S,
           const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-          float* __restrict__ colour) {
+          float* __restrict__ colour, float* __restrict__ tr_hl1, float* __restrict__ tr_hl2, float* __restrict__ tr_pre) {
+    // tr_*: (training forward) the two hidden layers after their ReLU, row-major [N,128], and the pre-activation of the output
+    // [N] - what the backward of the lighting MLP needs, so that it does not have to evaluate the MLP again
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -1214,6 +1216,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = fold16(aM, aC);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+        if (tr_hl1 && valid) store16(tr_hl1 + pt * 128 + 4 * half + 32 * m, v, 1.0f);
         split16<true>(v, h1h[m], h1l[m]);
     }
     float part = 0.0f;
@@ -1223,14 +1226,16 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
             light_block(w16 + (size_t)(OFF_LT1 / DSN_BLK + m * 4 + kb) * 4096, lane, h1h[kb], h1l[kb], aM, aC, true);
-        const f32x16 v = fold16(aM, aC);
+        f32x16 v = fold16(aM, aC);
         const f32x16 w2 = rows16(packed + OFF_WLT2, m, half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part = fmaf(w2[r], fmaxf(v[r], 0.0f), part);
+        for (int r = 0; r < 16; ++r) { v[r] = fmaxf(v[r], 0.0f); part = fmaf(w2[r], v[r], part); }
+        if (tr_hl2 && valid) store16(tr_hl2 + pt * 128 + 4 * half + 32 * m, v, 1.0f);
     }
     part += __shfl_xor(part, 32);
     const float o = part + packed[OFF_SCAL + 4];
     const float wgt = (o > 0.0f ? o : expm1f(o)) + 1.0f;   // ELU(alpha=1) + 1
+    if (tr_pre && valid && half == 0) tr_pre[pt] = o;
     if (valid && half == 0) {
         colour[3 * pt + 0] = wgt * essence[3 * pt + 0];
         colour[3 * pt + 1] = wgt * essence[3 * pt + 1];
@@ -1240,9 +1245,10 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
-                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st) {
+                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st,
+                        float* tr_hl1, float* tr_hl2, float* tr_pre) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_light16, dim3((unsigned)blocks), dim3(256), 0, st, packed, fs, n_w, x_w, ray_o, ray_d, z_vals,
-                       essence, N, S, active_list, active_count, colour);
+                       essence, N, S, active_list, active_count, colour, tr_hl1, tr_hl2, tr_pre);
 }

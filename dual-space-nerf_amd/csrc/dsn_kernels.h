@@ -39,7 +39,8 @@ void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const flo
                          float* dbg_s1, hipStream_t st);
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
-                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);
+                        int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st,
+                        float* tr_hl1 = nullptr, float* tr_hl2 = nullptr, float* tr_pre = nullptr);
 void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
                             float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
 // dsn_field.hip
@@ -60,6 +61,7 @@ size_t dsn_train_workspace_size(int64_t N);
 // the part of that workspace a training FORWARD fills for its backward (dsn_render_rays_train -> dsn_render_rays_grad)
 struct DsnTrainCache {
     uint8_t* transparent; int32_t* idx_c; float *x_c, *sigma, *essence, *grad, *n_w, *h0, *a0, *rr; void* masks;
+    float *hl1, *hl2, *pre;        // lighting MLP: hidden layers after ReLU [N,128] and the output pre-activation [N]
 };
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,

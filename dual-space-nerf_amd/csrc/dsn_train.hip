@@ -1120,7 +1120,7 @@ size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
 
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N) {
     const TrainWs w = carve(workspace, N);
-    DsnTrainCache c = {w.transparent, w.idx_c, w.x_c, w.sig, w.ess, w.g, w.n_w, w.h[0], w.ap[0], w.rr, w.masks};
+    DsnTrainCache c = {w.transparent, w.idx_c, w.x_c, w.sig, w.ess, w.g, w.n_w, w.h[0], w.ap[0], w.rr, w.masks, w.hl1, w.hl2, w.pre};
     return c;
 }
 
@@ -1169,11 +1169,13 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
     if (!cached) dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
     hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl);
-    hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
-                       N64, 256, w.hl1);
-    T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_bias_relu, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
-    hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
+    if (!cached) {      // (the training forward's k_light16 has left hl1, hl2 and pre in this workspace otherwise)
+        hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
+                           N64, 256, w.hl1);
+        T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
+        hipLaunchKernelGGL(k_t_bias_relu, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
+        hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
+    }
     hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
 
     // ---- adjoint of compositing and of the colour product ------------------------------------------------------
