@@ -430,7 +430,8 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
                                      _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream())
             assert rc == 0, L.dsn_last_error()
             ev[2].record()
-            rc = L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g), _lib._stream())
+            rc = L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g), _lib._ptr(sig), _lib._ptr(ess),
+                                     _lib._stream())
             assert rc == 0, L.dsn_last_error()
             ev[3].record()
             torch.cuda.synchronize()

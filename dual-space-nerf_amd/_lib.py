@@ -37,6 +37,8 @@ EXPORTS = [
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
+    "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
+    "dsn_set_screen_margin", "dsn_module_grad",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -44,6 +46,10 @@ NN_EXHAUSTIVE = 2
 FIELD_FP32 = 4
 SAMPLE_UNIFORM = 8
 NO_SCREEN = 16
+SCREEN_AUDIT = 32
+RAYS_ZJU, RAYS_H36M = 0, 1
+# int32 words of the render workspace the library leaves diagnostics in (include/dsnerf.h)
+CNT_ACTIVE, CNT_POS, CNT_KEEP, CNT_AUDIT, CNT_RANGE = 0, 16, 32, 40, 48
 
 
 def lib():
@@ -57,8 +63,12 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
         for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
-                  "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes"):
+                  "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
+                  "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
+        if L.dsn_abi_version() != 2:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 2 - rebuild it "
+                               "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
 
@@ -99,9 +109,13 @@ class PackedParams:
         self.buf = torch.zeros(lib().dsn_packed_param_bytes(), dtype=torch.uint8, device=self.device)
         self._versions = None
         self._keep = None
+        self.generation = 0        # bumped by every re-pack: what calibrations / caches of derived state key on
+        self.screen = None         # dict(deviation, margin, overflow_fraction, points, usable) once calibrate_screen() has run
 
     def update(self, state: dict, force=False):
-        """state: name -> tensor (any device).  Re-packs only when a tensor changed (version counters)."""
+        """state: name -> tensor (any device).  Re-packs only when a tensor changed (data pointer / version counter).
+        Edits made through `param.data` do not bump the version counter: pass force=True (or call net.packed(force=True))
+        after such an edit."""
         tensors = [state[k] for k in PARAM_ORDER]
         versions = tuple((t.data_ptr(), t._version) for t in tensors)
         if not force and versions == self._versions:
@@ -111,7 +125,28 @@ class PackedParams:
         _check(lib().dsn_pack_params(ptrs, _ptr(self.buf), _stream()), "dsn_pack_params")
         self._keep = dev  # keep sources alive until the pack kernel has run (stream-ordered)
         self._versions = versions
+        self.generation += 1
+        self.screen = None         # the packed image carries the conservative default margin again
         return self
+
+    def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20):
+        """Measure the density screen's margin for THESE parameters on the scene's current frame state
+        (dsn_calibrate_screen; synchronises: meant to run once per checkpoint, Renderer does it lazily before the first
+        eval-mode frame after the parameters changed).  Returns / stores dict(deviation, margin, overflow_fraction,
+        points, usable); usable = False means the screen would need a margin above the cap and is left out."""
+        ws = torch.empty(lib().dsn_calibrate_workspace_bytes(C.c_int64(n_points)), dtype=torch.uint8, device=self.device)
+        out = torch.zeros(4, dtype=torch.float32, device=self.device)
+        _check(lib().dsn_calibrate_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), C.c_int64(n_points), _ptr(ws), _ptr(out),
+                                          _stream()), "dsn_calibrate_screen")
+        d, m, ovf, n = (float(v) for v in out.cpu())
+        self.screen = {"deviation": d, "margin": m, "overflow_fraction": ovf, "points": int(n), "usable": bool(m < float("inf"))}
+        return self.screen
+
+    def set_screen_margin(self, margin: float):
+        _check(lib().dsn_set_screen_margin(_ptr(self.buf), C.c_float(margin), _stream()), "dsn_set_screen_margin")
+        self.screen = {"deviation": None, "margin": float(margin), "overflow_fraction": None, "points": 0,
+                       "usable": margin < float("inf")}
+        return self.screen
 
 
 class Scene:
@@ -149,6 +184,52 @@ class Scene:
                "dsn_set_frame")
         self._keep_frame = (xyz, poses, ls, r, rc)
         return self
+
+
+def _set_pose(buf, packed, poses, pose_feat, frame_idx, zero_code, light_shift, rot, rot_center, device):
+    f = lambda a, n: None if a is None else _f32(a.reshape(-1)[:n], device)
+    po = None if poses is None else _f32(poses.reshape(24, 3), device)
+    pf, ls, r, rc = f(pose_feat, 16), f(light_shift, 3), f(rot, 4), f(rot_center, 2)
+    _check(lib().dsn_set_pose(_ptr(buf), _ptr(packed.buf), _ptr(po), _ptr(pf), int(frame_idx), int(bool(zero_code)), _ptr(ls),
+                              _ptr(r), _ptr(rc), _stream()), "dsn_set_pose")
+    return (po, pf, ls, r, rc)
+
+
+def scene_set_pose(scene: Scene, packed: PackedParams, poses, frame_idx, zero_code=False, light_shift=None, rot=None,
+                   rot_center=None, pose_feat=None):
+    """pose code / embedding row / light edits of a scene, mesh untouched (dsn_set_pose)."""
+    scene._keep_pose = _set_pose(scene.buf, packed, poses, pose_feat, frame_idx, zero_code, light_shift, rot, rot_center, scene.device)
+    scene.frame_key = None     # no longer the state a set_frame(reuse=True) left
+    return scene
+
+
+class PoseState:
+    """Per-frame network state WITHOUT a body model (dsn_pose_state_bytes): all a density-only query or a stand-alone
+    SpaceNet.forward needs.  Quacks like a Scene for `field()` (V = F = 0)."""
+
+    def __init__(self, device):
+        require_gpu()
+        self.device = torch.device(device)
+        self.V = self.F = 0
+        self.buf = torch.zeros(lib().dsn_pose_state_bytes(), dtype=torch.uint8, device=self.device)
+
+    def set_pose(self, packed: PackedParams, poses, frame_idx, zero_code=False, light_shift=None, rot=None, rot_center=None,
+                 pose_feat=None):
+        self._keep = _set_pose(self.buf, packed, poses, pose_feat, frame_idx, zero_code, light_shift, rot, rot_center, self.device)
+        return self
+
+
+def light(packed: PackedParams, normal, xyz_world, view_dir_world, essence, fp32=False):
+    """model/spacenet.py:174-188 LightingMLP.forward as a pure function (dsn_light): [N,3] x 4 -> colour [N,3]."""
+    dev = packed.device
+    a = [_f32(t.reshape(-1, 3), dev) for t in (normal, xyz_world, view_dir_world, essence)]
+    N = a[0].shape[0]
+    assert all(t.shape[0] == N for t in a), "normal, xyz_world, view_dir_world and essence_feature must have one row per point"
+    col = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib().dsn_pose_state_bytes(), dtype=torch.uint8, device=dev)
+    _check(lib().dsn_light(_ptr(packed.buf), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), C.c_int64(N), _ptr(col), _ptr(scratch),
+                           FIELD_FP32 if fp32 else 0, _stream()), "dsn_light")
+    return col
 
 
 def nn_stats(scene: Scene):
@@ -230,12 +311,15 @@ def field_forward(scene: Scene, packed: PackedParams, x_c, active=None):
     return sigma, ess, rec, (pos, pcnt)
 
 
-def field_reverse(scene: Scene, packed: PackedParams, x_c, rec, pos):
+def field_reverse(scene: Scene, packed: PackedParams, x_c, rec, pos, sigma, essence):
+    """sigma / essence: the arrays field_forward returned (samples it flagged as outside the fp16 range are re-evaluated
+    here in exact fp32, all three outputs)."""
     x_c = x_c.reshape(-1, 3)
     N = x_c.shape[0]
     g = torch.zeros(N, 3, dtype=torch.float32, device=scene.device)
     _check(lib().dsn_field_reverse(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(x_c, torch.float32), C.c_int64(N),
-                                   _ptr(pos[0]), _ptr(pos[1]), _ptr(rec), _ptr(g), _stream()), "dsn_field_reverse")
+                                   _ptr(pos[0]), _ptr(pos[1]), _ptr(rec), _ptr(g), _ptr(sigma, torch.float32),
+                                   _ptr(essence, torch.float32), _stream()), "dsn_field_reverse")
     return g
 
 
@@ -319,7 +403,7 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True, train_cache=None):
+                fp32=False, uniform=False, screen=True, train_cache=None, audit=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -342,6 +426,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= SAMPLE_UNIFORM
     if not screen:
         flags |= NO_SCREEN
+    elif audit:
+        flags |= SCREEN_AUDIT
     buf = ws.get(R, S)
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT
@@ -406,6 +492,34 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
     return grads
 
 
+def module_grad(scene: Scene, params, poses, frame_idx, zero_code, x_world, x_canon, view_dir, d_colour, d_sigma,
+                ws: GradWorkspace = None, packed: PackedParams = None):
+    """Parameter gradients of DualSpaceNeRF.forward's (colour, density) on explicit points (dsn_module_grad).  Returns the
+    33 gradients in PARAM_ORDER (float32, device)."""
+    dev = scene.device
+    if isinstance(params, dict):
+        params = [params[k] for k in PARAM_ORDER]
+    prm = [_f32(p.detach(), dev) for p in params]
+    if packed is None:
+        packed = PackedParams(dev).update(dict(zip(PARAM_ORDER, prm)))
+    grads = [torch.empty_like(p) for p in prm]
+    pp = (C.c_void_p * 33)(*[p.data_ptr() for p in prm])
+    gp = (C.c_void_p * 33)(*[g.data_ptr() for g in grads])
+    xw, xc, vd = (_f32(t.reshape(-1, 3), dev) for t in (x_world, x_canon, view_dir))
+    N = xw.shape[0]
+    dc = _f32(d_colour.reshape(N, 3), dev)
+    ds = _f32(d_sigma.reshape(N), dev)
+    zeros = torch.zeros(N, dtype=torch.float32, device=dev)
+    ws = ws or GradWorkspace(dev)
+    buf = ws.get(N, 1)
+    poses = _f32(poses.reshape(24, 3), dev)
+    _check(lib().dsn_module_grad(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), pp, _ptr(poses), int(frame_idx),
+                                 int(bool(zero_code)), _ptr(xw), _ptr(xc), _ptr(vd), _ptr(zeros), C.c_int64(N), _ptr(dc), _ptr(ds), gp,
+                                 _ptr(buf), _stream()), "dsn_module_grad")
+    scene._keep_grad = (prm, xw, xc, vd, dc, ds, zeros, poses, packed)
+    return grads
+
+
 def image_scatter(out: dict, mask_at_box, H, W, clamp=False):
     """post_process on the device (utils/render_utils.py:466-472): compacted per-ray outputs -> [H,W,*] images with
     zeros outside mask_at_box.  out: dict with color [R,3], disp_map, acc_map, depth_map [R] (device)."""
@@ -437,8 +551,10 @@ def image_psnr(img_rgb, gt, mask_at_box=None):
     return out
 
 
-def camera_rays(K, R, T, bounds, H, W, device=None):
-    """Whole-image rays + box near/far on the device (utils/rays_utils.py:16-30, :63-97, :176-184).
+def camera_rays(K, R, T, bounds, H, W, device=None, convention="zju"):
+    """Whole-image rays + box near/far on the device: convention "zju" = utils/rays_utils.py:16-30, :63-97, :176-184
+    (un-normalised directions, padded box), "h36m" = utils/h36m_utils.py:14-28, :61-76, :162-176 (unit directions,
+    float32 slab test).
     K, R [3,3], T [3] or [3,1], bounds [2,3]: anything convertible to float64 tensors.  Returns
     (ray_o [H*W,3], ray_d [H*W,3], near [H*W], far [H*W], mask_at_box [H*W] bool), all on the device, uncompacted."""
     require_gpu()
@@ -451,6 +567,8 @@ def camera_rays(K, R, T, bounds, H, W, device=None):
     near = torch.empty(n, dtype=torch.float32, device=dev)
     far = torch.empty(n, dtype=torch.float32, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
-    _check(lib().dsn_camera_rays(_ptr(K), _ptr(R), _ptr(T), _ptr(bounds), H, W, _ptr(ray_o), _ptr(ray_d), _ptr(near),
-                                 _ptr(far), _ptr(mask), _stream()), "dsn_camera_rays")
+    if convention not in ("zju", "h36m"):
+        raise ValueError("convention must be 'zju' or 'h36m'")
+    _check(lib().dsn_camera_rays(_ptr(K), _ptr(R), _ptr(T), _ptr(bounds), H, W, RAYS_H36M if convention == "h36m" else RAYS_ZJU,
+                                 _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), _ptr(mask), _stream()), "dsn_camera_rays")
     return ray_o, ray_d, near, far, mask.bool()

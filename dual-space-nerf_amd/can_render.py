@@ -12,9 +12,19 @@ What differs from the reference, on purpose (DESIGN.md "boundary"):
   * in eval mode the networks are evaluated only on non-transparent samples (their sigma is zeroed and
     their colour has weight 0 in the reference, can_render.py:115-120) - outputs are identical;
   * `render()` in train mode returns tensors attached to ONE autograd node whose backward is
-    dsn_render_rays_grad (analytic parameter gradients, csrc/dsn_train.hip) instead of an op-by-op graph.
+    dsn_render_rays_grad (analytic parameter gradients, csrc/dsn_train.hip) instead of an op-by-op graph;
+  * `render_views(batches)` (not in the reference): the per-frame loop of novel_pose_vis.py:41-66 with several frames in
+    flight on their own HIP streams.
+
+Eval-mode safety nets: the plain-fp16 density screen runs with a margin CALIBRATED for the loaded
+parameters (first eval frame after the parameters changed: `screen_info`), can be audited on every frame
+(`screen_audit = True`, `last_screen_audit()`), and samples whose activations leave the fp16 range of the split-fp16
+kernels are re-evaluated in exact fp32 inside the library.
 """
 from __future__ import annotations
+
+import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -38,9 +48,15 @@ _OUT_KEYS = ("color", "disp_map", "acc_map", "depth_map", "weights", "z_vals")
 
 
 class _RenderRays(torch.autograd.Function):
-    """render_rays as one differentiable node: forward = dsn_render_rays, backward = dsn_render_rays_grad
+    """render_rays as one differentiable node: forward = dsn_render_rays_train, backward = dsn_render_rays_grad
     (what loss.backward() does in trainer.py:70-81).  Inputs that are not parameters carry no gradient, as in the
-    reference (rays, near/far, xyz, poses are data)."""
+    reference (rays, near/far, xyz, poses are data).
+
+    The forward leaves its activations in the renderer's ONE shared GradWorkspace; `_cache_gen` says whose they are.  A
+    backward whose generation is no longer current recomputes them - into the same workspace, so it takes a new generation
+    itself: with several renders outstanding every backward but (at most) the latest recomputes, and none reads another
+    call's activations.  The parameters go through save_for_backward, so an in-place update between forward and backward
+    (optimizer.step()) raises like it does for an op-by-op graph."""
 
     @staticmethod
     def forward(ctx, renderer, call, *params):
@@ -51,7 +67,9 @@ class _RenderRays(torch.autograd.Function):
         out = _lib.render_rays(renderer.scene, renderer.net.packed(renderer.device), renderer._ws, o, d, near, far, S,
                                renderer._t_vals(S), jitter, noise, skip_transparent=False, uniform=uniform,
                                train_cache=renderer._grad_ws)
-        ctx.renderer, ctx.call, ctx.params, ctx.gen = renderer, (o, d, noise, frame_args), params, renderer._cache_gen
+        ctx.save_for_backward(*params)
+        ctx.renderer, ctx.call, ctx.gen = renderer, (o, d, noise, frame_args), renderer._cache_gen
+        ctx.frame_key = renderer.scene.frame_key
         ctx.z_vals = out["z_vals"]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out["z_vals"])
@@ -62,19 +80,34 @@ class _RenderRays(torch.autograd.Function):
         r = ctx.renderer
         o, d, noise, frame_args = ctx.call
         xyz, poses, frame, zero_code, ls, rot, rc = frame_args
-        params = [p.detach() for p in ctx.params]
+        saved = ctx.saved_tensors                           # raises if a parameter was modified in place since the forward
+        params = [p.detach() for p in saved]
         sd = dict(zip(_lib.PARAM_ORDER, params))
         packed = r.net.packed(r.device)
-        r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc, reuse=True)   # no-op unless another frame was rendered since
+        if r.scene.frame_key != ctx.frame_key:              # another frame was set since this call's forward
+            r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc)
+            r._frame_src = None
         if g_color is None:
             g_color = torch.zeros(o.shape[0], 3, device=r.device)
         if not hasattr(r, "_grad_ws"):
             r._grad_ws = _lib.GradWorkspace(r.device)
+        cached = ctx.gen == getattr(r, "_cache_gen", -1)
+        if not cached:
+            r._cache_gen = getattr(r, "_cache_gen", 0) + 1  # the recomputation below overwrites the shared workspace
         grads = _lib.render_rays_grad(r.scene, sd, poses, frame, zero_code, o, d, ctx.z_vals, noise, g_color, g_disp, g_acc,
-                                      g_depth, g_weights, ws=r._grad_ws, packed=packed,
-                                      cached=(ctx.gen == getattr(r, "_cache_gen", -1)))
-        grads = [g.to(device=p.device, dtype=p.dtype).reshape(p.shape) for g, p in zip(grads, ctx.params)]
+                                      g_depth, g_weights, ws=r._grad_ws, packed=packed, cached=cached)
+        grads = [g.to(device=p.device, dtype=p.dtype).reshape(p.shape) for g, p in zip(grads, saved)]
         return (None, None) + tuple(grads)
+
+
+class _ViewSlot:
+    """scene + workspace + stream of one frame in flight (render_views)"""
+
+    def __init__(self, renderer, own_scene):
+        self.scene = renderer.scene if not own_scene else _lib.Scene(renderer.canonical_model["vertex"], renderer.face_idx,
+                                                                    renderer.device)
+        self.ws = renderer._ws if not own_scene else _lib.RenderWorkspace(renderer.device)
+        self.stream = torch.cuda.Stream(device=renderer.device)
 
 
 class Renderer:
@@ -92,8 +125,12 @@ class Renderer:
         self.sample_points_mode = cfg.MODEL.sample_points_mode
         self._ws = _lib.RenderWorkspace(self.device)
         self._tvals = {}
-        self.skip_transparent = True
-        self.last_active_fraction = None
+        self._frame_src = None
+        self._slots = []
+        self.skip_transparent = True      # eval mode: networks only on non-transparent samples (exact)
+        self.density_screen = True        # eval mode: plain-fp16 screen in front of the accurate pass (exact by its margin)
+        self.screen_audit = False         # eval mode: re-check 1/128 of the screened-out samples every frame
+        self.screen_info = None           # what the last calibration of the screen found (PackedParams.calibrate_screen)
 
     # ---- mode switches (reference :26-38) ----
     def train(self):
@@ -156,12 +193,43 @@ class Renderer:
         slot["done"].record()
         return out
 
-    def _set_frame(self, batch):
-        frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
+    # Which tensor the scene's posed mesh came from.  Identity, not address: a DataLoader hands a NEW tensor per batch that
+    # routinely reuses the freed address of the previous one, and an in-place update keeps the address - so the
+    # key is a weak reference to the tensor object plus its version counter.
+    def _mark_frame_src(self, xyz):
+        self._frame_src = (weakref.ref(xyz), xyz._version)
+
+    def _is_frame_src(self, xyz):
+        src = self._frame_src
+        return src is not None and src[0]() is xyz and src[1] == xyz._version
+
+    def _set_frame(self, batch, scene=None, frame=None):
+        """dsn_set_frame from a batch.  Returns the arguments as used (device tensors), which a training forward keeps for
+        its backward."""
+        scene = self.scene if scene is None else scene
+        if frame is None:
+            frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
         zero_code, ls, rot, rc = self.net.frame_args(batch)
-        self.scene.set_frame(self.net.packed(self.device), self._dev(batch["xyz"][0]), batch["poses"][0], frame, zero_code, ls,
-                             rot, rc)
-        return frame
+        xyz = self._dev(batch["xyz"][0])
+        poses = batch["poses"][0].to(device=self.device, dtype=torch.float32).contiguous()
+        scene.set_frame(self.net.packed(self.device), xyz, poses, frame, zero_code, ls, rot, rc)
+        if scene is self.scene:
+            self._mark_frame_src(batch["xyz"])
+        return (xyz, poses, frame, zero_code, ls, rot, rc)
+
+    def _screen_usable(self):
+        """eval mode: is the density screen on for this frame?  Calibrates its margin for the current parameters first
+        (once per parameter version: synchronises then).  Needs the scene's frame state to be set."""
+        if not (self.density_screen and self.skip_transparent):
+            return False
+        packed = self.net.packed(self.device)
+        if packed.screen is None:
+            info = packed.calibrate_screen(self.scene)
+            self.screen_info = dict(info)
+            if not info["usable"]:
+                warnings.warn("dsnerf_amd: the plain-fp16 density screen deviates by %.3g of the term magnitude for these parameters "
+                              "(cap 0.005): it stays off, every non-transparent sample takes the accurate pass" % info["deviation"])
+        return packed.screen["usable"]
 
     def _draws(self, R, S):
         """Train-mode random draws from the CPU default generator in the reference's order:
@@ -215,7 +283,7 @@ class Renderer:
         jitter = None
         if self.net.training and self.cfg.MODEL.perturb > 0.0:
             jitter = torch.rand(1, R, S).reshape(R, S).to(self.device)
-        if getattr(self, "_frame_xyz_ptr", None) != xyz.data_ptr():
+        if not self._is_frame_src(xyz):
             self._upload_xyz(xyz)
         pts, z = _lib.sample(self.scene, o, d, n_dev, f_dev, S, self._t_vals(S), jitter, want_pts=True, gg=(mode == "GG"))
         if mode == "GG":   # in-place update like the reference (:52-53)
@@ -228,7 +296,17 @@ class Renderer:
         x = self._dev(xyz.reshape(-1, 3))
         poses = torch.zeros(24, 3, device=self.device)
         self.scene.set_frame(self.net.packed(self.device), x, poses, 0, True, None, None, None)
-        self._frame_xyz_ptr = xyz.data_ptr()
+        self._mark_frame_src(xyz)
+
+    def _ensure_mesh(self, batch):
+        """the scene must hold batch['xyz'] as its posed mesh (direct callers of the warp / network stages)"""
+        xyz = batch["xyz"]
+        if self._is_frame_src(xyz):
+            return
+        if "poses" in batch and "frame" in batch:
+            self._set_frame(batch)
+        else:
+            self._upload_xyz(xyz)
 
     # ---- warp (reference :299-379) ----
     def w2l(self, pts_world, ray_o_W, ray_d_W, batch):
@@ -245,15 +323,8 @@ class Renderer:
         ray_d_W, when given, is the per-POINT direction tensor [B,N,3] the reference passes."""
         assert floor == -4 and ceil == 5, "the uv clamp range is compiled in (utils/render_utils.py:103)"
         B, ray, sp, _ = pts_world.shape
-        xyz = batch["xyz"]
-        if getattr(self, "_frame_xyz_ptr", None) != xyz.data_ptr():
-            if "poses" in batch and "frame" in batch:
-                self._set_frame(batch)
-                self._frame_xyz_ptr = xyz.data_ptr()
-            else:
-                self._upload_xyz(xyz)
+        self._ensure_mesh(batch)
         pts = self._dev(pts_world.reshape(-1, 3))
-        N = pts.shape[0]
         if ray_d_W is not None:
             d = self._dev(ray_d_W.reshape(-1, 3))   # per point -> S=1 addressing
             out = _lib.warp(self.scene, pts, d, 1, want_dir=True)
@@ -262,14 +333,33 @@ class Renderer:
         return out["x_c"], out["transparent"].bool().reshape(B, -1)
 
     # ---- network + compositing on explicit points (reference :65-134) ----
+    def _module_info(self, batch_info, frame_idx):
+        """batch_info for a call into self.net with this renderer's scene holding the frame (so the module does not build a
+        second scene): reference batch_info needs poses, xyz, Th, canonical_model, face_idx (model/spacenet.py:210-266)."""
+        bi = dict(batch_info)
+        if "xyz" in bi and "poses" in bi:
+            if not self._is_frame_src(bi["xyz"]) or self.scene.frame_key is None:
+                fi = int(torch.as_tensor(frame_idx).reshape(-1)[0])
+                self._set_frame(bi, frame=fi)
+            bi["_dsn_scene"] = self.scene
+        return bi
+
     def render_rays(self, pts, rays, z_vals, frame_idx, net, transparent_mask=None, batch_info=None):
+        """can_render.py:97-134.  Differentiable w.r.t. the parameters in train mode (DualSpaceNeRF.forward's autograd node
+        + torch ops on its outputs would be the reference's graph; here compositing is dsn_composite, which carries no
+        graph - train through Renderer.render, whose single node covers the whole path)."""
+        if self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            raise RuntimeError("Renderer.render_rays / batchify_pts build no autograd graph in dsnerf_amd (compositing is one HIP "
+                               "kernel): train through Renderer.render, or call them under torch.no_grad() / in eval mode")
         pts, rays, z_vals = self._dev(pts), self._dev(rays), self._dev(z_vals)
         rays_d = rays[:, 0, :3].contiguous()
         B, sp = pts.shape[:2]
         noise = None
         if self.net.training and self.cfg.MODEL.raw_noise_std > 0.0:
             noise = (torch.randn(B, sp) * self.cfg.MODEL.raw_noise_std).to(self.device)
-        rgbs, density, _ = net(pts.reshape(-1, 6), rays.reshape(-1, 6), frame_idx, batch_info=batch_info)
+        bi = self._module_info(batch_info or {}, frame_idx)
+        with torch.no_grad():
+            rgbs, density, _ = net(pts.reshape(-1, 6), rays.reshape(-1, 6), frame_idx, batch_info=bi)
         tm = None if transparent_mask is None else transparent_mask.to(self.device).reshape(B, sp).to(torch.uint8).contiguous()
         rgb_map, disp_map, acc_map, weights, depth_map = _lib.composite(
             rgbs.reshape(B, sp, 3).contiguous(), density.reshape(B, sp).contiguous(), tm, z_vals, rays_d, noise)
@@ -287,23 +377,18 @@ class Renderer:
         near, far = self._dev(batch["near"][0]), self._dev(batch["far"][0])
         R = o.shape[0]
         S = self.cfg.MODEL.COARSE_RAY_SAMPLING
-        self._set_frame(batch)
-        self._frame_xyz_ptr = batch["xyz"].data_ptr()
+        frame_args = self._set_frame(batch)
         jitter, noise = self._draws(R, S)
         if self.sample_points_mode not in ("GG", "uniform"):
             raise Exception("error")   # the reference fails on unknown modes too (get_sampling_points returns nothing)
         uniform = self.sample_points_mode == "uniform"
         sd = dict(self.net.named_parameters())
         if self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in sd.values()):
-            frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
-            frame_args = (batch["xyz"][0], batch["poses"][0], frame) + tuple(self.net.frame_args(batch))
             outs = _RenderRays.apply(self, (o, d, near, far, S, jitter, noise, uniform, frame_args),
                                      *[sd[k] for k in _lib.PARAM_ORDER])
             out = dict(zip(_OUT_KEYS, outs))
         else:
-            out = _lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o, d, near, far, S, self._t_vals(S),
-                                   jitter, noise, skip_transparent=self.skip_transparent and not self.net.training,
-                                   uniform=uniform)
+            out = self._render_eval(self.scene, self._ws, o, d, near, far, S, jitter, noise)
         if batch["near"].is_cuda:   # in-place semantics of the reference when the batch already lives on the device
             batch["near"][0].copy_(near)
             batch["far"][0].copy_(far)
@@ -311,34 +396,72 @@ class Renderer:
         batch["face_idx"] = self.face_idx
         return {"coarse": out}
 
+    def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None):
+        skip = self.skip_transparent and not self.net.training
+        if screen is None:
+            screen = skip and noise is None and self._screen_usable()
+        return _lib.render_rays(scene, self.net.packed(self.device), ws, o, d, near, far, S, self._t_vals(S), jitter, noise,
+                                skip_transparent=skip, uniform=(self.sample_points_mode == "uniform"), screen=screen,
+                                audit=self.screen_audit)
+
+    def last_screen_audit(self, ws=None):
+        """(screen_audit = True) what the audit of the last eval frame found - synchronises.  dict(audited, violations,
+        max_sigma): `violations` audited samples (declared empty by the screen) have an accurate density > 0; they were rendered
+        correctly (audited samples take the accurate pass), but their un-audited peers were not, so the screen is switched off
+        for this renderer when it happens."""
+        ws = ws or self._ws
+        if ws.buf is None:
+            return None
+        c = ws.buf[:256].view(torch.int32).cpu()
+        res = {"audited": int(c[_lib.CNT_AUDIT]), "violations": int(c[_lib.CNT_AUDIT + 4]),
+               "max_sigma": float(c[_lib.CNT_AUDIT + 5:_lib.CNT_AUDIT + 6].view(torch.float32)[0])}
+        if res["violations"] > 0 and self.density_screen:
+            self.density_screen = False
+            warnings.warn("dsnerf_amd: the density screen dropped samples with positive density (%d of %d audited, max sigma %.3g): "
+                          "screen switched off" % (res["violations"], res["audited"], res["max_sigma"]))
+        return res
+
+    def range_overflow_count(self):
+        """train mode: samples of the last render() whose activations / adjoints left the fp16 range of the split-fp16 kernels
+        (there is no exact twin of the stored activations: a non-zero count means this step's gradients are not to be trusted;
+        synchronises)."""
+        if self._ws.buf is None:
+            return 0
+        return int(self._ws.buf[:256].view(torch.int32)[_lib.CNT_RANGE])
+
     # ---- whole-image path (reference :172-278) ----
-    def batchify_rays_view(self, ray_o, ray_d, near, far, batch, chunk=None):
+    def batchify_rays_view(self, ray_o, ray_d, near, far, batch, chunk=None, scene=None, ws=None):
+        scene = self.scene if scene is None else scene
+        ws = self._ws if ws is None else ws
         o, d = self._dev(ray_o[0]), self._dev(ray_d[0])
         n, f = self._dev(near[0]).clone(), self._dev(far[0]).clone()
         S = self.cfg.MODEL.COARSE_RAY_SAMPLING
-        self._set_frame(batch)
-        self._frame_xyz_ptr = batch["xyz"].data_ptr()
+        self._set_frame(batch, scene=scene)
         R = o.shape[0]
         chunk = R if chunk is None else int(chunk)
+        screen = None
+        if scene is not self.scene:      # calibration runs on the renderer's own scene (any frame state of these parameters)
+            screen = (self.skip_transparent and not self.net.training and self.density_screen
+                      and bool((self.net.packed(self.device).screen or {}).get("usable", False)))
         outs = []
         for i in range(0, R, chunk):
             j = min(R, i + chunk)
             jitter, noise = self._draws(j - i, S)
-            outs.append(_lib.render_rays(self.scene, self.net.packed(self.device), self._ws, o[i:j].contiguous(),
-                                         d[i:j].contiguous(), n[i:j].contiguous(), f[i:j].contiguous(), S,
-                                         self._t_vals(S), jitter, noise,
-                                         skip_transparent=self.skip_transparent and not self.net.training,
-                                         uniform=(self.sample_points_mode == "uniform")))
-        coarse = {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
+            outs.append(self._render_eval(scene, ws, o[i:j].contiguous(), d[i:j].contiguous(), n[i:j].contiguous(),
+                                          f[i:j].contiguous(), S, jitter, noise, screen=None if noise is not None else screen))
+        coarse = outs[0] if len(outs) == 1 else {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
         return coarse, {}
+
+    def _view_images(self, batch, chunk, scene, ws):
+        coarse, _ = self.batchify_rays_view(batch["ray_o"], batch["ray_d"], batch["near"], batch["far"], batch, chunk, scene, ws)
+        _, H, W, _ = batch["img"].shape
+        # utils/render_utils.py:466-472 post_process, done on the device (dsn_image_scatter)
+        return _lib.image_scatter(coarse, self._dev(batch["mask_at_box"][0], torch.uint8), H, W)
 
     def render_view(self, batch, chunk=None, device_output=False):
         """device_output=True (not in the reference) keeps the [H,W,*] images on the GPU - for multi-frame sequences
         (novel_pose_vis.py:41-66) and on-device metrics (`image_metrics`)."""
-        coarse, _ = self.batchify_rays_view(batch["ray_o"], batch["ray_d"], batch["near"], batch["far"], batch, chunk)
-        _, H, W, _ = batch["img"].shape
-        # utils/render_utils.py:466-472 post_process, done on the device (dsn_image_scatter)
-        img = _lib.image_scatter(coarse, self._dev(batch["mask_at_box"][0], torch.uint8), H, W)
+        img = self._view_images(batch, chunk, self.scene, self._ws)
         if device_output:
             return img
         # four contiguous device images -> four device->host copies (0.1-0.3 ms each).  Packing them into one [H,W,6] copy and
@@ -346,6 +469,53 @@ class Renderer:
         # (fresh host tensors like the reference's; on the GPU boxes first-touch page faults of new host memory make this step
         # vary between 1 and 20 ms per frame - `device_output=True` avoids it)
         return {k: img[k].contiguous().cpu() for k in ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")}
+
+    def render_views(self, batches, frames_in_flight=2, device_output=True, chunk=None):
+        """The per-frame loop of novel_pose_vis.py:41-66 / test.py:55-64 (`for batch in loader: render.render_view(batch)`) as
+        ONE call over an iterable of batches, with `frames_in_flight` frames on their own HIP streams (own scene blob and
+        workspace each): the per-frame setup, sampling and warp kernels of frame k+1 run beside the matrix-bound field kernels
+        of frame k.  Returns the list of render_view results in order - bit-identical to calling render_view per batch.
+        device_output=True keeps the images on the GPU (the D2H copies of host outputs are issued on each frame's stream and
+        overlap the next frames too)."""
+        n = max(1, int(frames_in_flight))
+        while len(self._slots) < n:
+            self._slots.append(_ViewSlot(self, own_scene=len(self._slots) > 0))
+        slots = self._slots[:n]
+        cur = torch.cuda.current_stream(self.device)
+        self.net.packed(self.device)                         # shared, read-only state is materialised on the caller's stream
+        self._t_vals(self.cfg.MODEL.COARSE_RAY_SAMPLING)
+        if not self.net.training and self.density_screen and self.skip_transparent:
+            batches = iter(batches)
+            first = next(batches, None)
+            if first is None:
+                return []
+            if self.net.packed(self.device).screen is None:     # calibrate on the first frame's state, on the caller's stream
+                self._set_frame(first)
+                self._screen_usable()
+            import itertools
+            batches = itertools.chain([first], batches)
+        results = []
+        keys = ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")
+        for k, batch in enumerate(batches):
+            slot = slots[k % n]
+            slot.stream.wait_stream(cur)
+            with torch.cuda.stream(slot.stream):
+                img = self._view_images(batch, chunk, slot.scene, slot.ws)
+                if not device_output:
+                    host = {kk: torch.empty(img[kk].shape, dtype=torch.float32).pin_memory() for kk in keys}
+                    for kk in keys:
+                        host[kk].copy_(img[kk], non_blocking=True)
+                    results.append(host)
+                else:
+                    for t in img.values():
+                        t.record_stream(cur)          # consumed on the caller's stream after the join below
+                    results.append(img)
+        for slot in slots:
+            cur.wait_stream(slot.stream)
+        if not device_output:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._frame_src = None      # slot 0 shares the renderer's scene: it now holds the last frame slot 0 rendered
+        return results
 
     def image_metrics(self, color_img, batch, clamp=True):
         """test.py:62-71 on the device: clamp to [0,1], psnr with and without mask_at_box against batch["img"].
@@ -360,8 +530,10 @@ class Renderer:
 
     # ---- density query for marching cubes (reference :280-296) ----
     def query_volume(self, pts, code_idx, transparent_mask=None, batch_info={}):
+        """batch_info needs only 'poses' (the density-only branch of the reference, model/spacenet.py:223-241)."""
         B, N = pts.shape[:2]
-        density = self.net(pts, None, code_idx, batch_info, density_only=True)
+        with torch.no_grad():
+            density = self.net(pts, None, code_idx, batch_info, density_only=True)
         if transparent_mask is not None:
             density[transparent_mask.to(density.device).reshape([-1, 1])] = 0
         return density.reshape(B, N, 1)

@@ -36,6 +36,7 @@ int dsn_pack_params(const float* const* params33_host, void* packed, void* strea
     DSN_REQUIRE(params33_host && packed, "dsn_pack_params: null argument");
     for (int i = 0; i < DSN_NUM_PARAMS; ++i) DSN_REQUIRE(params33_host[i], "dsn_pack_params: null parameter pointer");
     dsn_launch_pack_params(params33_host, (float*)packed, (hipStream_t)stream);
+    dsn_launch_set_screen_margin((float*)packed, DSN_SCREEN_MARGIN_DEFAULT, (hipStream_t)stream);   // until dsn_calibrate_screen has run
     return dsn_check_launch("dsn_pack_params");
 }
 
@@ -43,6 +44,7 @@ int dsn_pack_params(const float* const* params33_host, void* packed, void* strea
 int dsn_pack_params_host_image(const float* const* params33_host, float* packed_host) {
     DSN_REQUIRE(params33_host && packed_host, "dsn_pack_params_host_image: null argument");
     dsn_pack_params_host(params33_host, packed_host);
+    packed_host[OFF_SCAL + 5] = DSN_SCREEN_MARGIN_DEFAULT;
     return 0;
 }
 
@@ -80,6 +82,20 @@ int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xy
     dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2,
                           s.frame, st);
     return dsn_check_launch("dsn_set_frame");
+}
+
+size_t dsn_pose_state_bytes(void) { return dsn_pose_state_size(); }
+
+int dsn_set_pose(void* scene_or_pose_state, const void* packed, const float* poses24x3, const float* pose_feat16, int frame_idx,
+                 int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2, void* stream) {
+    DSN_REQUIRE(scene_or_pose_state && packed, "dsn_set_pose: null argument");
+    DSN_REQUIRE(poses24x3 || pose_feat16, "dsn_set_pose: give poses (batch['poses'], pose_mlp is applied) or the 16 pose features");
+    DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_set_pose: frame index outside the embedding table (maxFrame=500)");
+    // the per-frame state sits at the same offset in a scene blob and in a pose-only blob (dsn_common.h dsn_scene_view)
+    DsnFrameState* fs = (DsnFrameState*)((char*)scene_or_pose_state + 256);
+    dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2, fs,
+                          (hipStream_t)stream, pose_feat16);
+    return dsn_check_launch("dsn_set_pose");
 }
 
 int dsn_sample_gg(const void* scene, int V, int F, const float* ray_o, const float* ray_d, float* near, float* far, int R, int S,
@@ -132,13 +148,16 @@ int dsn_field(const void* scene, int V, int F, const void* packed, const float* 
     DSN_REQUIRE(scene && packed && x_c && sigma, "dsn_field: null argument");
     DSN_REQUIRE(N > 0, "dsn_field: empty point batch");
     DSN_REQUIRE((active_list == nullptr) == (active_count == nullptr), "dsn_field: active_list and active_count go together");
-    DSN_REQUIRE(V > 0 && F > 0, "dsn_field: bad V/F");
-    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    DSN_REQUIRE((V > 0 && F > 0) || (V == 0 && F == 0), "dsn_field: bad V/F (0/0 = pose-only state of dsn_pose_state_bytes())");
+    DsnSceneView s = dsn_scene_view((void*)scene, V > 0 ? V : 1, F > 0 ? F : 1);     // only s.frame is used (fixed offset)
     // split-fp16 kernel for the full evaluation; the exact-fp32 kernel serves density-only / colour-only queries
-    if (!(flags & DSN_FIELD_FP32) && essence && grad)
+    if (!(flags & DSN_FIELD_FP32) && essence && grad) {
         dsn_launch_field16((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
                            (hipStream_t)stream);
-    else
+        // range fallback: samples the split-fp16 kernel flagged (sigma = NaN) are re-evaluated in exact fp32
+        dsn_launch_field_fix((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
+                             (hipStream_t)stream);
+    } else
         dsn_launch_field((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, grad,
                          (hipStream_t)stream);
     return dsn_check_launch("dsn_field");
@@ -160,13 +179,51 @@ int dsn_field_forward(const void* scene, int V, int F, const void* packed, const
 }
 
 int dsn_field_reverse(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N, const int32_t* pos_list,
-                      const int32_t* pos_count, const void* records, float* grad, void* stream) {
-    DSN_REQUIRE(scene && packed && x_c && pos_list && pos_count && records && grad, "dsn_field_reverse: null argument");
+                      const int32_t* pos_count, const void* records, float* grad, float* sigma, float* essence, void* stream) {
+    DSN_REQUIRE(scene && packed && x_c && pos_list && pos_count && records && grad && sigma && essence, "dsn_field_reverse: null argument");
     DSN_REQUIRE(N > 0, "dsn_field_reverse: empty point batch");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_field_reverse: bad V/F");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    dsn_launch_field16_bwd((const float*)packed, s.frame, x_c, N, pos_list, pos_count, grad, records, (hipStream_t)stream);
+    dsn_launch_field16_bwd((const float*)packed, s.frame, x_c, N, pos_list, pos_count, grad, records, (hipStream_t)stream, sigma);
+    // range fallback for what dsn_field_forward or the reverse pass flagged (sigma = NaN): exact fp32, all three outputs
+    dsn_launch_field_fix((const float*)packed, s.frame, x_c, N, pos_list, pos_count, sigma, essence, grad, (hipStream_t)stream);
     return dsn_check_launch("dsn_field_reverse");
+}
+
+// model/spacenet.py:174-188 LightingMLP.forward as a pure function of its four arguments
+int dsn_light(const void* packed, const float* normal, const float* xyz_world, const float* view_dir_world,
+              const float* essence, int64_t N, float* colour, void* zero_pose_state, int flags, void* stream) {
+    DSN_REQUIRE(packed && normal && xyz_world && view_dir_world && essence && colour && zero_pose_state, "dsn_light: null argument");
+    DSN_REQUIRE(N > 0, "dsn_light: empty point batch");
+    hipStream_t st = (hipStream_t)stream;
+    // the lighting kernels read the light-centre / rotation edits from a frame state; those belong to DualSpaceNeRF.forward
+    // (:254-263), not to this function: run on a zeroed state
+    if (hipMemsetAsync(zero_pose_state, 0, dsn_pose_state_size(), st) != hipSuccess) return dsn_fail("%s", "dsn_light: memset failed");
+    const DsnFrameState* fs = (const DsnFrameState*)((const char*)zero_pose_state + 256);
+    if (flags & DSN_FIELD_FP32)
+        dsn_launch_light((const float*)packed, fs, normal, xyz_world, nullptr, view_dir_world, nullptr, essence, N, 1, nullptr, nullptr,
+                         colour, st);
+    else
+        dsn_launch_light16((const float*)packed, fs, normal, xyz_world, nullptr, view_dir_world, nullptr, essence, N, 1, nullptr,
+                           nullptr, colour, st);
+    return dsn_check_launch("dsn_light");
+}
+
+size_t dsn_calibrate_workspace_bytes(int64_t n_points) { return n_points > 0 ? dsn_calibrate_workspace_size(n_points) : 0; }
+
+int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t n_points, void* workspace, float* out4, void* stream) {
+    DSN_REQUIRE(scene && packed && workspace, "dsn_calibrate_screen: null argument");
+    DSN_REQUIRE(V > 0 && F > 0 && n_points > 0, "dsn_calibrate_screen: bad sizes");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    dsn_launch_calibrate_screen(s, (float*)packed, n_points, workspace, out4, (hipStream_t)stream);
+    return dsn_check_launch("dsn_calibrate_screen");
+}
+
+int dsn_set_screen_margin(void* packed, float margin, void* stream) {
+    DSN_REQUIRE(packed, "dsn_set_screen_margin: null argument");
+    DSN_REQUIRE(margin > 0.0f, "dsn_set_screen_margin: the margin must be positive (+inf = keep every sample)");
+    dsn_launch_set_screen_margin((float*)packed, margin, (hipStream_t)stream);
+    return dsn_check_launch("dsn_set_screen_margin");
 }
 
 int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
@@ -264,6 +321,26 @@ int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, co
     return dsn_check_launch("dsn_render_rays_grad");
 }
 
+// backward of DualSpaceNeRF.forward on explicit points (model/spacenet.py:210-266): see dsnerf.h
+int dsn_module_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
+                    int frame_idx, int zero_code, const float* x_world, const float* x_canon, const float* view_dir,
+                    const float* zeros_n, int64_t N, const float* d_colour, const float* d_sigma, float* const* grads33_host,
+                    void* workspace, void* stream) {
+    DSN_REQUIRE(scene && packed && params33_host && poses24x3 && x_world && x_canon && view_dir && zeros_n && d_colour && d_sigma &&
+                grads33_host && workspace, "dsn_module_grad: null argument");
+    DSN_REQUIRE(N > 0 && N < ((int64_t)1 << 30) && V > 0 && F > 0, "dsn_module_grad: bad sizes");
+    DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_module_grad: frame index outside the embedding table");
+    for (int i = 0; i < DSN_NUM_PARAMS; ++i)
+        DSN_REQUIRE(params33_host[i] && grads33_host[i], "dsn_module_grad: null parameter / gradient pointer");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    // N "rays" of ONE sample each: origin = the world point, direction = its view direction, z = 0
+    const char* err = dsn_train_run(s, (const float*)packed, params33_host, poses24x3, frame_idx, zero_code, x_world, view_dir, zeros_n,
+                                    nullptr, (int)N, 1, d_colour, nullptr, nullptr, nullptr, nullptr, grads33_host, workspace,
+                                    (hipStream_t)stream, false, x_canon, d_colour, d_sigma);
+    if (err) return dsn_fail("dsn_module_grad: %s failed", err);
+    return dsn_check_launch("dsn_module_grad");
+}
+
 // diagnostics (synchronises the stream): {ncell, ok, total, cap} of world-fine, world-coarse, canon-fine,
 // canon-coarse nearest-face levels -> out16_host
 int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream) {
@@ -282,10 +359,12 @@ int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, voi
 
 // utils/rays_utils.py:16-30 get_rays + :63-97 get_near_far, whole-image path (:176-184)
 int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
-                    float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream) {
+                    int convention, float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream) {
     DSN_REQUIRE(K3x3 && R3x3 && T3 && bounds2x3 && ray_o && ray_d && near && far && mask_at_box, "dsn_camera_rays: null argument");
     DSN_REQUIRE(H > 0 && W > 0, "dsn_camera_rays: empty image");
-    dsn_launch_camera_rays(K3x3, R3x3, T3, bounds2x3, H, W, ray_o, ray_d, near, far, mask_at_box, (hipStream_t)stream);
+    DSN_REQUIRE(convention == DSN_RAYS_ZJU || convention == DSN_RAYS_H36M, "dsn_camera_rays: unknown convention");
+    dsn_launch_camera_rays(K3x3, R3x3, T3, bounds2x3, H, W, ray_o, ray_d, near, far, mask_at_box, (hipStream_t)stream,
+                           convention == DSN_RAYS_H36M);
     return dsn_check_launch("dsn_camera_rays");
 }
 
@@ -307,8 +386,16 @@ struct DsnWorkspace {
     void* masks;          // [N] x 224 B relu-mask records
     void* nn_small;       // per-cell scratch of the cell-major nearest-face search
     int32_t* keep;        // [N]   samples the density screen could not rule out
+    int32_t* audit;       // [audit_cap] samples declared empty that DSN_SCREEN_AUDIT sends through the accurate pass anyway
+    int audit_cap;
     size_t bytes;
 };
+// words of DsnWorkspace::count (device, int32): diagnostics the host mirror reads after a frame
+#define DSN_CNT_ACTIVE 0      // non-transparent samples
+#define DSN_CNT_POS 16        // samples with sigma > 0 (reverse pass, normals, lighting)
+#define DSN_CNT_KEEP 32       // samples the density screen sent to the accurate pass
+#define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: samples audited, [44] of those with accurate sigma > 0, [45] their max sigma (float bits)
+#define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
     DsnWorkspace w;
     size_t N = (size_t)R * S;
@@ -327,6 +414,8 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.masks = (void*)p;           p += dsn_align256(224 * N);
     w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
     w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
+    w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
+    w.audit = (int32_t*)p;        p += dsn_align256(4 * (size_t)w.audit_cap);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -384,21 +473,29 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     else if (skip) {
         // eval mode: forward for every non-transparent sample, then d sigma/dx, normals and lighting only where sigma > 0
         // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
-        int32_t* pcnt = w.count + 16;
-        if (!(flags & DSN_NO_SCREEN)) {
+        int32_t* pcnt = w.count + DSN_CNT_POS;
+        const bool screen = !(flags & DSN_NO_SCREEN);
+        const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
+        if (screen) {
             // plain-fp16 screen: samples whose fp16 density is negative by the safety margin keep that (negative) density and leave the
             // list; count[32] = samples that go through the accurate pass
-            int32_t* kcnt = w.count + 32;
-            dsn_launch_screen16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.keep, kcnt, nullptr, nullptr, st);
+            int32_t* kcnt = w.count + DSN_CNT_KEEP;
+            dsn_launch_screen16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.keep, kcnt, nullptr, nullptr, st,
+                                audit ? w.audit : nullptr, audit ? w.count + DSN_CNT_AUDIT : nullptr, w.audit_cap);
             list = w.keep;
             cnt = kcnt;
         }
         dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st);
-        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st);
+        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma);
         list = w.pos;
         cnt = pcnt;
-    } else
+        // range fallback: whatever either pass flagged (sigma = NaN; such samples are on the sigma > 0 list) in exact fp32
+        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+        if (audit) dsn_launch_screen_audit(w.audit, w.count + DSN_CNT_AUDIT, w.audit_cap, w.sigma, w.count + DSN_CNT_AUDIT + 4, st);
+    } else {
         dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+    }
     dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
     if (flags & DSN_FIELD_FP32)
         dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
@@ -428,7 +525,11 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
-    dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st);
+    // (train mode has no exact-fp32 twin of the stored activations: samples outside the fp16 range are counted in count[48],
+    //  which the host mirror checks - Renderer.range_overflow_count())
+    if (hipMemsetAsync(w.count, 0, 256, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays_train: memset failed");
+    dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st,
+                             w.count + DSN_CNT_RANGE);
     dsn_launch_normal(s, c.x_c, c.grad, N, nullptr, nullptr, c.idx_c, c.n_w, exh, st);
     dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, nullptr, nullptr, w.colour, st,
                        c.hl1, c.hl2, c.pre);

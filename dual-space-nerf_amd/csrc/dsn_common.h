@@ -34,7 +34,7 @@ struct DsnFrameState {   // small per-frame vectors
     float rot[4];
     float rot_center[2];
     float has_rot;
-    float pad[29];
+    float pad[29];       // (keeps bias0 256-byte aligned inside the struct)
     float bias0[256];    // stage1.0 bias with the 24 constant input columns (code, pose) folded in
 };
 
@@ -61,6 +61,9 @@ __host__ __device__ inline DsnSceneView dsn_scene_view(void* base, int V, int F)
     // header: V, F stored for sanity checks
     s.V = V; s.F = F;
     p += 256;
+    // the per-frame state comes FIRST: a "pose-only" blob (dsn_pose_state_bytes(): header + this struct, no body model)
+    // is a valid prefix of a scene, so density-only / stand-alone network queries need no mesh (dsn_set_pose, dsn_field V=F=0)
+    s.frame = (DsnFrameState*)p;    p += dsn_align256(sizeof(DsnFrameState));
     s.canon = (float*)p;            p += dsn_align256(sizeof(float) * 3 * (size_t)V);
     s.faces = (int32_t*)p;          p += dsn_align256(sizeof(int32_t) * 3 * (size_t)F);
     s.xyz = (float*)p;              p += dsn_align256(sizeof(float) * 3 * (size_t)V);
@@ -68,11 +71,11 @@ __host__ __device__ inline DsnSceneView dsn_scene_view(void* base, int V, int F)
     s.cent_canon = (float4*)p;      p += dsn_align256(sizeof(float4) * (size_t)F);
     s.face_world = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
     s.face_canon = (DsnFaceRec*)p;  p += dsn_align256(sizeof(DsnFaceRec) * (size_t)F);
-    s.frame = (DsnFrameState*)p;    p += dsn_align256(sizeof(DsnFrameState));
     s.nn_world = dsn_nn_view(p, F);
     s.nn_canon = dsn_nn_view(p, F);
     return s;
 }
+__host__ __device__ inline size_t dsn_pose_state_size() { return 256 + dsn_align256(sizeof(DsnFrameState)); }
 __host__ __device__ inline size_t dsn_scene_size(int V, int F) {
     return 256 + 2 * dsn_align256(sizeof(float) * 3 * (size_t)V) + dsn_align256(sizeof(int32_t) * 3 * (size_t)F) +
            2 * dsn_align256(sizeof(float4) * (size_t)F) + 2 * dsn_align256(sizeof(DsnFaceRec) * (size_t)F) +
@@ -208,7 +211,8 @@ enum {
     OFF_BLT0 = OFF_WRGB3 + 3 * 128,        // lighting biases 128, 128
     OFF_BLT1 = OFF_BLT0 + 128,
     OFF_WLT2 = OFF_BLT1 + 128,             // lights_encoding.4 weight in C-layout order : 128
-    OFF_SCAL = OFF_WLT2 + 128,             // [0]=density bias, [1..3]=rgb3 bias, [4]=lights_encoding.4 bias
+    OFF_SCAL = OFF_WLT2 + 128,             // [0]=density bias, [1..3]=rgb3 bias, [4]=lights_encoding.4 bias,
+                                           // [5]=margin of the density screen (default / dsn_calibrate_screen, k_screen16)
     // raw (unpacked) copies used by the per-frame setup kernel
     OFF_RAW_W0 = OFF_SCAL + 64,            // stage1.0.weight [256,87]
     OFF_RAW_B0 = OFF_RAW_W0 + 256 * 87,    // stage1.0.bias [256]
@@ -235,6 +239,7 @@ __host__ __device__ inline size_t dsn_stream16_index(int gb, int hw) {
     if (gb >= DSN_STREAM_BLOCKS) return (size_t)gb * 2048 + hw;
     return (size_t)(gb >> 3) * 16384 + (size_t)(hw >> 9) * 4096 + (size_t)(gb & 7) * 512 + (hw & 511);
 }
+#define DSN_SCREEN_MARGIN_DEFAULT 0.01f          // conservative margin of the density screen until it has been calibrated
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
 #define DSN_LO_INV (1.0f / 4096.0f)
 

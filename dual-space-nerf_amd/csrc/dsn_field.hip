@@ -277,7 +277,10 @@ __device__ __forceinline__ void dsn_layer_bwd(DsnWStream& ws, const f32x16 (&in)
 __global__ void __launch_bounds__(FIELD_THREADS, 1)
 k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
         int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
+        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
+    // fix_nan != 0: the range fallback of the split-fp16 kernels (dsn_field16.hip).  A sample whose activations left the
+    // fp16 range there carries sigma = NaN; this launch re-evaluates exactly those samples (waves without one leave at
+    // once, the other lanes of a wave with one compute but do not write) - sigma, essence and d sigma/dx in exact fp32.
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -285,9 +288,14 @@ k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, 
     const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
     if (slot0 >= count) return;   // wave-uniform
     int64_t slot = slot0 + (lane & 31);
-    const bool valid = slot < count;
+    bool valid = slot < count;
     if (!valid) slot = count - 1;
     const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
+    if (fix_nan) {
+        const float s = sigma[pt];
+        valid = valid && (s != s);
+        if (!__any(valid)) return;   // wave-uniform
+    }
     const float x0 = x_c[3 * pt], x1 = x_c[3 * pt + 1], x2 = x_c[3 * pt + 2];
 
     // ---- positional encoding as 32 k-steps (2 register blocks): low lanes sin / x / z, high lanes cos / y / 0
@@ -434,7 +442,16 @@ void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float*
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad);
+                       active_count, sigma, essence, grad, 0);
+}
+// range fallback of the split-fp16 kernels: exact-fp32 re-evaluation of the listed samples whose sigma is NaN
+void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                          const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                          float* grad, hipStream_t st) {
+    int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_field, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
+                       active_count, sigma, essence, grad, 1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -9,7 +9,10 @@
 // reference this is as accurate as the reference's own float32 run (tests/test_gpu_field16.py;
 // sigma 6e-6 abs).  Plain bf16 / fp16 inputs miss the 1e-4 bar by 10x, bf16 2-way split by 1.4x.
 // Range: the reverse pass runs on g * 2^-6 (exact rescale at the end) so that |g| up to 4e6 stays
-// inside fp16; forward activations must stay below 65504 (they are O(10) for NeRF trunks).
+// inside fp16; forward activations must stay below 65504 (they are O(10) for NeRF trunks).  Every epilogue keeps a
+// running maximum of the values it splits (one v_max3 per two elements); a sample that reaches F16_RANGE anywhere is
+// FLAGGED: its sigma is written as NaN and the exact-fp32 kernel re-evaluates it (dsn_launch_field_fix, dsn_field.hip) -
+// checkpoints whose activations or adjoints leave the fp16 range render correctly, only slower (tests/test_gpu_range.py).
 //
 // Structure.  Same transposed formulation and register chaining as k_field (dsn_field.hip): one
 // wavefront owns 32 points, the accumulator layout of the 32x32 MFMA is re-used as the next
@@ -50,6 +53,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define F16_CHUNK 8              // blocks per ring barrier; the ring holds two chunks (fixed: the DMA immediates span one chunk)
 #define F16_RING_SLOTS (2 * F16_CHUNK)
 #define F16_NCHUNK (DSN_STREAM_BLOCKS / F16_CHUNK)   // 109
+#define F16_RANGE 65000.0f                           // |value| an epilogue may hand to the fp16 split (fp16 max 65504)
 #define F16_GSCALE 0.015625f                         // reverse pass runs on g / 64
 #define F16_GUNSCALE 64.0f
 
@@ -233,6 +237,13 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
     for (int r = 0; r < 16; ++r) a[r] = dsn_keep_active(a[r], m, r);
 }
 
+// running maximum of |v| over everything a lane splits into fp16 operands (range guard, see the header)
+__device__ __forceinline__ void track16(float& ovf, const f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) ovf = fmaxf(fmaxf(ovf, fabsf(v[r])), fabsf(v[r + 1]));
+}
+__device__ __forceinline__ float dsn_nan_flag() { return __uint_as_float(0x7fc00000u); }
+
 // Deferred epilogue, two accumulator registers at a time.  With one wave per SIMD nothing else can cover the VALU
 // work of an epilogue (fold, relu / mask, hi-lo split, pack: ~12 instructions per element), so the epilogue of output
 // block m-1 is cut into 8 slices of two elements and slice kb is issued right behind the MFMAs of block (m, kb):
@@ -241,7 +252,7 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 // ([N,256] fp32 per layer: point row, features 32 m + 8 (r >> 2) + 4 half + (r & 3)), times `stscale`.
 template <bool FWD, bool ST = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
-                                          half8 (&yh)[2], half8 (&yl)[2], float* st = nullptr, float stscale = 1.0f) {
+                                          half8 (&yh)[2], half8 (&yl)[2], float& ovf, float* st = nullptr, float stscale = 1.0f) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -259,6 +270,7 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
     }
+    ovf = FWD ? fmaxf(fmaxf(ovf, vv[0]), vv[1]) : fmaxf(fmaxf(ovf, fabsf(vv[0])), fabsf(vv[1]));   // v_max3_f32 (relu output >= 0)
     // Training stores.  The chunk boundary (w16_boundary: s_waitcnt vmcnt(0) for the LDS-DMA pieces) also waits for every
     // store in flight, and it sits right in front of slice 7 (blocks per output tile = blocks per chunk).  Stores issued slice
     // by slice were 1-3 blocks old at that wait and cost a full write latency per chunk (3.84 ms vs 2.34 ms without stores);
@@ -290,7 +302,7 @@ __device__ __forceinline__ void store16(float* st, const f32x16& v, float stscal
 template <bool ST = false>
 __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const float* __restrict__ bias,
                                             const half8 (&xh)[8][2], const half8 (&xl)[8][2], half8 (&yh)[8][2],
-                                            half8 (&yl)[8][2], uint32_t (&mk)[4], float* st = nullptr) {
+                                            half8 (&yl)[8][2], uint32_t (&mk)[4], float& ovf, float* st = nullptr) {
     const int half = lane >> 5;
     f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
@@ -298,14 +310,14 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr); });
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr);
+        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
@@ -313,7 +325,7 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
 template <bool ST = false>
 __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const half8 (&xh)[8][2],
                                             const half8 (&xl)[8][2], half8 (&yh)[8][2], half8 (&yl)[8][2],
-                                            const uint32_t (&mk)[4], float* st = nullptr, float stscale = F16_GUNSCALE) {
+                                            const uint32_t (&mk)[4], float& ovf, float* st = nullptr, float stscale = F16_GUNSCALE) {
     f32x16 pM = zero16(), pC = zero16();
     uint32_t dummy = 0;
 #pragma unroll
@@ -321,12 +333,12 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], (ST && st) ? st + 32 * 7 : nullptr, stscale);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr, stscale);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
@@ -392,6 +404,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #define MK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
     uint32_t mk[4];
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
+    float ovf = 0.0f;          // range guard: running max of |value| over everything this lane splits into fp16
     // per-sample mask record: [half][layer] uint4, 224 B contiguous per sample
     uint4* const mrec = masks ? masks + ((size_t)pt * 2 + half) * 7 : nullptr;
     // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
@@ -431,12 +444,13 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         if (ST) store16(th ? th + 0 * tr_ls + 32 * m : nullptr, v, 1.0f);
+        track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(0, mk)
-    layer16_fwd<ST>(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk, th ? th + 1 * tr_ls : nullptr); MK_STORE(1, mk)
-    layer16_fwd<ST>(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk, th ? th + 2 * tr_ls : nullptr); MK_STORE(2, mk)
-    layer16_fwd<ST>(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk, th ? th + 3 * tr_ls : nullptr); MK_STORE(3, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk, ovf, th ? th + 1 * tr_ls : nullptr); MK_STORE(1, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk, ovf, th ? th + 2 * tr_ls : nullptr); MK_STORE(2, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk, ovf, th ? th + 3 * tr_ls : nullptr); MK_STORE(3, mk)
     // stage2.0 : [h, pe] -> 256
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -452,10 +466,11 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
         if (ST) store16(th ? th + 4 * tr_ls + 32 * m : nullptr, v, 1.0f);
+        track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
     MK_STORE(4, mk)
-    layer16_fwd<ST>(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk, th ? th + 5 * tr_ls : nullptr); MK_STORE(5, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk, ovf, th ? th + 5 * tr_ls : nullptr); MK_STORE(5, mk)
     // stage2.4 with the density head and the seed of the reverse pass fused into its epilogue
     float sg_part = 0.0f;
 #pragma unroll
@@ -469,11 +484,14 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
+        track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
     sg_part += __shfl_xor(sg_part, 32);
     const float sg = sg_part + v_scal[0];
-    if (valid && half == 0) sigma[pt] = sg;
+    // range guard, forward half: a flagged sample carries sigma = NaN until the exact-fp32 kernel has re-evaluated it
+    const bool flag_fwd = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
+    if (valid && half == 0) sigma[pt] = flag_fwd ? dsn_nan_flag() : sg;
     if (MODE == F16_FWD || MODE == F16_TRAIN) {
         // masks of all 7 layers -> the sample's record (read back by k_field16<reverse> / k_tangent16)
         MK_STORE(6, mk)
@@ -484,8 +502,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         }
     }
     if (MODE == F16_FWD) {
-        // samples with positive density -> the reverse-pass list
-        const bool pos = valid && half == 0 && sg > 0.0f;
+        // samples with positive density -> the reverse-pass list (flagged samples too: the fallback behind the reverse pass
+        // walks this list, and whatever it finds their density to be, a normal and a colour for them cost nothing but time)
+        const bool pos = valid && half == 0 && (sg > 0.0f || flag_fwd);
         const unsigned long long bm = __ballot(pos);
         const int cnt = __popcll(bm);
         int base = 0;
@@ -545,8 +564,8 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         if (ST) store16(ta ? ta + 6 * tr_ls + 32 * m : nullptr, g, F16_GUNSCALE);
         split16<true>(g, ah[m], al[m]);
     }
-    MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 5 * tr_ls : nullptr);
-    MK_LOAD(4, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 4 * tr_ls : nullptr);
+    MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 5 * tr_ls : nullptr);
+    MK_LOAD(4, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 4 * tr_ls : nullptr);
     MK_LOAD(3, mk)
     // stage2.0^T : 256 -> [256 h | 64 pe]
     f32x16 dpe[2];
@@ -557,6 +576,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = fold16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
         if (ST) store16(ta ? ta + 3 * tr_ls + 32 * m : nullptr, v, F16_GUNSCALE);
+        track16(ovf, v);
         split16<true>(v, bh[m], bl[m]);
     }
 #pragma unroll
@@ -565,9 +585,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         dpe[b] = fold16(aM, aC);
     }
-    MK_LOAD(2, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 2 * tr_ls : nullptr);
-    MK_LOAD(1, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 1 * tr_ls : nullptr);
-    MK_LOAD(0, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 0 * tr_ls : nullptr);
+    MK_LOAD(2, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 2 * tr_ls : nullptr);
+    MK_LOAD(1, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 1 * tr_ls : nullptr);
+    MK_LOAD(0, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 0 * tr_ls : nullptr);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x16 aM = zero16(), aC = zero16();
@@ -600,6 +620,12 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
             grad[3 * pt] = g[0] * F16_GUNSCALE; grad[3 * pt + 1] = g[1] * F16_GUNSCALE; grad[3 * pt + 2] = g[2] * F16_GUNSCALE;
         }
     }
+    // range guard, reverse half (ovf still holds the forward maximum in the single-launch modes)
+    const bool flagged = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
+    if (flagged && valid && half == 0) {
+        if (MODE == F16_TRAIN) { if (pos_count) atomicAdd(pos_count, 1); }    // training: counted, reported by the host mirror
+        else sigma[pt] = dsn_nan_flag();
+    }
 }
 
 void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -614,12 +640,14 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
 // training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
-                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st) {
+                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st,
+                              int32_t* range_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
+    // range_count (optional): incremented once per sample whose activations / adjoints left the fp16 range
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
-                       (int32_t*)nullptr, tr_h, tr_a, tr_rr);
+                       range_count, tr_h, tr_a, tr_rr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -634,11 +662,12 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
 // ... reverse pass on the sigma > 0 samples only
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st) {
+                            hipStream_t st, float* sigma) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
+    // sigma: only ever WRITTEN here, with the NaN flag of a sample whose adjoints left the fp16 range (see the header)
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
-                       pos_list, pos_count, (float*)nullptr, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
+                       pos_list, pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
                        (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
 }
 
@@ -848,8 +877,9 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
     float* const ta = valid ? tr_a + pt * 256 + 4 * half : nullptr;
 #define AMK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
     uint32_t mk[4];
-    AMK_LOAD(5, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 5 * ls : nullptr, sc);
-    AMK_LOAD(4, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 4 * ls : nullptr, sc);
+    float ovf_unused = 0.0f;   // (every sample runs on seed / max|seed|: the range guard of k_field16 is not needed here)
+    AMK_LOAD(5, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf_unused, ta ? ta + 5 * ls : nullptr, sc);
+    AMK_LOAD(4, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 4 * ls : nullptr, sc);
     AMK_LOAD(3, mk)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {       // stage2.0^T, h part
@@ -865,9 +895,9 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
         f32x16 aM = zero16(), aC = zero16();
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
     }
-    AMK_LOAD(2, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 2 * ls : nullptr, sc);
-    AMK_LOAD(1, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ta ? ta + 1 * ls : nullptr, sc);
-    AMK_LOAD(0, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ta ? ta + 0 * ls : nullptr, sc);
+    AMK_LOAD(2, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 2 * ls : nullptr, sc);
+    AMK_LOAD(1, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf_unused, ta ? ta + 1 * ls : nullptr, sc);
+    AMK_LOAD(0, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 0 * ls : nullptr, sc);
 #undef AMK_LOAD
 }
 
@@ -896,12 +926,8 @@ void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, con
 #ifndef F16_SCREEN_ACC
 #define F16_SCREEN_ACC 1
 #endif
-#ifndef F16_SCREEN_REL
-#define F16_SCREEN_REL 0.01f
-#endif
-#ifndef F16_SCREEN_ABS
-#define F16_SCREEN_ABS 0.01f
-#endif
+#define F16_SCREEN_REL DSN_SCREEN_MARGIN_DEFAULT
+#define F16_SCREEN_ABS DSN_SCREEN_MARGIN_DEFAULT
 #define F16_SCREEN_BLOCKS (OFF_RGB1 / DSN_BLK)       // 416: stage1.0 ... stage2.4
 
 // hi quarters only: quarter q = 0 (k-step 0) and 2 (k-step 1) of every block; the 16 pieces of a chunk are shared out as
@@ -1006,7 +1032,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
            const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
            int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
-           float* __restrict__ dbg_s1, float margin) {
+           float* __restrict__ dbg_s1, float margin_override, int32_t* __restrict__ audit_list, int32_t* __restrict__ audit_count,
+           int audit_cap) {
     __shared__ __attribute__((aligned(16))) char ring[2 * 16384];
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
     __shared__ __attribute__((aligned(16))) half8 s_pe[4][64 * NW];
@@ -1097,13 +1124,28 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     sg += bd;
     s1 += fabsf(bd);
     const bool mine = valid && half == 0;
-    const bool empty = sg < -(margin * s1 + margin);      // margin = F16_SCREEN_REL = F16_SCREEN_ABS unless DSN_SCREEN_MARGIN overrides
+    // margin: packed[OFF_SCAL + 5] - the conservative default written by dsn_pack_params (F16_SCREEN_REL) or the value
+    // dsn_calibrate_screen measured for THESE parameters (10x the largest deviation seen, +inf = never declare anything
+    // empty); DSN_SCREEN_MARGIN (experiments) overrides it
+    const float margin = margin_override > 0.0f ? margin_override : s_vec[2560 + 5];
+    const bool empty = sg < -(margin * s1 + margin);
     if (mine) {
         if (empty) sigma[pt] = sg;
         if (dbg_sigma) { dbg_sigma[pt] = sg; dbg_s1[pt] = s1; }
     }
+    // audit (DSN_SCREEN_AUDIT): a pseudo-random 1/128 of the samples declared empty go through the accurate pass anyway
+    // and are remembered; k_screen_audit then counts those whose accurate density is positive (there must be none)
+    bool audit = false;
+    if (audit_list && mine && empty) {
+        uint32_t hsh = (uint32_t)pt * 2654435761u;
+        hsh ^= hsh >> 15;
+        if ((hsh & 127u) == 5u) {
+            const int a = atomicAdd(audit_count, 1);
+            if (a < audit_cap) { audit_list[a] = (int32_t)pt; audit = true; }
+        }
+    }
     // the others go to the accurate pass: workgroup-aggregated append
-    const bool keep = mine && !empty;
+    const bool keep = mine && (!empty || audit);
     const unsigned long long bm = __ballot(keep);
     if (lane == 0) s_cnt[wave] = __popcll(bm);
     __syncthreads();
@@ -1123,18 +1165,94 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
 
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
-                         float* dbg_s1, hipStream_t st) {
+                         float* dbg_s1, hipStream_t st, int32_t* audit_list, int32_t* audit_count, int audit_cap) {
     if (N == 0) return;
     static const bool four = getenv("DSN_SCREEN_WAVES") && atoi(getenv("DSN_SCREEN_WAVES")) == 4;
-    // tuning / experiment switch: the relative and absolute safety margin of the empty test (default 0.01)
-    static const float margin = getenv("DSN_SCREEN_MARGIN") ? (float)atof(getenv("DSN_SCREEN_MARGIN")) : F16_SCREEN_REL;
-    static_assert(F16_SCREEN_REL == F16_SCREEN_ABS, "one margin constant");
+    // experiment switch: overrides the margin the packed parameters carry (default / calibrated, see k_screen16)
+    static const float margin = getenv("DSN_SCREEN_MARGIN") ? (float)atof(getenv("DSN_SCREEN_MARGIN")) : 0.0f;
     if (four)
         hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, st, packed, fs, x_c, N, active_list,
-                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin);
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
     else
         hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)((N + 255) / 256)), dim3(512), 0, st, packed, fs, x_c, N, active_list,
-                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin);
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
+}
+
+// DSN_SCREEN_AUDIT: out[0] += number of audited samples (declared empty by the screen, evaluated by the accurate pass anyway)
+// whose accurate density is > 0; out[1] = max over them of that density (float bits; positive floats order like their bits)
+__global__ void __launch_bounds__(256) k_screen_audit(const int32_t* __restrict__ audit_list, const int32_t* __restrict__ audit_count,
+                                                      int audit_cap, const float* __restrict__ sigma, int32_t* __restrict__ out) {
+    const int n = min(*audit_count, audit_cap);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float s = sigma[audit_list[i]];
+        if (s > 0.0f) { atomicAdd(out, 1); atomicMax(out + 1, __float_as_int(s)); }
+    }
+}
+void dsn_launch_screen_audit(const int32_t* audit_list, const int32_t* audit_count, int audit_cap, const float* sigma, int32_t* out,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(k_screen_audit, dim3(64), dim3(256), 0, st, audit_list, audit_count, audit_cap, sigma, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dsn_calibrate_screen: the screen's margin for THESE parameters.  n points around the canonical surface (face centroid +
+// a hash offset within +-0.15 m: where the canonical points of non-transparent samples lie, |h| <= 0.1), the screen's
+// sigma~ and S1 and the exact-fp32 density for each; d = max |sigma~ - sigma| / (S1 + 1) over the finite ones is the
+// largest margin any of them would have needed (a sample is wrongly dropped iff sigma > 0 and sigma~ < -m (S1 + 1)).
+// margin = 10 d, at least F16_SCREEN_FLOOR; above F16_SCREEN_CAP the screen is useless for this network: margin = +inf.
+// ---------------------------------------------------------------------------------------------
+#define F16_SCREEN_FLOOR 0.002f
+#define F16_SCREEN_CAP 0.05f
+__global__ void __launch_bounds__(256) k_calib_points(const float4* __restrict__ cent, int F, int64_t n, float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = cent[(int)(i % F)];
+    uint32_t h = (uint32_t)i * 2654435761u + 0x9e3779b9u;
+    float o[3];
+    for (int k = 0; k < 3; ++k) {
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        o[k] = ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.3f;
+    }
+    x[3 * i] = c.x + o[0]; x[3 * i + 1] = c.y + o[1]; x[3 * i + 2] = c.z + o[2];
+}
+__global__ void __launch_bounds__(256) k_calib_reduce(const float* __restrict__ sg, const float* __restrict__ s1,
+                                                      const float* __restrict__ sig, int64_t n, uint32_t* __restrict__ acc) {
+    float d = 0.0f;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = sg[i], b = s1[i], c = sig[i];
+        const float q = fabsf(a - c) / (b + 1.0f);
+        if (q == q && fabsf(q) < INFINITY) d = fmaxf(d, q); else ++bad;     // fp16 overflow inside the screen: sample is kept anyway
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { d = fmaxf(d, __shfl_xor(d, o)); bad += __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(acc, __float_as_uint(d)); atomicAdd(acc + 1, (uint32_t)bad); }
+}
+__global__ void k_calib_finish(const uint32_t* __restrict__ acc, float* __restrict__ packed_margin, float* __restrict__ out4, float n) {
+    const float d = __uint_as_float(acc[0]);
+    float m = fmaxf(10.0f * d, F16_SCREEN_FLOOR);
+    if (!(m <= F16_SCREEN_CAP)) m = INFINITY;
+    *packed_margin = m;
+    if (out4) { out4[0] = d; out4[1] = m; out4[2] = (float)acc[1] / n; out4[3] = n; }
+}
+size_t dsn_calibrate_workspace_size(int64_t n) { return 256 + dsn_align256(12 * (size_t)n) + 4 * dsn_align256(4 * (size_t)n); }
+void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st) {
+    char* p = (char*)workspace;
+    uint32_t* acc = (uint32_t*)p;             p += 256;
+    float* x = (float*)p;                     p += dsn_align256(12 * (size_t)n);
+    float* sg = (float*)p;                    p += dsn_align256(4 * (size_t)n);
+    float* s1 = (float*)p;                    p += dsn_align256(4 * (size_t)n);
+    float* sig = (float*)p;                   p += dsn_align256(4 * (size_t)n);
+    int32_t* lst = (int32_t*)p;
+    (void)hipMemsetAsync(acc, 0, 256, st);
+    hipLaunchKernelGGL(k_calib_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.cent_canon, s.F, n, x);
+    dsn_launch_screen16(packed, s.frame, x, n, nullptr, nullptr, sg, lst, (int32_t*)(acc + 8), sg, s1, st, nullptr, nullptr, 0);
+    dsn_launch_field(packed, s.frame, x, n, nullptr, nullptr, sig, nullptr, nullptr, st);
+    hipLaunchKernelGGL(k_calib_reduce, dim3(1024), dim3(256), 0, st, sg, s1, sig, n, acc);
+    hipLaunchKernelGGL(k_calib_finish, dim3(1), dim3(1), 0, st, acc, packed + OFF_SCAL + 5, out4, (float)n);
+}
+__global__ void k_set_scalar(float* p, float v) { *p = v; }
+void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, packed + OFF_SCAL + 5, margin);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,11 +36,13 @@ void dsn_launch_face_setup(const float* verts, const int32_t* faces, int F, DsnF
 __global__ void __launch_bounds__(256) k_pose_setup(const float* __restrict__ packed, const float* __restrict__ poses,
                                                      int frame_idx, int zero_code, const float* __restrict__ light_shift,
                                                      const float* __restrict__ rot, const float* __restrict__ rot_center,
-                                                     DsnFrameState* __restrict__ fs) {
+                                                     DsnFrameState* __restrict__ fs, const float* __restrict__ pose_feat16) {
+    // pose_feat16 (optional): the 16 pose features given explicitly (SpaceNet.forward's pose_feats argument,
+    // model/spacenet.py:93-131) instead of batch_rod2quat + pose_mlp on `poses` (DualSpaceNeRF.forward :223-236)
     __shared__ float q[92];
     __shared__ float h1[64], h2[64], feat[16], code[8];
     int t = threadIdx.x;
-    if (t < 23) {
+    if (t < 23 && !pose_feat16) {
         const float* r = poses + 3 * (t + 1);
         float a[3] = {r[0] + 1e-16f, r[1] + 1e-16f, r[2] + 1e-16f};
         float angle = dsn_norm3(a);
@@ -53,14 +55,14 @@ __global__ void __launch_bounds__(256) k_pose_setup(const float* __restrict__ pa
     }
     if (t < 8) code[t] = zero_code ? 0.0f : packed[OFF_RAW_EMB + frame_idx * 8 + t];
     __syncthreads();
-    if (t < 64) {
+    if (t < 64 && !pose_feat16) {
         float acc = packed[OFF_RAW_PM0B + t];
         const float* w = packed + OFF_RAW_PM0W + t * 92;
         for (int k = 0; k < 92; ++k) acc += w[k] * q[k];
         h1[t] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    if (t < 64) {
+    if (t < 64 && !pose_feat16) {
         float acc = packed[OFF_RAW_PM2B + t];
         const float* w = packed + OFF_RAW_PM2W + t * 64;
         for (int k = 0; k < 64; ++k) acc += w[k] * h1[k];
@@ -68,9 +70,13 @@ __global__ void __launch_bounds__(256) k_pose_setup(const float* __restrict__ pa
     }
     __syncthreads();
     if (t < 16) {
-        float acc = packed[OFF_RAW_PM4B + t];
-        const float* w = packed + OFF_RAW_PM4W + t * 64;
-        for (int k = 0; k < 64; ++k) acc += w[k] * h2[k];
+        float acc;
+        if (pose_feat16) acc = pose_feat16[t];
+        else {
+            acc = packed[OFF_RAW_PM4B + t];
+            const float* w = packed + OFF_RAW_PM4W + t * 64;
+            for (int k = 0; k < 64; ++k) acc += w[k] * h2[k];
+        }
         feat[t] = acc;
         fs->pose_feat[t] = acc;
     }
@@ -94,9 +100,9 @@ __global__ void __launch_bounds__(256) k_pose_setup(const float* __restrict__ pa
 
 void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_idx, int zero_code,
                            const float* light_shift, const float* rot, const float* rot_center, DsnFrameState* fs,
-                           hipStream_t st) {
+                           hipStream_t st, const float* pose_feat16) {
     hipLaunchKernelGGL(k_pose_setup, dim3(1), dim3(256), 0, st, packed, poses, frame_idx, zero_code, light_shift, rot,
-                       rot_center, fs);
+                       rot_center, fs, pose_feat16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,8 +788,61 @@ __global__ void __launch_bounds__(256) k_camera_rays(const double* __restrict__ 
     far[p] = m ? (float)fmax(d0, d1) : 0.0f;
 }
 
+// Human3.6M convention (utils/h36m_utils.py:14-28 get_rays, :61-76 get_near_far, composed by get_rays_within_bounds
+// :162-176 / the test split of sample_ray_h36m :147-157): the direction is NORMALISED in float64 before the cast to
+// float32 (:26), and the box test is the float32 slab test on the unit direction with the reference's +-1e-5 clamp of
+// near-zero components (:64-66), against the FIRST ray's origin (ray_o[:1], :67-68) and the UNPADDED float32 bounds;
+// near / far are divided by the float32 norm of the (already unit) direction (:74-75).  All of get_near_far is float32
+// numpy: one rounding per operation, kept here (-ffp-contract=off).
+__global__ void __launch_bounds__(256) k_camera_rays_h36m(const double* __restrict__ K, const double* __restrict__ Rm,
+                                                           const double* __restrict__ T, const double* __restrict__ bounds,
+                                                           int H, int W, float* __restrict__ ray_o, float* __restrict__ ray_d,
+                                                           float* __restrict__ near, float* __restrict__ far,
+                                                           uint8_t* __restrict__ mask_at_box) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const double k00 = K[0], k01 = K[1], k02 = K[2], k10 = K[3], k11 = K[4], k12 = K[5], k20 = K[6], k21 = K[7], k22 = K[8];
+    const double det = k00 * (k11 * k22 - k12 * k21) - k01 * (k10 * k22 - k12 * k20) + k02 * (k10 * k21 - k11 * k20);
+    const double id = 1.0 / det;
+    const double Ki[9] = {(k11 * k22 - k12 * k21) * id, (k02 * k21 - k01 * k22) * id, (k01 * k12 - k02 * k11) * id,
+                          (k12 * k20 - k10 * k22) * id, (k00 * k22 - k02 * k20) * id, (k02 * k10 - k00 * k12) * id,
+                          (k10 * k21 - k11 * k20) * id, (k01 * k20 - k00 * k21) * id, (k00 * k11 - k01 * k10) * id};
+    double o[3];
+    for (int c = 0; c < 3; ++c) o[c] = -(Rm[0 * 3 + c] * T[0] + Rm[1 * 3 + c] * T[1] + Rm[2 * 3 + c] * T[2]);
+    const double i = (double)(float)(p % W), j = (double)(float)(p / W);
+    double pc[3], pw[3], dd[3];
+    for (int c = 0; c < 3; ++c) pc[c] = i * Ki[c * 3 + 0] + j * Ki[c * 3 + 1] + Ki[c * 3 + 2];
+    for (int c = 0; c < 3; ++c)
+        pw[c] = (pc[0] - T[0]) * Rm[0 * 3 + c] + (pc[1] - T[1]) * Rm[1 * 3 + c] + (pc[2] - T[2]) * Rm[2 * 3 + c];
+    for (int c = 0; c < 3; ++c) dd[c] = pw[c] - o[c];
+    const double nd = sqrt((dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]);       // np.linalg.norm(axis=2) in float64 (:26)
+    float of[3], df[3];
+    for (int c = 0; c < 3; ++c) { of[c] = (float)o[c]; df[c] = (float)(dd[c] / nd); }
+    for (int c = 0; c < 3; ++c) { ray_o[3 * p + c] = of[c]; ray_d[3 * p + c] = df[c]; }
+    // get_near_far (:61-76), float32 throughout
+    const float nrm = sqrtf((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);
+    float tn = -INFINITY, tf = INFINITY;
+    for (int c = 0; c < 3; ++c) {
+        float v = dsn_div(df[c], nrm);
+        if (v < 1e-5f && v > -1e-10f) v = 1e-5f;          // the two clamps in the reference's order (:65-66)
+        if (v > -1e-5f && v < 1e-10f) v = -1e-5f;
+        const float bmin = (float)bounds[c], bmax = (float)bounds[3 + c];
+        const float a = dsn_div(bmin - of[c], v), b = dsn_div(bmax - of[c], v);   // ray_o[:1]: every ray shares the camera origin
+        tn = fmaxf(tn, fminf(a, b));
+        tf = fminf(tf, fmaxf(a, b));
+    }
+    const bool m = tn < tf;
+    mask_at_box[p] = m ? 1 : 0;
+    near[p] = m ? dsn_div(tn, nrm) : 0.0f;
+    far[p] = m ? dsn_div(tf, nrm) : 0.0f;
+}
+
 void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
-                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st) {
-    hipLaunchKernelGGL(k_camera_rays, dim3((H * W + 255) / 256), dim3(256), 0, st, K, R, T, bounds, H, W, ray_o, ray_d,
-                       near, far, mask);
+                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st, int h36m) {
+    if (h36m)
+        hipLaunchKernelGGL(k_camera_rays_h36m, dim3((H * W + 255) / 256), dim3(256), 0, st, K, R, T, bounds, H, W, ray_o, ray_d,
+                           near, far, mask);
+    else
+        hipLaunchKernelGGL(k_camera_rays, dim3((H * W + 255) / 256), dim3(256), 0, st, K, R, T, bounds, H, W, ray_o, ray_d,
+                           near, far, mask);
 }

@@ -6,7 +6,7 @@ void dsn_launch_face_setup(const float* verts, const int32_t* faces, int F, DsnF
                            hipStream_t st);
 void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_idx, int zero_code,
                            const float* light_shift, const float* rot, const float* rot_center, DsnFrameState* fs,
-                           hipStream_t st);
+                           hipStream_t st, const float* pose_feat16 = nullptr);
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
                           hipStream_t st);
@@ -33,22 +33,32 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
                             void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st);
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st);
+                            hipStream_t st, float* sigma);
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
-                         float* dbg_s1, hipStream_t st);
+                         float* dbg_s1, hipStream_t st, int32_t* audit_list = nullptr, int32_t* audit_count = nullptr,
+                         int audit_cap = 0);
+void dsn_launch_screen_audit(const int32_t* audit_list, const int32_t* audit_count, int audit_cap, const float* sigma, int32_t* out,
+                             hipStream_t st);
+size_t dsn_calibrate_workspace_size(int64_t n);
+void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st);
+void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st);
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                         int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st,
                         float* tr_hl1 = nullptr, float* tr_hl2 = nullptr, float* tr_pre = nullptr);
 void dsn_launch_camera_rays(const double* K, const double* R, const double* T, const double* bounds, int H, int W,
-                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
+                            float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st, int h36m = 0);
 // dsn_field.hip
 void dsn_pack_params_host(const float* const* params33_host, float* packed_host);
 void dsn_launch_pack_params(const float* const* params33_dev_array, float* packed, hipStream_t st);
 void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                       const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                       float* grad, hipStream_t st);
+// exact-fp32 re-evaluation of the listed samples whose sigma is NaN (range fallback of the split-fp16 kernels)
+void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
+                          const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
+                          float* grad, hipStream_t st);
 void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                         const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                         float* grad, hipStream_t st);
@@ -65,7 +75,8 @@ struct DsnTrainCache {
 };
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
-                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st);
+                              float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st,
+                              int32_t* range_count = nullptr);
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
                           hipStream_t st);
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
@@ -74,7 +85,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
-                          const float* d_weights, float* const* grads33, void* workspace, hipStream_t st, bool cached = false);
+                          const float* d_weights, float* const* grads33, void* workspace, hipStream_t st, bool cached = false,
+                          const float* ext_x_c = nullptr, const float* ext_d_col = nullptr, const float* ext_d_sig = nullptr);
 
 // dsn_image.hip: image epilogue on the device (post_process scatter, clamp, mse / psnr)
 size_t dsn_image_workspace_size(int H, int W);

@@ -1139,7 +1139,13 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
-                          const float* d_weights, float* const* grd, void* workspace, hipStream_t st, bool cached) {
+                          const float* d_weights, float* const* grd, void* workspace, hipStream_t st, bool cached,
+                          const float* ext_x_c, const float* ext_d_col, const float* ext_d_sig) {
+    // ext_* (all three or none): "module" mode, the backward of DualSpaceNeRF.forward (model/spacenet.py:210-266) on explicit
+    // points - canonical points ext_x_c [N,3] instead of the warp of the rays' samples, and the per-sample cotangents of
+    // (colour, density) ext_d_col [N,3] / ext_d_sig [N] instead of the adjoint of compositing.  The caller passes S = 1,
+    // ray_o = world points, ray_d = view directions, z_vals = zeros (x_w = o + d * 0 exactly).
+    const bool module = ext_x_c != nullptr;
     const int64_t N64 = (int64_t)R * S;
     if (N64 > (int64_t)1 << 30) return "batch too large for the 32-bit GEMM interface";
     const int N = (int)N64;
@@ -1155,7 +1161,9 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
 
     // ---- forward: warp, encoding, trunk, heads ------------------------------------------------------------
     // (skipped when dsn_render_rays_train has just left all of it in this workspace)
-    if (!cached)
+    if (module) {
+        if (hipMemcpyAsync(w.x_c, ext_x_c, sizeof(float) * 3 * (size_t)N64, hipMemcpyDeviceToDevice, st) != hipSuccess) return "x_c copy";
+    } else if (!cached)
         dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
                         nullptr, false, st);
     hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe);
@@ -1179,9 +1187,12 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
 
     // ---- adjoint of compositing and of the colour product ------------------------------------------------------
-    hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
-                       noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig);
-    hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, w.d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
+    if (!module)
+        hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
+                           noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig);
+    const float* const d_col = module ? ext_d_col : w.d_col;
+    const float* const d_sig = module ? ext_d_sig : w.d_sig;
+    hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
                        w.d_pre);
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
@@ -1221,9 +1232,9 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                        w.d_rr);
     T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B]));
-    wcolsum<1>(w.h[6], 256, w.d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
+    wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
     T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
-    hipLaunchKernelGGL(k_t_seed, grid_for((tot) / 4), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], w.d_sig, cur, 256, tot, cur);
+    hipLaunchKernelGGL(k_t_seed, grid_for((tot) / 4), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], d_sig, cur, 256, tot, cur);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;

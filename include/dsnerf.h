@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 1
+#define DSN_ABI_VERSION 2
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -62,6 +62,18 @@ DSN_EXPORT int dsn_set_body(void* scene, const float* canon_vertex, const int32_
 DSN_EXPORT int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
                   int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
                   void* stream);
+
+/* Pose-only state: what a density-only query needs of a frame (DualSpaceNeRF.forward(density_only=True),
+ * model/spacenet.py:223-241, used by Renderer.query_volume can_render.py:280-296 with a batch_info that holds only
+ * 'poses') and what the stand-alone SpaceNet.forward(pos, rays, idx, density_only, pose_feats) consumes
+ * (model/spacenet.py:93-131): embedding row `frame_idx` (zeroed when zero_code), the 16 pose features - either computed
+ * from poses24x3 by batch_rod2quat + pose_mlp, or given explicitly as pose_feat16 (the pose_feats argument; one of the
+ * two must be non-NULL, pose_feat16 wins) - and the light / rotation edits.  The target is a scene blob (its mesh is left
+ * untouched) or a blob of dsn_pose_state_bytes() bytes, which dsn_field accepts with V = F = 0. */
+DSN_EXPORT size_t dsn_pose_state_bytes(void);
+DSN_EXPORT int dsn_set_pose(void* scene_or_pose_state, const void* packed, const float* poses24x3, const float* pose_feat16,
+                 int frame_idx, int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
+                 void* stream);
 
 /* ---- stage kernels -----------------------------------------------------------------------*/
 /* utils/pts_utils.py:18-58 geometry_guided_ray_marching + :3-16 uniform_sampling.
@@ -110,7 +122,19 @@ DSN_EXPORT int dsn_field_forward(const void* scene, int V, int F, const void* pa
                       const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                       void* records, int32_t* pos_list, int32_t* pos_count, void* stream);
 DSN_EXPORT int dsn_field_reverse(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
-                      const int32_t* pos_list, const int32_t* pos_count, const void* records, float* grad, void* stream);
+                      const int32_t* pos_list, const int32_t* pos_count, const void* records, float* grad, float* sigma,
+                      float* essence, void* stream);
+/* Range of the split-fp16 kernels.  Activations (|h| < 65000) and adjoints (|d sigma/dh| < 4e6) must fit fp16; every
+ * split-fp16 kernel watches the values it splits, and a sample that leaves the range is FLAGGED: dsn_field_forward leaves
+ * sigma = NaN for it and puts it on pos_list, dsn_field_reverse (which is why it takes sigma / essence, the arrays
+ * dsn_field_forward wrote) and dsn_field / dsn_render_rays re-evaluate flagged samples with the exact-fp32 kernel before
+ * they return.  Results for such samples are the exact-fp32 kernel's (DSN_FIELD_FP32), bit for bit. */
+
+/* model/spacenet.py:174-188 LightingMLP.forward(normal, xyz_world, view_dir_world, essence_feature) as a pure function:
+ * colour [N,3] = (ELU(lights_encoding([normal, xyz_world, view / |view|])) + 1) * essence.  All inputs [N,3] per point.
+ * zero_pose_state: scratch of dsn_pose_state_bytes() bytes (cleared here).  flags: DSN_FIELD_FP32. */
+DSN_EXPORT int dsn_light(const void* packed, const float* normal, const float* xyz_world, const float* view_dir_world,
+              const float* essence, int64_t N, float* colour, void* zero_pose_state, int flags, void* stream);
 
 /* model/spacenet.py:278-298 normal_local2world + :254-265 + :174-188 LightingMLP.forward.
  * x_w = world sample points [N,3], ray_d [N/S,3]; outputs face_idx_canon [N], n_w [N,3],
@@ -131,8 +155,11 @@ DSN_EXPORT int dsn_composite(const float* colour, const float* sigma, const uint
  * K, R [3,3], T [3], bounds [2,3] (min xyz; max xyz) are float64 DEVICE arrays (the reference's numpy dtype).
  * Outputs for all H*W pixels (row-major): ray_o, ray_d [H*W,3], near, far [H*W] (0 where the ray does not cross the
  * box exactly twice), mask_at_box [H*W].  The caller compacts with the mask like the reference does (:181-183). */
+#define DSN_RAYS_ZJU 0   /* utils/rays_utils.py:16-30,63-97: un-normalised directions, padded box, "exactly two faces" test in float64 */
+#define DSN_RAYS_H36M 1  /* utils/h36m_utils.py:14-28,61-76 (get_rays_within_bounds :162-176): unit directions (normalised in
+                          * float64), float32 slab test on the unpadded bounds with the +-1e-5 direction clamp */
 DSN_EXPORT int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
-                    float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream);
+                    int convention, float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream);
 
 /* ---- image epilogue on the device ----------------------------------------------------------
  * utils/render_utils.py:466-472 post_process: row k of the compacted per-ray outputs (rgb [R,3], disp/acc/depth [R],
@@ -155,6 +182,17 @@ DSN_EXPORT int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const 
 DSN_EXPORT int dsn_field_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
                      const int32_t* active_list, const int32_t* active_count, float* sigma, int32_t* keep_list,
                      int32_t* keep_count, void* stream);
+
+/* The screen's margin is a property of the PARAMETERS and travels in `packed`: dsn_pack_params writes the conservative default
+ * (0.01); dsn_calibrate_screen measures it for the packed parameters and the scene's current frame state - n_points points
+ * around the canonical surface, screen vs exact-fp32 density, margin = max(10 x the largest deviation |sigma~ - sigma| /
+ * (S1 + 1), 0.002), or +inf (nothing is ever declared empty) when that exceeds 0.05 - and writes it into `packed`, all on the
+ * stream.  out4 (device, optional) = {largest deviation, margin, fraction of points the screen overflowed on, n_points}.
+ * dsn_set_screen_margin sets it by hand.  workspace: dsn_calibrate_workspace_bytes(n_points). */
+DSN_EXPORT size_t dsn_calibrate_workspace_bytes(int64_t n_points);
+DSN_EXPORT int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t n_points, void* workspace, float* out4,
+                         void* stream);
+DSN_EXPORT int dsn_set_screen_margin(void* packed, float margin, void* stream);
 
 /* diagnostics of the density screen: the plain-fp16 density sigma~ [N] and the magnitude S1 [N] of its terms for
  * every point (no lists, nothing skipped) - lets tests measure the margin against dsn_field's sigma. */
@@ -187,6 +225,17 @@ DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void*
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
                          int flags, void* stream);
 
+/* Backward of DualSpaceNeRF.forward(pos[N,6], rays[N,6], frame_idx, batch_info) (model/spacenet.py:210-266) on explicit
+ * points, what autograd computes when a caller differentiates (colour, density) w.r.t. the parameters (can_render.py:97-134
+ * render_rays / batchify_pts in train mode): x_world = pos[:, :3], x_canon = pos[:, 3:], view_dir = rays[:, :3],
+ * d_colour [N,3] / d_sigma [N] the cotangents of the two outputs, zeros_n = N zero floats (device).  The scene holds the
+ * frame (dsn_set_frame with the same parameters).  Every gradient is overwritten; inputs receive no gradient (they are
+ * data in the reference too).  workspace: dsn_grad_workspace_bytes(N, 1). */
+DSN_EXPORT int dsn_module_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host,
+                    const float* poses24x3, int frame_idx, int zero_code, const float* x_world, const float* x_canon,
+                    const float* view_dir, const float* zeros_n, int64_t N, const float* d_colour, const float* d_sigma,
+                    float* const* grads33_host, void* workspace, void* stream);
+
 /* ---- fused path: can_render.py:137-168 Renderer.render on R rays --------------------------
  * flags: DSN_SKIP_TRANSPARENT evaluates the networks only on non-transparent samples (exact in
  * eval mode: their sigma is forced to 0 and their colour is multiplied by weight 0; must not be
@@ -206,6 +255,11 @@ DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void*
  * plain-fp16 pass of the trunk and sends only the samples whose fp16 density is not negative by a safety margin - sigma~ >= -(1 % of the
  * magnitude of its terms + 0.01) - through the accurate pass; the others contribute exactly zero either way. */
 #define DSN_NO_SCREEN 16
+/* audit of the density screen: a pseudo-random 1/128 of the samples it declares empty go through the accurate pass anyway
+ * (the frame stays exact); afterwards int32 word 40 of `workspace` holds how many were audited, word 44 how many of those have
+ * an accurate density > 0 (must be 0: such a sample would have been dropped wrongly) and word 45 the largest such density
+ * (float bits). */
+#define DSN_SCREEN_AUDIT 32
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
@@ -217,8 +271,9 @@ DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* pack
 DSN_EXPORT int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream);
 
 /* diagnostics: after a DSN_SKIP_TRANSPARENT render, int32 word 0 of `workspace` holds the number of non-transparent
- * samples (field forward evaluated) and word 16 the number of those with sigma > 0 (d sigma/dx, normal and lighting
- * evaluated) - device memory. */
+ * samples, word 32 the number the density screen sent to the accurate pass (field forward evaluated) and word 16 the number
+ * of those with sigma > 0 (d sigma/dx, normal and lighting evaluated); after dsn_render_rays_train word 48 holds the number of
+ * samples whose activations left the fp16 range (train mode has no exact fallback: must be 0) - device memory. */
 #ifdef __cplusplus
 }
 #endif

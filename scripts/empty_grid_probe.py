@@ -27,5 +27,5 @@ def timed(fn, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 print("empty forward grid  %.3f ms" % timed(lambda: L.dsn_field_forward(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(ess), _lib._ptr(rec), _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream())))
-print("empty reverse grid  %.3f ms" % timed(lambda: L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g), _lib._stream())))
+print("empty reverse grid  %.3f ms" % timed(lambda: L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(pcnt), _lib._ptr(rec), _lib._ptr(g), _lib._ptr(sig), _lib._ptr(ess), _lib._stream())))
 print("empty screen grid   %.3f ms" % timed(lambda: L.dsn_field_screen(*a0, _lib._ptr(lst), _lib._ptr(cnt), _lib._ptr(sig), _lib._ptr(pos), _lib._ptr(pcnt), _lib._stream())))

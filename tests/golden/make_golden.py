@@ -86,9 +86,45 @@ def stage_case(name, canon, faces, xyz, poses, rays, sel, S, state, train=False,
     return out
 
 
+def weight_set(tag):
+    """"" = the hash-generated default (synth.make_state_dict()), "w2" = trained by the real reference
+    (make_weights_w2.py -> weights_w2.npz), "w3" = hash-generated with a large init gain (|sigma| ~ 1e3, activations ~ 1e2)."""
+    if tag == "":
+        return synth.make_state_dict()
+    if tag == "w2":
+        z = np.load(os.path.join(HERE, "weights_w2.npz"))
+        return {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    if tag == "w3":
+        return synth.make_state_dict(seed=7, gain=3.5)
+    raise ValueError(tag)
+
+
+def other_weight_sets():
+    """the stage / end-to-end cases again on the trained (w2) and the large-magnitude (w3) parameters (VERDICT r01 weak #1)"""
+    import torch
+
+    torch.set_num_threads(8)
+    poses = synth.make_poses()
+    canon_s, faces_s = synth.make_small_body()
+    xyz_s = synth.pose_body(canon_s)
+    rays_s = synth.make_rays(8, 8, xyz_s, cam_dist=2.2, focal_frac=2.0)
+    sel_s = np.arange(64)
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(64, 64, xyz)
+    for tag, nfull in (("w2", 192), ("w3", 96)):
+        state = weight_set(tag)
+        stage_case("small_eval_" + tag, canon_s, faces_s, xyz_s, poses, rays_s, sel_s, 16, state)
+        stage_case("small_train_" + tag, canon_s, faces_s, xyz_s, poses, rays_s, sel_s, 16, state, train=True)
+        sel = np.arange(0, 4096, 16)[32:32 + nfull]
+        stage_case("full_eval_" + tag, canon, faces, xyz, poses, rays, sel, 64, state)
+
+
 def main():
     import torch
 
+    if "--other-weights" in sys.argv:
+        return other_weight_sets()
     torch.set_num_threads(8)
     state = synth.make_state_dict()
     poses = synth.make_poses()

@@ -6,20 +6,48 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CASES = ["small_eval", "small_train", "small_novel", "small_rot", "full_eval"]
+# the same stage / end-to-end cases on two more parameter sets (tests/golden/make_golden.py --other-weights):
+#   _w2: TRAINED by the real reference (tests/golden/make_weights_w2.py; weights_w2.npz) - larger, non-uniform layer scales
+#   _w3: hash-generated with init gain 3.5 - |sigma| ~ 1e3, |d sigma/dx| ~ 2e5, activations ~ 1e2
+W_CASES = ["small_eval_w2", "small_train_w2", "full_eval_w2", "small_eval_w3", "small_train_w3", "full_eval_w3"]
+ALL_CASES = CASES + W_CASES
 
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def state():
+_STATE = {}
+
+
+def state(name=None):
+    """the 33 parameters a golden case was generated with (by case name; default set when the name carries no tag)"""
     import dsnerf_amd.synth as synth
-    return synth.make_state_dict()
+    tag = "w2" if name and "_w2" in name else ("w3" if name and "_w3" in name else "")
+    if tag not in _STATE:
+        if tag == "w2":
+            z = np.load(os.path.join(GOLDEN, "weights_w2.npz"))
+            _STATE[tag] = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+        elif tag == "w3":
+            _STATE[tag] = synth.make_state_dict(seed=7, gain=3.5)
+        else:
+            _STATE[tag] = synth.make_state_dict()
+    return _STATE[tag]
+
+
+def ref_tol(g, key, base, rel=4e-6):
+    """absolute tolerance on array `key` of a golden case: `base` (the bar: 1e-4 on sigma / RGB), or `rel` x the largest
+    magnitude in the array where float32 itself is coarser than the bar.  rel = 4e-6: two independent float32
+    implementations of the network (the reference and the C oracle, same inputs) differ by 0.3e-6 .. 1.4e-6 of max |sigma|
+    on all three parameter sets (measured: sigma 8e-6 at |sigma| <= 9, 2.7e-5 at 64, 1.5e-3 at 1400) - the float32-vs-float64
+    companions of the fixtures are NOT a usable floor here, they differ in the canonical points themselves."""
+    m = float(np.abs(g[key]).max())
+    return base if m <= 100.0 else max(base, rel * m)     # the bar itself wherever the magnitudes leave float32 room for it
 
 
 def code_for(g, sd, name):
     c = sd["nerf.embedding.weight"][int(g["frame"])]
-    return c * 0 if name == "small_novel" else c   # test.py:193-196 sets net.nerf.w = 0
+    return c * 0 if name.startswith("small_novel") else c   # test.py:193-196 sets net.nerf.w = 0
 
 
 def light_kw(g):

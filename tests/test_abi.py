@@ -30,7 +30,9 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.dsn_abi_version() == 1
+    assert lib.dsn_abi_version() == 2
+    assert lib.dsn_pose_state_bytes() >= 256 + 4 * (64 + 256)          # header + DsnFrameState
+    assert lib.dsn_calibrate_workspace_bytes(C.c_int64(1 << 20)) >= (1 << 20) * 28
     assert lib.dsn_packed_param_bytes() > 3_000_000            # fwd + transposed images of ~0.5 M params
     assert lib.dsn_scene_bytes(6890, 13776) > 13776 * (64 * 2 + 16 * 2)
     assert lib.dsn_scene_bytes(0, 0) == 0
@@ -60,9 +62,14 @@ def test_every_entry_point_rejects_null_arguments(lib):
         "dsn_field": lambda: lib.dsn_field(z, 1, 1, z, z, i64(0), z, z, z, z, z, 0, z),
         "dsn_field_screen": lambda: lib.dsn_field_screen(z, 1, 1, z, z, i64(0), z, z, z, z, z, z),
         "dsn_field_forward": lambda: lib.dsn_field_forward(z, 1, 1, z, z, i64(0), z, z, z, z, z, z, z, z),
-        "dsn_field_reverse": lambda: lib.dsn_field_reverse(z, 1, 1, z, z, i64(0), z, z, z, z, z),
+        "dsn_field_reverse": lambda: lib.dsn_field_reverse(z, 1, 1, z, z, i64(0), z, z, z, z, z, z, z),
         "dsn_shade": lambda: lib.dsn_shade(z, 1, 1, z, z, z, z, z, z, i64(0), 1, z, z, z, z, z, 0, z),
-        "dsn_camera_rays": lambda: lib.dsn_camera_rays(z, z, z, z, 0, 0, z, z, z, z, z, z),
+        "dsn_camera_rays": lambda: lib.dsn_camera_rays(z, z, z, z, 0, 0, 0, z, z, z, z, z, z),
+        "dsn_set_pose": lambda: lib.dsn_set_pose(z, z, z, z, 0, 0, z, z, z, z),
+        "dsn_light": lambda: lib.dsn_light(z, z, z, z, z, i64(0), z, z, 0, z),
+        "dsn_calibrate_screen": lambda: lib.dsn_calibrate_screen(z, 1, 1, z, i64(0), z, z, z),
+        "dsn_set_screen_margin": lambda: lib.dsn_set_screen_margin(z, C.c_float(0.01), z),
+        "dsn_module_grad": lambda: lib.dsn_module_grad(z, 1, 1, z, z, z, 0, 0, z, z, z, z, i64(0), z, z, z, z, z),
         "dsn_image_scatter": lambda: lib.dsn_image_scatter(z, z, z, z, 1, z, 0, 0, 0, z, z, z, z, z, z),
         "dsn_image_psnr": lambda: lib.dsn_image_psnr(z, z, z, z, 0, 0, z, z, z),
         "dsn_render_rays_grad": lambda: lib.dsn_render_rays_grad(z, 1, 1, z, z, z, 0, 0, z, z, z, z, 0, 0, z, z, z, z, z, z, z, 0, z),

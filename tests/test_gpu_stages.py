@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import oracle as O
-from helpers import CASES, code_for, light_kw, load, maxdiff, per_point_dirs, state
+from helpers import ALL_CASES, CASES, code_for, light_kw, load, maxdiff, per_point_dirs, ref_tol, state
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,19 @@ def ctx():
     dev = torch.device("cuda:0")
     sd = state()
     packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
-    return dict(lib=_lib, dev=dev, sd=sd, packed=packed, P=O.Params(sd), scenes={})
+    return dict(lib=_lib, dev=dev, sd=sd, packed=packed, P=O.Params(sd), scenes={}, sets={})
+
+
+def W(ctx, name):
+    """parameters of the weight set a golden case was generated with: dict(sd, packed, P) (default set: ctx's own)"""
+    sd = state(name)
+    if sd is ctx["sd"] or sd is state():
+        return ctx
+    key = id(sd)
+    if key not in ctx["sets"]:
+        packed = ctx["lib"].PackedParams(ctx["dev"]).update({k: torch.from_numpy(v) for k, v in sd.items()})
+        ctx["sets"][key] = dict(sd=sd, packed=packed, P=O.Params(sd))
+    return ctx["sets"][key]
 
 
 def scene_for(ctx, g, name):
@@ -26,8 +38,8 @@ def scene_for(ctx, g, name):
     sc = _lib.Scene(torch.from_numpy(g["canonical_vertex"]), torch.from_numpy(g["faces"].astype(np.int64)), dev)
     kw = light_kw(g)
     t = lambda k: (torch.from_numpy(np.ascontiguousarray(kw[k])) if k in kw else None)
-    sc.set_frame(ctx["packed"], torch.from_numpy(g["xyz"]), torch.from_numpy(g["poses"]), int(g["frame"]),
-                 zero_code=(name == "small_novel"), light_shift=t("light_shift"), rot=t("rot"), rot_center=t("rot_center"))
+    sc.set_frame(W(ctx, name)["packed"], torch.from_numpy(g["xyz"]), torch.from_numpy(g["poses"]), int(g["frame"]),
+                 zero_code=name.startswith("small_novel"), light_shift=t("light_shift"), rot=t("rot"), rot_center=t("rot_center"))
     return sc
 
 
@@ -44,7 +56,7 @@ def test_packed_image_matches_host_twin(ctx):
     assert np.array_equal(got, buf)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_sampler(ctx, name):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
@@ -59,7 +71,7 @@ def test_sampler(ctx, name):
 
 
 @pytest.mark.parametrize("exhaustive", [False, True])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_warp(ctx, name, exhaustive):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
@@ -80,18 +92,20 @@ def test_warp(ctx, name, exhaustive):
 
 
 @pytest.mark.parametrize("fp32", [False, True])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_field(ctx, name, fp32):
     """fp32=False: default split-fp16 MFMA kernel (k_field16); fp32=True: exact-fp32 MFMA kernel (k_field).
     Both must meet the same bounds against the reference."""
     g = load(name)
     dev = ctx["dev"]
     sc = scene_for(ctx, g, name)
-    sig, ess, gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=fp32)
+    w = W(ctx, name)
+    sig, ess, gr = ctx["lib"].field(sc, w["packed"], T(g["x_c"], dev), fp32=fp32)
     sig, ess, gr = sig.cpu().numpy(), ess.cpu().numpy(), gr.cpu().numpy()
-    # vs the reference's own float32 outputs (north_star: 1e-4 abs on sigma / RGB)
-    assert maxdiff(sig, g["sigma"]) < 1e-4
-    assert maxdiff(ess, g["essence"]) < 1e-4
+    # vs the reference's own float32 outputs (north_star: 1e-4 abs on sigma / RGB; for the large-magnitude parameter sets,
+    # where float32 itself is coarser than that, 3x the reference's own float32-vs-float64 distance: helpers.ref_tol)
+    assert maxdiff(sig, g["sigma"]) < ref_tol(g, "sigma", 1e-4), (maxdiff(sig, g["sigma"]), ref_tol(g, "sigma", 1e-4))
+    assert maxdiff(ess, g["essence"]) < ref_tol(g, "essence", 1e-4), (maxdiff(ess, g["essence"]), ref_tol(g, "essence", 1e-4))
     # d sigma/dx is ill-conditioned (encoding x512, ReLU kinks: a pre-activation within rounding of 0 flips a
     # whole mask and moves the gradient discretely - the reference's own float32/float64 runs disagree the same
     # way), so it is judged per point, relative, with a small outlier budget instead of a max-abs bound.
@@ -104,12 +118,12 @@ def test_field(ctx, name, fp32):
     # and no further from the float64 reference than the float32 reference is (x1.5 slack)
     assert maxdiff(sig, g["sigma_f64"]) <= 1.5 * maxdiff(g["sigma"], g["sigma_f64"]) + 1e-5
     # vs the oracle on the same inputs
-    osig, oess, ogr = O.field(g["x_c"], ctx["P"], code_for(g, ctx["sd"], name), g["pose_feat"][0])
-    assert maxdiff(sig, osig) < 1e-4 and maxdiff(ess, oess) < 1e-5
+    osig, oess, ogr = O.field(g["x_c"], w["P"], code_for(g, w["sd"], name), g["pose_feat"][0])
+    assert maxdiff(sig, osig) < ref_tol(g, "sigma", 1e-4) and maxdiff(ess, oess) < ref_tol(g, "essence", 1e-5)
 
 
 @pytest.mark.parametrize("fp32", [False, True])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_field_active_list(ctx, name, fp32):
     """compacted evaluation == dense evaluation on the listed points, untouched elsewhere"""
     g = load(name)
@@ -122,8 +136,8 @@ def test_field_active_list(ctx, name, fp32):
     lst[:len(act)] = T(act, dev)
     cnt = torch.zeros(64, dtype=torch.int32, device=dev)
     cnt[0] = len(act)
-    d_sig, d_ess, d_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), fp32=fp32)
-    a_sig, a_ess, a_gr = ctx["lib"].field(sc, ctx["packed"], T(g["x_c"], dev), active=(lst, cnt), fp32=fp32)
+    d_sig, d_ess, d_gr = ctx["lib"].field(sc, W(ctx, name)["packed"], T(g["x_c"], dev), fp32=fp32)
+    a_sig, a_ess, a_gr = ctx["lib"].field(sc, W(ctx, name)["packed"], T(g["x_c"], dev), active=(lst, cnt), fp32=fp32)
     m = torch.zeros_like(d_sig, dtype=torch.bool)
     m[T(act.astype(np.int64), dev)] = True
     assert torch.equal(a_sig[m], d_sig[m]) and torch.equal(a_ess[m], d_ess[m]) and torch.equal(a_gr[m], d_gr[m])
@@ -131,7 +145,7 @@ def test_field_active_list(ctx, name, fp32):
 
 
 @pytest.mark.parametrize("use_list", [False, True])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_field_forward_reverse_equals_single_launch(ctx, name, use_list):
     """dsn_field_forward + dsn_field_reverse (the eval-mode split) == dsn_field, bit for bit: sigma/essence on every
     evaluated point, grad on exactly the points with sigma > 0; everything else untouched."""
@@ -151,9 +165,9 @@ def test_field_forward_reverse_equals_single_launch(ctx, name, use_list):
         active = (lst, cnt)
         m = torch.zeros(N, dtype=torch.bool, device=dev)
         m[T(act.astype(np.int64), dev)] = True
-    d_sig, d_ess, d_gr = ctx["lib"].field(sc, ctx["packed"], x)
-    sig, ess, rec, pos = ctx["lib"].field_forward(sc, ctx["packed"], x, active=active)
-    gr = ctx["lib"].field_reverse(sc, ctx["packed"], x, rec, pos)
+    d_sig, d_ess, d_gr = ctx["lib"].field(sc, W(ctx, name)["packed"], x)
+    sig, ess, rec, pos = ctx["lib"].field_forward(sc, W(ctx, name)["packed"], x, active=active)
+    gr = ctx["lib"].field_reverse(sc, W(ctx, name)["packed"], x, rec, pos, sig, ess)
     assert torch.equal(sig[m], d_sig[m]) and torch.equal(ess[m], d_ess[m])
     assert float(sig[~m].abs().sum()) == 0.0
     want = m & (d_sig > 0)
@@ -168,16 +182,17 @@ def test_field_forward_reverse_equals_single_launch(ctx, name, use_list):
 
 
 @pytest.mark.parametrize("exhaustive,fp32", [(False, False), (True, False), (False, True)])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_shade(ctx, name, exhaustive, fp32):
     g = load(name)
     dev, S = ctx["dev"], int(g["S"])
     sc = scene_for(ctx, g, name)
-    idx, n_w, col = ctx["lib"].shade(sc, ctx["packed"], T(g["x_c"], dev), T(g["grad_sigma"], dev), T(g["pts"], dev),
+    idx, n_w, col = ctx["lib"].shade(sc, W(ctx, name)["packed"], T(g["x_c"], dev), T(g["grad_sigma"], dev), T(g["pts"], dev),
                                      T(g["ray_d"], dev), T(g["essence"], dev), S, exhaustive=exhaustive, fp32=fp32)
     assert np.array_equal(idx.cpu().numpy(), g["idx_canon"])
     assert np.array_equal(n_w.cpu().numpy(), g["n_w"])          # same inputs -> bit-exact normals
-    assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5
+    # same inputs -> only the lighting MLP's arithmetic differs: 1e-5, relative to the colour magnitude where that is > 1
+    assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5 * max(1.0, float(np.abs(g["colour"]).max()))
 
 
 def test_normals_of_points_outside_the_grids(ctx):
@@ -208,7 +223,7 @@ def test_normals_of_points_outside_the_grids(ctx):
     assert torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_composite(ctx, name):
     g = load(name)
     dev = ctx["dev"]

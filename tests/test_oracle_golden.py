@@ -5,16 +5,22 @@ import pytest
 import torch
 
 import oracle as O
-from helpers import CASES, code_for, light_kw, load, maxdiff, per_point_dirs, state
+from helpers import ALL_CASES, CASES, code_for, light_kw, load, maxdiff, per_point_dirs, ref_tol, state
 
 
 @pytest.fixture(scope="module")
 def params():
-    sd = state()
-    return sd, O.Params(sd)
+    cache = {}
+
+    def get(name):
+        sd = state(name)
+        if id(sd) not in cache:
+            cache[id(sd)] = (sd, O.Params(sd))
+        return cache[id(sd)]
+    return get
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_sampler_bit_exact(name):
     g = load(name)
     S = int(g["S"])
@@ -28,7 +34,7 @@ def test_sampler_bit_exact(name):
     assert maxdiff(O.linspace01(S), tv) <= 1.2e-7
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_warp_bit_exact(name):
     g = load(name)
     assert np.array_equal(O.centroids(g["xyz"], g["faces"]), g["centroid_world"])
@@ -40,47 +46,52 @@ def test_warp_bit_exact(name):
     assert np.array_equal(w["ray_d_can"], g["ray_d_can"])
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_field(name, params):
-    sd, P = params
+    sd, P = params(name)
     g = load(name)
     q, pf = O.pose_feat(g["poses"], P)
     assert np.array_equal(q, g["pose_quat"][0])
-    assert maxdiff(pf, g["pose_feat"][0]) < 5e-7
+    assert maxdiff(pf, g["pose_feat"][0]) < 5e-7 * max(1.0, float(np.abs(g["pose_feat"]).max()))     # summation order of a 3-layer MLP
     sig, ess, gr = O.field(g["x_c"], P, code_for(g, sd, name), g["pose_feat"][0])
-    assert maxdiff(sig, g["sigma"]) < 5e-5                  # |sigma| <= 10: GEMM-order noise only
-    assert maxdiff(ess, g["essence"]) < 5e-6
-    scale = np.abs(g["grad_sigma"]).max()
-    assert maxdiff(gr, g["grad_sigma"]) < 2e-4 * scale      # ill-conditioned (PE x512, ReLU kinks)
+    assert maxdiff(sig, g["sigma"]) < ref_tol(g, "sigma", 5e-5, 2e-6)       # GEMM-order noise only (|sigma| <= 64: 5e-5)
+    assert maxdiff(ess, g["essence"]) < ref_tol(g, "essence", 5e-6, 2e-6)
+    # d sigma/dx is ill-conditioned (PE x512, ReLU kinks: a pre-activation within rounding of 0 flips a mask and moves the
+    # gradient discretely), so it is judged per point with a small outlier budget, like the GPU kernels are
+    gn = np.linalg.norm(g["grad_sigma"], axis=-1)
+    rel = np.linalg.norm(gr - g["grad_sigma"], axis=-1) / np.maximum(gn, 1.0)
+    assert np.median(rel) < 2e-6 and np.mean(rel > 1e-4) < 2e-3, (np.median(rel), np.mean(rel > 1e-4))
+    if "_w" not in name:
+        assert maxdiff(gr, g["grad_sigma"]) < 2e-4 * np.abs(g["grad_sigma"]).max()     # no flip at all on the default set
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_normal_and_lighting(name, params):
-    sd, P = params
+    sd, P = params(name)
     g = load(name)
     idc, nw = O.normal_world(g["x_c"], g["grad_sigma"], g["canonical_vertex"], g["xyz"], g["faces"])
     assert np.array_equal(idc, g["idx_canon"])
     assert np.array_equal(nw, g["n_w"])
     col = O.lighting(g["n_w"], g["pts"], per_point_dirs(g), g["essence"], P, **light_kw(g))
-    assert maxdiff(col, g["colour"]) < 1e-6
+    assert maxdiff(col, g["colour"]) < 1e-6 * max(1.0, float(np.abs(g["colour"]).max()))
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_composite(name):
     g = load(name)
     noise = g["noise"] if "noise" in g.files else None
     cm = O.composite(g["raw"], g["z_vals"], g["ray_d"], noise)
     for k in ("rgb_map", "acc_map", "weights", "depth_map"):
-        assert maxdiff(cm[k], g[k]) < 2e-6, k
+        assert maxdiff(cm[k], g[k]) < 2e-6 * max(1.0, float(np.abs(g[k]).max())), k
     fin = np.isfinite(g["disp_map"])
     assert np.array_equal(np.isnan(cm["disp_map"]), np.isnan(g["disp_map"]))   # NaN where acc == 0
     assert np.allclose(cm["disp_map"][fin], g["disp_map"][fin], rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_render_end_to_end(name, params):
     """Whole path vs Renderer.render of the reference (trainer.py:70's call)."""
-    sd, P = params
+    sd, P = params(name)
     g = load(name)
     S = int(g["S"])
     tv = torch.linspace(0.0, 1.0, steps=S).numpy()
@@ -90,8 +101,10 @@ def test_render_end_to_end(name, params):
                  g["poses"], code_for(g, sd, name), jitter=jit, noise=noise, t_vals=tv, **light_kw(g))
     assert np.array_equal(e["z_vals"], g["render:z_vals"])
     for k in ("color", "depth_map", "acc_map", "weights"):
-        assert maxdiff(e[k], g["render:" + k]) < 1e-4, k      # north_star tolerance
-        assert maxdiff(e[k], g["render:" + k]) < 5e-6, k      # what is actually achieved
+        big = float(np.abs(g["render:" + k]).max())
+        assert maxdiff(e[k], g["render:" + k]) < ref_tol(g, "render:" + k, 1e-4), k       # north_star tolerance
+        achieved = 5e-6 if "_w" not in name else 3e-5      # (w3: a sigma error of 1e-3 at |sigma| ~ 1e3 is 1e-5 in alpha)
+        assert maxdiff(e[k], g["render:" + k]) < achieved * max(1.0, big), k              # what is actually achieved
 
 
 def test_reference_noise_floor_documented():
@@ -111,14 +124,15 @@ def test_camera_rays_restatement():
     assert np.array_equal(near[mask], g["near"]) and np.array_equal(far[mask], g["far"])
 
 
-@pytest.mark.parametrize("name", ["small_train_grads", "small_train_grads_nonoise", "full_train_grads"])
+@pytest.mark.parametrize("name", ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2",
+                                  "full_train_grads_w2"])
 def test_train_oracle_reproduces_reference_autograd(name):
     """oracle/train_oracle.py (differentiable restatement, torch CPU) against the loss and the parameter gradients the
     reference's own loss.backward() produced (tests/golden/make_golden_grads.py)."""
     import train_oracle as TO
     g = load(name)
     noise = g["noise"] if float(g["raw_noise_std"]) > 0 else None
-    loss, grads, out = TO.loss_and_grads(state(), g, g["render:z_vals"], noise, g["target_rgb"], g["occupancy"])
+    loss, grads, out = TO.loss_and_grads(state(name), g, g["render:z_vals"], noise, g["target_rgb"], g["occupancy"])
     assert abs(loss - float(g["loss"])) < 1e-6
     assert maxdiff(out["color"], g["render:color"]) < 1e-5
     idx = lambda n: (np.arange(4096, dtype=np.int64) * 2654435761 + 12345) % n
