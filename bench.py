@@ -60,6 +60,13 @@ def parse():
                     help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
                          "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
     ap.add_argument("--train-rays", type=int, default=8192)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong-scaling mode (BASELINE configs[3]): ONE 1024 x 1024 x 128 frame, its rays dealt to the ranks in "
+                         "round-robin 3072-ray tiles (RayParallel.tile_indices), rendered pixels all-gathered inside the timed "
+                         "region; N = 1 renders the whole frame on one GPU")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements of the default N = 1 line (screen off, exact fp32, host-to-host "
+                         "render_view, eager-torch GPU baseline, torch CPU baseline)")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="secondary mode: time the eager-PyTorch restatement of the path (oracle/train_oracle.py) on this GPU "
                          "the way the reference runs it (3072-ray chunks; 8192-ray training step), nearest-face searches "
@@ -101,7 +108,10 @@ def main():
     if args.train:
         return train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist)
     if args.eager_baseline:
-        return eager_baseline(args, _lib, synth, dev)
+        print(json.dumps(eager_baseline(args, _lib, synth, dev)))
+        return
+    if args.strong:
+        return strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist)
     H = W = args.hw
     S = args.samples
     R = H * W
@@ -131,6 +141,14 @@ def main():
     packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
     for j in range(depth):          # allocate every slot's workspace up front (setup, not a step: W may be smaller than the depth)
         wss[j].get(R, S)
+    # the density screen's margin is measured for these parameters once, like Renderer does after a checkpoint load
+    # (PackedParams.calibrate_screen: set-up, not a step)
+    screen_info = None
+    if not (args.dense or args.fp32 or args.no_screen):
+        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+        screen_info = packed.calibrate_screen(scene)
+        if not screen_info["usable"]:
+            args.no_screen = True
     torch.cuda.synchronize()
     k_step = 0
 
@@ -191,7 +209,10 @@ def main():
         "metric": f"rendered rays/sec ({S} samples/ray), {H}x{W} frame",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": ("f32 (v_mfma_f32_32x32x2_f32)" if args.fp32 else
+                  "split-f16x3 (3 x v_mfma_f32_32x32x16_f16 on hi/lo fp16 operand halves, f32 accumulate: f32-equivalent accuracy)"
+                  + ("" if (args.dense or args.no_screen) else " + plain-f16 density screen")),
+        "data": "synthetic",
         "config": {
             "workload": f"{H}x{W} frame x {S} samples/ray per GPU (BASELINE configs[1]; N>1: one frame per GPU, configs[4]), "
                         f"synthetic closed body V=6890/F=13776, camera framed so that all rays cross the body AABB (mask_at_box), "
@@ -201,6 +222,7 @@ def main():
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
             "density_screen": not (args.dense or args.fp32 or args.no_screen),
+            "density_screen_calibration": screen_info,
             "accurate_pass_sample_fraction": n_kept / float(R * S),
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,
@@ -215,12 +237,165 @@ def main():
         result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args)
+    if rank == 0 and world == 1 and not args.no_extras and not (args.dense or args.fp32):
+        # what else ran on this box, in the same line: the same frame without the screen and with the exact-fp32
+        # kernel, the host-batch -> host-image path of the reference's render_view, and the eager-torch restatement on this GPU
+        def frame_ms(reps, **kw):
+            n_, f_ = near0.clone(), far0.clone()
+            ms = []
+            for i in range(reps + 1):
+                n_.copy_(near0); f_.copy_(far0)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+                _lib.render_rays(scene, packed, ws, ray_o, ray_d, n_, f_, S, t_vals, None, None, want_weights=False, out=outs[0], **kw)
+                torch.cuda.synchronize()
+                if i:
+                    ms.append(1e3 * (time.perf_counter() - t))
+            return float(np.mean(ms))
+        ex = result["config"]
+        ex["ms_per_frame_alone_no_screen"] = frame_ms(5, screen=False)
+        ex["ms_per_frame_alone_fp32_exact"] = frame_ms(2, fp32=True)
+        ex["host_to_host_ms"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
+        if not args.no_cpu_baseline:
+            result["eager_gpu_baseline"] = eager_baseline(args, _lib, synth, dev, chunks=3, train=False)
+            result["eager_gpu_baseline"]["x_faster_per_frame"] = result["eager_gpu_baseline"]["eval_ms_per_512x512_frame"] * \
+                (H * W / (512.0 * 512.0)) / ms_serial
+            result["cpu_baseline_torch"] = cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
+
+
+def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S):
+    """The reference's render_view contract (can_render.py:248-278): a batch of HOST tensors in (what its DataLoader hands
+    over), four HOST images out, one frame at a time through the Renderer mirror.  PCIe-inclusive: never `value`."""
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
+                          MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0, raw_noise_std=1.0,
+                                                TYPE="nerf", FINE_RAY_SAMPLING=-1))
+    net = dsnerf_amd.DualSpaceNeRF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(dev)
+    r = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+    r.eval()
+    C = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    batch = {"ray_o": C(rays["ray_o"])[None], "ray_d": C(rays["ray_d"])[None], "near": C(rays["near"])[None], "far": C(rays["far"])[None],
+             "xyz": C(xyz)[None], "poses": C(poses)[None], "Th": torch.zeros(1, 1, 3), "frame": torch.tensor([5]),
+             "img": torch.zeros(1, H, W, 3, dtype=torch.float64), "mask_at_box": torch.ones(1, H * W, dtype=torch.bool)}
+    ms = []
+    for i in range(6):
+        b = dict(batch)
+        b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = r.render_view(b)
+        assert not out["coarse_color"].is_cuda
+        if i:
+            ms.append(1e3 * (time.perf_counter() - t))
+    return float(np.mean(ms))
+
+
+def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
+    """BASELINE configs[3]: ONE 1024 x 1024 frame at 128 samples per ray, split over the ranks.  The rays are dealt in
+    round-robin tiles of 3072 (with the transparent skip the rows through the torso cost several times the rows above the
+    head; tiles even that out); every rank renders its tiles with the whole-frame kernels and ONE all_gather_into_tensor of
+    equal slabs of packed [rays, 6] pixels brings the frame together on every rank, inside the timed region, followed by
+    the un-dealing scatter into frame order.  value = rays of the frame / time: strong scaling."""
+    import torch.distributed as dist
+    H = W = args.hw if args.hw != 512 else 1024
+    S = args.samples if args.samples != 64 else 128
+    R = H * W
+    canon, faces = synth.make_body()
+    sd = synth.make_state_dict()
+    poses = synth.make_poses(seed=5)
+    xyz = synth.pose_body(canon, seed=3)
+    rays = synth.make_rays(H, W, xyz, fit_box=True)
+    rp = dsnerf_amd.RayParallel()
+    idx_of = [rp.tile_indices(R, 3072, r) for r in range(world)]
+    mine = idx_of[rank].numpy()
+    slab = max(int(i.numel()) for i in idx_of)
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    ws = _lib.RenderWorkspace(dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # the geometry-guided sampler uses the batch's FIRST ray origin for every ray (utils/pts_utils.py:31): one camera, same origin
+    o, d, near0, far0 = T(rays["ray_o"][mine]), T(rays["ray_d"][mine]), T(rays["near"][mine]), T(rays["far"][mine])
+    d_xyz, d_poses = T(xyz), T(poses)
+    t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    Rl = len(mine)
+    ws.get(Rl, S)
+    scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+    info = packed.calibrate_screen(scene)
+    near, far = near0.clone(), far0.clone()
+    px = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
+    allp = torch.empty(world * slab, 6, dtype=torch.float32, device=dev)
+    full = torch.empty(R, 6, dtype=torch.float32, device=dev)
+    dev_idx = [i.to(dev) for i in idx_of]
+    out = None
+
+    def step():
+        nonlocal out
+        near.copy_(near0)
+        far.copy_(far0)
+        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
+                               screen=info["usable"])
+        px[:Rl, 0:3] = out["color"]
+        px[:Rl, 3] = out["disp_map"]
+        px[:Rl, 4] = out["acc_map"]
+        px[:Rl, 5] = out["depth_map"]
+        if use_dist:
+            dist.all_gather_into_tensor(allp, px)
+            for r_ in range(world):
+                full[dev_idx[r_]] = allp[r_ * slab: r_ * slab + dev_idx[r_].numel()]
+        else:
+            full[dev_idx[0]] = px[:Rl]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cnt = ws.buf[:256].view(torch.int32).cpu()
+    ms = 1e3 * dt / args.steps
+    res = {"metric": f"rendered rays/sec ({S} samples/ray), ONE {H}x{W} frame split over the GPUs", "value": R * args.steps / dt,
+           "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None,
+           "dtype": "split-f16x3 (3 x v_mfma_f32_32x32x16_f16 on hi/lo fp16 operand halves, f32 accumulate) + plain-f16 density screen",
+           "data": "synthetic",
+           "config": {"workload": f"one {H}x{W} frame x {S} samples/ray (BASELINE configs[3]) over {world} GPU(s): round-robin 3072-ray "
+                                  f"tiles, {Rl} rays on rank 0, synthetic closed body V=6890/F=13776, all rays cross the body AABB, GG "
+                                  f"sampling, eval mode",
+                      "rays_on_rank0": Rl, "samples_per_ray": S, "ms_per_frame": ms,
+                      "evaluated_sample_fraction_rank0": int(cnt[_lib.CNT_ACTIVE]) / float(Rl * S),
+                      "accurate_pass_sample_fraction_rank0": int(cnt[_lib.CNT_KEEP]) / float(Rl * S),
+                      "density_screen_calibration": info,
+                      "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms * 1e-3) / 1e12,
+                      "exchange": (f"all_gather_into_tensor [{slab},6] fp32 per rank (RCCL) + scatter to frame order, in the timed region"
+                                   if use_dist else "none (scatter to frame order only)")}}
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        _flush_c_stdio()
+        print(json.dumps(res), flush=True)
 
 
 def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
@@ -297,7 +472,7 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
                        "approx_algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}), flush=True)
 
 
-def eager_baseline(args, _lib, synth, dev):
+def eager_baseline(args, _lib, synth, dev, chunks=5, train=True):
     """Stand-in for "the reference on one MI355X" (it cannot travel): the differentiable torch restatement the tests
     use as their oracle, run with eager PyTorch-ROCm on this GPU.  The parameter-independent geometry (sampling, both
     nearest-face searches, warp) is taken from the HIP kernels and NOT timed, which favours the baseline: in the
@@ -344,7 +519,15 @@ def eager_baseline(args, _lib, synth, dev):
     sel = np.arange(H * W // 2, H * W // 2 + chunk)
     g, z, geom = prepare(sel)
     params = {k: T(v) for k, v in sd.items()}
-    t_eval = timed(lambda: TO.render(params, g, jitter_z=z, geom=geom), 5)
+    t_eval = timed(lambda: TO.render(params, g, jitter_z=z, geom=geom), chunks)
+    res = {"metric": "eager-PyTorch restatement on this GPU (network, autograd d sigma/dx, normals, lighting, compositing on one "
+                     "3072-ray chunk as the reference processes a frame, can_render.py:172-245; both nearest-face searches excluded "
+                     "- they come precomputed from the HIP kernels, which favours this baseline)",
+           "eval_rays_per_s": chunk / t_eval, "eval_ms_per_3072_ray_chunk": 1e3 * t_eval,
+           "eval_ms_per_512x512_frame": 1e3 * t_eval * (512 * 512 / chunk), "samples_per_ray": S, "kind": "port",
+           "torch": torch.__version__}
+    if not train:
+        return res
     # train: forward + backward of an MSE loss on 8192 rays (trainer.py:70-81)
     R = args.train_rays
     sel = np.linspace(0, H * W - 1, R).astype(np.int64)
@@ -359,11 +542,8 @@ def eager_baseline(args, _lib, synth, dev):
         torch.nn.functional.mse_loss(out["color"], target).backward()
 
     t_train = timed(train_step, 3)
-    print(json.dumps({"metric": "eager-PyTorch baseline on this GPU (network, normals, lighting, compositing; nearest-face "
-                                "searches excluded)", "eval_rays_per_s": chunk / t_eval, "eval_ms_per_3072_ray_chunk": 1e3 * t_eval,
-                      "eval_ms_per_512x512_frame": 1e3 * t_eval * (H * W / chunk), "train_rays_per_s": R / t_train,
-                      "train_ms_per_step": 1e3 * t_train, "train_rays": R, "samples_per_ray": S, "kind": "port",
-                      "torch": torch.__version__}))
+    res.update({"train_rays_per_s": R / t_train, "train_ms_per_step": 1e3 * t_train, "train_rays": R})
+    return res
 
 
 def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
@@ -505,6 +685,37 @@ def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):
     return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{n} rays evenly spread over the same frame x {S} samples (dense evaluation, OpenMP over all "
                       f"host cores), {dt:.1f} s"}
+
+
+def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
+    """SURVEY 8d baseline (ii): the torch restatement of the path (oracle/train_oracle.py: the reference's op sequence with
+    torch CPU ops, autograd for d sigma/dx) on the host cores, on one 3072-ray chunk of the same frame as the reference
+    processes it (can_render.py:172-245); geometry (both nearest-face searches) from the C oracle, timed with it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import train_oracle as TO
+    import oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    R = rays["ray_o"].shape[0]
+    n = 3072
+    sel = np.arange(R // 2, R // 2 + n)
+    tv = torch.linspace(0.0, 1.0, steps=S).numpy()
+    params = {k: torch.from_numpy(v) for k, v in sd.items()}
+    g = {"ray_o": rays["ray_o"][sel], "ray_d": rays["ray_d"][sel], "xyz": xyz, "canonical_vertex": canon, "faces": faces, "poses": poses,
+         "frame": 5}
+
+    def run():
+        t0 = time.perf_counter()
+        near, far = rays["near"][sel].copy(), rays["far"][sel].copy()
+        z = O.sample_gg(g["ray_o"], g["ray_d"], near, far, xyz, S, None, tv)["z_vals"]
+        TO.render(params, g, jitter_z=z)
+        return time.perf_counter() - t0
+
+    run()
+    dt = run()
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"one {n}-ray chunk of the same frame x {S} samples, torch {torch.__version__} CPU ops with {cores} threads "
+                      f"(networks, autograd d sigma/dx, normals, lighting, compositing) + C-oracle geometry, {dt:.1f} s"}
 
 
 if __name__ == "__main__":

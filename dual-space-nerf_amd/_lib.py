@@ -145,7 +145,7 @@ class PackedParams:
     def set_screen_margin(self, margin: float):
         _check(lib().dsn_set_screen_margin(_ptr(self.buf), C.c_float(margin), _stream()), "dsn_set_screen_margin")
         self.screen = {"deviation": None, "margin": float(margin), "overflow_fraction": None, "points": 0,
-                       "usable": margin < float("inf")}
+                       "usable": margin < float("inf")}       # (a margin <= 0 is unsafe: tests use it to provoke the audit)
         return self.screen
 
 

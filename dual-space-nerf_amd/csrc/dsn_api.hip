@@ -221,7 +221,7 @@ int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t 
 
 int dsn_set_screen_margin(void* packed, float margin, void* stream) {
     DSN_REQUIRE(packed, "dsn_set_screen_margin: null argument");
-    DSN_REQUIRE(margin > 0.0f, "dsn_set_screen_margin: the margin must be positive (+inf = keep every sample)");
+    DSN_REQUIRE(margin == margin, "dsn_set_screen_margin: NaN margin");     // (+inf = keep every sample; <= 0 is unsafe, tests only)
     dsn_launch_set_screen_margin((float*)packed, margin, (hipStream_t)stream);
     return dsn_check_launch("dsn_set_screen_margin");
 }

@@ -234,3 +234,32 @@ def camera_rays_np(K, R, T, bounds, H, W):
     near[mask] = np.minimum(d0, d1).astype(np.float32)
     far[mask] = np.maximum(d0, d1).astype(np.float32)
     return ray_o, ray_d, near, far, mask
+
+
+def camera_rays_h36m_np(K, R, T, bounds, H, W):
+    """numpy restatement of the Human3.6M ray set-up: utils/h36m_utils.py:14-28 get_rays (direction normalised in float64, :26),
+    the float32 cast and :61-76 get_near_far - a float32 slab test on the unit direction with the +-1e-5 clamp of near-zero
+    components (:64-66), against the FIRST ray's origin (:67-68).  Pinned by tests/golden/camera_rays_h36m.npz (made from the
+    reference's own functions).  Returns UNcompacted arrays + mask."""
+    K, R, T = np.asarray(K, np.float64), np.asarray(R, np.float64), np.asarray(T, np.float64).reshape(3)
+    o = -(R.T @ T)
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    xy1 = np.stack([ii, jj, np.ones_like(ii)], -1).reshape(-1, 3).astype(np.float64)
+    pw = (xy1 @ np.linalg.inv(K).T - T) @ R
+    d = pw - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    ray_d = d.astype(np.float32)
+    ray_o = np.broadcast_to(o, pw.shape).astype(np.float32)
+    b = np.asarray(bounds, np.float32)
+    norm_d = np.linalg.norm(ray_d, axis=-1, keepdims=True)
+    v = ray_d / norm_d
+    v[(v < 1e-5) & (v > -1e-10)] = 1e-5
+    v[(v > -1e-5) & (v < 1e-10)] = -1e-5
+    tmin = (b[:1] - ray_o[:1]) / v
+    tmax = (b[1:2] - ray_o[:1]) / v
+    t1, t2 = np.minimum(tmin, tmax), np.maximum(tmin, tmax)
+    nr, fr = np.max(t1, axis=-1), np.min(t2, axis=-1)
+    mask = nr < fr
+    near = np.where(mask, nr / norm_d[:, 0], 0).astype(np.float32)
+    far = np.where(mask, fr / norm_d[:, 0], 0).astype(np.float32)
+    return ray_o, ray_d, near, far, mask

@@ -142,7 +142,7 @@ def render(params: dict, g: dict, jitter_z=None, noise=None, zero_code=False, dt
     acc = weights.sum(-1)
     disp = 1.0 / torch.max(torch.full_like(depth, 1e-10), depth / acc)
     return {"color": rgb, "disp_map": disp, "acc_map": acc, "depth_map": depth, "weights": weights,
-            "sigma": sigma.reshape(-1), "essence": essence, "grad_sigma": grad, "n_w": n_w}
+            "sigma": sigma.reshape(-1), "essence": essence, "grad_sigma": grad, "n_w": n_w, "colour": colour}
 
 
 def loss_and_grads(state: dict, g: dict, z_vals, noise, target, occupancy=None, dtype=torch.float32):

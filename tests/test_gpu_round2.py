@@ -1,0 +1,613 @@
+"""GPU tests of what round 2 added at the boundary and around the split-fp16 kernels:
+  * fp16 RANGE fallback: samples whose activations / adjoints leave the fp16 range are re-evaluated by the exact-fp32 kernel;
+  * density-screen CALIBRATION (per parameter set) and AUDIT;
+  * Human3.6M ray set-up, render_views (f-3);
+  * stand-alone module forwards (LightingMLP, SpaceNet with pose_feats, pose-only density queries) and the differentiable
+    DualSpaceNeRF.forward (dsn_module_grad);
+  * regressions for the advisor's findings (shared gradient workspace, tensor identity of the posed mesh).
+Everything goes through the C ABI (ctypes); the references are the golden vectors of the real reference, the oracle and the
+exact-fp32 kernel."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+import train_oracle as TO
+from helpers import GOLDEN, code_for, load, maxdiff, state
+from test_gpu_render import make_batch, make_cfg, make_renderer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def full_frame(hw=512, seed=3, pose_seed=5):
+    from dsnerf_amd import synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon, seed=seed)
+    rays = synth.make_rays(hw, hw, xyz, fit_box=True)
+    batch = {"ray_o": torch.from_numpy(rays["ray_o"])[None], "ray_d": torch.from_numpy(rays["ray_d"])[None],
+             "near": torch.from_numpy(rays["near"].copy())[None], "far": torch.from_numpy(rays["far"].copy())[None],
+             "xyz": torch.from_numpy(xyz)[None], "poses": torch.from_numpy(synth.make_poses(seed=pose_seed))[None],
+             "Th": torch.tensor([0.2, -0.1, 1.0]).reshape(1, 1, 3), "frame": torch.tensor([5]),
+             "img": torch.zeros(1, hw, hw, 3, dtype=torch.float64), "mask_at_box": torch.ones(1, hw * hw, dtype=torch.bool)}
+    return canon, faces, batch
+
+
+def renderer_with(sd, canon, faces, S=64):
+    import dsnerf_amd
+    net = dsnerf_amd.DualSpaceNeRF(make_cfg(S))
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    net.cuda()
+    return dsnerf_amd.Renderer(net, None, make_cfg(S), torch.from_numpy(canon), body_data={"f": faces})
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# f-2: Human3.6M rays
+# ------------------------------------------------------------------------------------------------------------------------
+def test_camera_rays_h36m():
+    """dsn_camera_rays(DSN_RAYS_H36M) vs the reference's utils/h36m_utils.get_rays_within_bounds golden (unit directions,
+    float32 slab test): mask identical, rays / near / far within 1 ulp; at 1024 x 1024 (BASELINE configs[3]) against the stored
+    every-37th-pixel sample of the reference and, on all pixels, against the oracle's restatement"""
+    from dsnerf_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "camera_rays_h36m.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd, near, far, mask = _lib.camera_rays(g["K"], g["R"], g["T"], g["bounds"], H, W, device=DEV, convention="h36m")
+    m = mask.cpu().numpy()
+    assert np.array_equal(m, g["mask_at_box"])
+    assert maxdiff(ro.cpu().numpy(), g["ray_o"]) <= 2.4e-7 and maxdiff(rd.cpu().numpy(), g["ray_d"]) <= 6e-8
+    assert maxdiff(near.cpu().numpy()[m], g["near"]) <= 4.8e-7 and maxdiff(far.cpu().numpy()[m], g["far"]) <= 4.8e-7
+    H2, W2 = int(g["H2"]), int(g["W2"])
+    ro, rd, near, far, mask = _lib.camera_rays(g["K2"], g["R"], g["T2"], g["bounds"], H2, W2, device=DEV, convention="h36m")
+    p = g["pick2"]
+    m = mask.cpu().numpy()
+    assert int(m.sum()) == int(g["mask2_count"]) and np.array_equal(m[p], g["mask2"])
+    assert maxdiff(rd.cpu().numpy()[p], g["ray_d2"]) <= 6e-8
+    assert maxdiff(near.cpu().numpy()[p], g["near2"]) <= 4.8e-7 and maxdiff(far.cpu().numpy()[p], g["far2"]) <= 4.8e-7
+    o = O.camera_rays_h36m_np(g["K2"], g["R"], g["T2"], g["bounds"], H2, W2)
+    assert np.array_equal(m, o[4])
+    assert maxdiff(rd.cpu().numpy(), o[1]) <= 6e-8 and maxdiff(near.cpu().numpy(), o[2]) <= 4.8e-7
+    assert abs(float(rd.norm(dim=-1).mean()) - 1.0) < 1e-6
+    with pytest.raises(ValueError):
+        _lib.camera_rays(g["K"], g["R"], g["T"], g["bounds"], H, W, device=DEV, convention="blender")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# fp16 range fallback
+# ------------------------------------------------------------------------------------------------------------------------
+def overflowing_state(layer="nerf.stage1.4"):
+    """default parameters (activations O(1)) with two consecutive trunk layers scaled up by c ~ 300 each - weights stay far
+    below the 1023 the fp16 weight images hold, the second layer's outputs reach 1e5 > fp16 max on most points - and the scale
+    taken back over the next two layers (1/c each): sigma stays O(10), the exact-fp32 kernel is fine with it, plain split-fp16
+    operands are not"""
+    sd = {k: v.copy() for k, v in state().items()}
+    if layer == "nerf.stage1.4":
+        c = np.float32(300.0)
+        up1, up2, down = "nerf.stage1.2", "nerf.stage1.4", [("nerf.stage1.6.weight", slice(None)), ("nerf.stage2.0.weight", slice(0, 256))]
+    elif layer == "nerf.stage2.2":
+        c = np.float32(350.0)
+        up1, up2, down = "nerf.stage2.0", "nerf.stage2.2", [("nerf.stage2.4.weight", slice(None)), ("nerf.density_net.0.weight", slice(None)),
+                                                           ("nerf.rgb_net.1.weight", slice(None))]
+    else:
+        raise ValueError(layer)
+    sd[up1 + ".weight"] *= c
+    sd[up1 + ".bias"] *= c
+    sd[up2 + ".weight"] *= c
+    sd[up2 + ".bias"] *= c * c
+    for k, cols in down:
+        sd[k][:, cols] *= np.float32(1.0) / c
+    return sd
+
+
+@pytest.mark.parametrize("layer", ["nerf.stage1.4", "nerf.stage2.2"])
+def test_fp16_range_fallback_equals_exact_kernel(layer):
+    """activations beyond the fp16 range: dsn_field (split-fp16 + fallback) returns the exact-fp32 kernel's values BIT FOR BIT on
+    the samples that left the range, everything is finite, and the in-range samples keep their split-fp16 values"""
+    from dsnerf_amd import _lib
+    g = load("full_eval")
+    sd = overflowing_state(layer)
+    packed = _lib.PackedParams(DEV).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    sc = _lib.Scene(torch.from_numpy(g["canonical_vertex"]), torch.from_numpy(g["faces"].astype(np.int64)), DEV)
+    sc.set_frame(packed, torch.from_numpy(g["xyz"]), torch.from_numpy(g["poses"]), int(g["frame"]))
+    x = T(g["x_c"])
+    a = _lib.field(sc, packed, x, fp32=False)
+    b = _lib.field(sc, packed, x, fp32=True)
+    for t in a:
+        assert torch.isfinite(t).all()
+    same = (a[0] == b[0]) & (a[1] == b[1]).all(-1) & (a[2] == b[2]).all(-1)
+    frac = float(same.float().mean())
+    assert 0.05 < frac < 0.995, frac            # a real share of the points overflowed and took the exact kernel, not all ...
+    # ... and the others agree with it like the two kernels always do
+    assert maxdiff(a[0].cpu().numpy(), b[0].cpu().numpy()) < 1e-4
+    # oracle (float32 C restatement) agrees with both
+    P = O.Params(sd)
+    osig, oess, _ = O.field(g["x_c"], P, sd["nerf.embedding.weight"][int(g["frame"])], O.pose_feat(g["poses"], P)[1])
+    assert maxdiff(a[0].cpu().numpy(), osig) < 1e-3 and maxdiff(a[1].cpu().numpy(), oess) < 1e-4
+    # the two-launch form (eval-mode split): flagged samples are on the reverse list, carry NaN in between, and come out equal
+    sig, ess, rec, pos = _lib.field_forward(sc, packed, x)
+    assert bool(torch.isnan(sig).any())
+    gr = _lib.field_reverse(sc, packed, x, rec, pos, sig, ess)
+    assert torch.isfinite(sig).all() and torch.isfinite(ess).all()
+    assert torch.equal(sig, a[0]) and torch.equal(ess, a[1])
+    want = a[0] > 0
+    assert torch.equal(gr[want], a[2][want])
+
+
+def test_fp16_range_fallback_in_the_fused_path():
+    """a whole frame rendered with parameters that overflow fp16: finite pixels, equal to the exact-fp32 render within the
+    parity tolerance, with the density screen on and off, with and without the transparent skip"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)
+    r = renderer_with(overflowing_state("nerf.stage1.4"), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+
+    def run(**kw):
+        n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        return _lib.render_rays(r.scene, r.net.packed(r.device), _lib.RenderWorkspace(r.device), o, d, n, f, S, r._t_vals(S), **kw)
+
+    exact = run(fp32=True)
+    assert float(exact["acc_map"].max()) > 0.05
+    for kw in ({}, {"screen": False}, {"skip_transparent": False}):
+        out = run(**kw)
+        assert torch.isfinite(out["color"]).all() and torch.isfinite(out["weights"]).all()
+        assert float((out["color"] - exact["color"]).abs().max()) < 1e-4, kw
+        assert float((out["weights"] - exact["weights"]).abs().max()) < 1e-4, kw
+
+
+def test_training_counts_range_overflow():
+    """train mode has no exact twin of its stored activations: samples outside the fp16 range are COUNTED
+    (Renderer.range_overflow_count), zero for ordinary parameters"""
+    g = load("small_train")
+    r = make_renderer(g, "small_train")
+    r.train()
+    r.render(make_batch(g))
+    assert r.range_overflow_count() == 0
+    canon, faces = g["canonical_vertex"], g["faces"]
+    r2 = renderer_with(overflowing_state("nerf.stage1.4"), canon, faces, S=int(g["S"]))
+    r2.train()
+    r2.render(make_batch(g))
+    assert r2.range_overflow_count() > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# density screen: calibration and audit
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wname", ["", "_w2", "_w3"])
+def test_screen_calibration_bounds_the_frame(wname):
+    """PackedParams.calibrate_screen on each parameter set: the calibrated margin (10x the largest deviation seen on 1 M points
+    around the canonical surface) is >= 4x the largest deviation over a whole 512 x 512 x 64 frame of another pose, no sample
+    the screen drops with that margin has an accurate density >= 0, and the frame is bit-identical with the screen on / off"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=512, seed=23, pose_seed=41)
+    r = renderer_with(state("x" + wname), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    packed = r.net.packed(r.device)
+    info = packed.calibrate_screen(r.scene)
+    assert info["usable"] and 0.002 <= info["margin"] <= 0.05 and info["overflow_fraction"] < 0.5, info
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+    pts, z = _lib.sample(r.scene, o, d, n, f, S, r._t_vals(S), None)
+    w = _lib.warp(r.scene, pts, d, S, want_dir=False, want_active=True)
+    act = w["active_list"][: int(w["active_count"][0])].long()
+    sig, _, _ = _lib.field(r.scene, packed, w["x_c"], want_essence=False, want_grad=False,
+                           active=(w["active_list"], w["active_count"]), fp32=True)
+    sg, s1 = _lib.screen_debug(r.scene, packed, w["x_c"])
+    sig, sg, s1 = sig[act], sg[act], s1[act]
+    ok = torch.isfinite(sg) & torch.isfinite(s1)
+    dev_frame = float(((sg - sig).abs() / (s1 + 1.0))[ok].max())
+    m = info["margin"]
+    empty = ok & (sg < -(m * s1 + m))
+    assert int((empty & (sig >= 0)).sum()) == 0
+    assert m >= 4.0 * dev_frame, (m, dev_frame, info)
+    print(f"weights '{wname}': calibration deviation {info['deviation']:.2e} -> margin {m:.2e}; frame deviation {dev_frame:.2e}; "
+          f"{float(empty.float().mean()):.3f} of {act.numel()} evaluated samples declared empty")
+    outs = []
+    for screen in (True, False):
+        n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        outs.append(_lib.render_rays(r.scene, packed, _lib.RenderWorkspace(r.device), o, d, n2, f2, S, r._t_vals(S), screen=screen))
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def pathological_state():
+    """a network the plain-fp16 screen cannot follow: the odd rows of stage2.2 are copies of the even ones plus 1e-3 noise, and
+    stage2.4 reads the DIFFERENCE of each pair times 400 - exact arithmetic sees O(1) values, fp16 activations (11 bits) see
+    mostly rounding noise"""
+    from dsnerf_amd import synth
+    sd = {k: v.copy() for k, v in state().items()}
+    w5, b5, w6 = sd["nerf.stage2.2.weight"], sd["nerf.stage2.2.bias"], sd["nerf.stage2.4.weight"]
+    noise = (synth.hash_uniform(128 * 256, 901).reshape(128, 256) - 0.5).astype(np.float32) * np.float32(2e-3)
+    w5[1::2] = w5[0::2] + noise
+    b5[1::2] = b5[0::2]
+    v = w6[:, 0::2].copy() * np.float32(400.0)
+    w6[:, 0::2] = v
+    w6[:, 1::2] = -v
+    return sd
+
+
+def test_pathological_network_switches_the_screen_off():
+    """when the calibration finds deviations beyond the cap the screen is left out: Renderer warns, renders without it, and
+    the frame is bit-identical to an explicit screen-off render"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)
+    r = renderer_with(pathological_state(), canon, faces)
+    r.eval()
+    with pytest.warns(UserWarning, match="density screen"):
+        out = r.render(dict(batch))["coarse"]
+    assert r.screen_info is not None and not r.screen_info["usable"] and r.screen_info["deviation"] > 0.005, r.screen_info
+    r.density_screen = False
+    ref = r.render(dict(batch))["coarse"]
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.isfinite(out["color"]).all() and float(out["acc_map"].max()) > 0.01
+    # and a fresh default network is calibrated usable by the same path
+    r2 = renderer_with(state(), canon, faces)
+    r2.eval()
+    r2.render(dict(batch))
+    assert r2.screen_info["usable"] and r2.screen_info["margin"] < 0.011
+
+
+def test_screen_audit():
+    """screen_audit: 1/128 of the samples the screen drops are evaluated anyway; none may have a positive density; the frame is
+    unchanged.  With a margin far too small (set by hand) the audit finds violations and the renderer turns the screen off"""
+    canon, faces, batch = full_frame(hw=512)
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    plain = {k: v.clone() for k, v in r.render(dict(batch))["coarse"].items()}
+    r.screen_audit = True
+    audited = r.render(dict(batch))["coarse"]
+    res = r.last_screen_audit()
+    assert res["audited"] > 1000 and res["violations"] == 0, res
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(plain[k], audited[k]), k
+    r.net.packed(r.device).set_screen_margin(-0.02)         # "empty" up to sigma~ < 0.02 (S1 + 1): drops positive densities
+    with pytest.warns(UserWarning, match="switched off"):
+        r.render(dict(batch))
+        res = r.last_screen_audit()
+    assert res["violations"] > 0 and res["max_sigma"] > 0.0 and r.density_screen is False, res
+    again = r.render(dict(batch))["coarse"]                 # screen off now: the exact frame again
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(plain[k], again[k]), k
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# f-3: sequences
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("in_flight,device_output", [(2, True), (3, False), (1, True)])
+def test_render_views_equals_single_calls(in_flight, device_output):
+    """Renderer.render_views(batches, frames_in_flight) == [render_view(b) for b in batches], bit for bit (4 frames of a
+    novel-pose sequence: different posed meshes, pose vectors and frame indices)"""
+    from dsnerf_amd import synth
+    canon, faces = synth.make_body()
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    batches = []
+    for k in range(4):
+        _, _, b = full_frame(hw=96, seed=30 + k, pose_seed=50 + k)
+        b["frame"] = torch.tensor([3 + 2 * k])
+        m = torch.ones(96 * 96, dtype=torch.bool)
+        m[k::11] = False                                       # a partial mask_at_box per frame
+        sel = m.nonzero().reshape(-1)
+        for key in ("ray_o", "ray_d"):
+            b[key] = b[key][:, sel]
+        for key in ("near", "far"):
+            b[key] = b[key][:, sel]
+        b["mask_at_box"] = m[None]
+        batches.append(b)
+    singles = [r.render_view(dict(b), device_output=True) for b in batches]
+    singles = [{k: v.clone() for k, v in s.items()} for s in singles]
+    seq = r.render_views([dict(b) for b in batches], frames_in_flight=in_flight, device_output=device_output)
+    assert len(seq) == 4
+    for a, b in zip(singles, seq):
+        for k in ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth"):
+            assert b[k].is_cuda == device_output
+            assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), k
+    assert float(singles[0]["coarse_acc"].max()) > 0.05
+    assert r.render_views([], frames_in_flight=2) == []
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# module boundary
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["small_eval", "full_eval_w2"])
+def test_lighting_mlp_forward(name):
+    """LightingMLP.forward(normal, xyz_world, view_dir_world, essence) (model/spacenet.py:174-188) on the golden inputs of the
+    reference == its golden colours; as a sub-module of DualSpaceNeRF and stand-alone with only its own state_dict"""
+    import dsnerf_amd
+    g = load(name)
+    r = make_renderer(g, name)
+    r.eval()
+    S = int(g["S"])
+    dirs = np.repeat(g["ray_d"][:, None, :], S, 1).reshape(-1, 3)
+    args = (T(g["n_w"]), T(g["pts"].reshape(-1, 3)), T(dirs), T(g["essence"]))
+    col = r.net.lighting_mlp(*args)
+    assert col.shape == (g["n_w"].shape[0], 3)
+    assert maxdiff(col.cpu().numpy(), g["colour"]) < 1e-5 * max(1.0, float(np.abs(g["colour"]).max()))
+    solo = dsnerf_amd.LightingMLP(3)
+    solo.load_state_dict({k[len("lighting_mlp."):]: torch.from_numpy(v) for k, v in state(name).items() if k.startswith("lighting_mlp.")})
+    solo.cuda().eval()
+    assert torch.equal(solo(*args), col)
+    solo.train()
+    with pytest.raises(RuntimeError, match="autograd"):
+        solo(*args)
+    with torch.no_grad():
+        assert torch.equal(solo(*args), col)
+
+
+@pytest.mark.parametrize("name", ["small_eval", "small_novel", "full_eval_w2"])
+def test_spacenet_forward_honours_pose_feats_and_idx(name):
+    """SpaceNet.forward(pos, rays, idx, density_only, pose_feats) (model/spacenet.py:93-148) with the reference's own pose
+    features: golden sigma / essence; [R,S,3] input; density_only; and rows with DIFFERENT frame indices / pose features in one
+    call (evaluated per distinct row) against the oracle"""
+    g = load(name)
+    r = make_renderer(g, name)
+    r.eval()
+    sd = state(name)
+    nerf = r.net.nerf
+    N = g["x_c"].shape[0]
+    S = int(g["S"])
+    x = T(g["x_c"])
+    pf = T(np.repeat(g["pose_feat"], N, 0))
+    idx = torch.full((N // S, S), int(g["frame"]))
+    rgbs, den, zero = nerf(x, None, idx, False, pf)
+    assert zero == 0 and rgbs.shape == (N, 3) and den.shape == (N, 1)
+    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < 1e-4 and maxdiff(rgbs.cpu().numpy(), g["essence"]) < 1e-4
+    rgbs3, den3, _ = nerf(x.reshape(N // S, S, 3), None, idx, False, pf)                # bins mode (:109-112)
+    assert torch.equal(den3, den) and torch.equal(rgbs3, rgbs)
+    assert torch.equal(nerf(x, None, idx, True, pf), den)
+    # two groups: second half of the points with another frame index and scaled pose features
+    idx2 = idx.reshape(-1).clone()
+    pf2 = pf.clone()
+    idx2[N // 2:] = 17
+    pf2[N // 2:] *= 0.5
+    _, den2, _ = nerf(x, None, idx2, False, pf2)
+    assert torch.equal(den2[: N // 2], den[: N // 2])
+    P = O.Params(sd)
+    code = sd["nerf.embedding.weight"][17] * (0 if name == "small_novel" else 1)
+    osig, _, _ = O.field(g["x_c"][N // 2:], P, code, g["pose_feat"][0] * 0.5, want_grad=False)
+    assert maxdiff(den2[N // 2:, 0].cpu().numpy(), osig) < 1e-4
+    with pytest.raises(RuntimeError, match="pose_feats"):
+        nerf(x, None, idx, False, None)
+
+
+def test_density_queries_need_only_poses():
+    """DualSpaceNeRF.forward(density_only=True) and Renderer.query_volume with a batch_info that holds ONLY 'poses' (the
+    reference's density-only branch reads nothing else, model/spacenet.py:223-241), on a renderer that has not rendered yet"""
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    bi = {"poses": torch.from_numpy(g["poses"])[None]}
+    x = torch.from_numpy(g["x_c"])
+    den = r.net(x, None, int(g["frame"]), bi, density_only=True)
+    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < 1e-4
+    q = r.query_volume(x[None], torch.tensor([int(g["frame"])]), torch.from_numpy(g["transparent"])[None], bi)
+    assert q.shape == (1, x.shape[0], 1)
+    qa = q.reshape(-1).cpu().numpy()
+    assert float(np.abs(qa[g["transparent"]]).sum()) == 0.0
+    assert maxdiff(qa[~g["transparent"]], g["sigma"][~g["transparent"]]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["small_train_grads", "full_train_grads_w2"])
+def test_module_forward_is_differentiable(name):
+    """DualSpaceNeRF.forward in train mode: (colour, density) carry ONE autograd node whose backward (dsn_module_grad) gives the
+    gradients of sum(gc * colour) + sum(gs * density) w.r.t. all 33 parameters == torch autograd of the CPU oracle on the same
+    explicit points (including the second-order path through d sigma/dx -> normal -> lighting)"""
+    g = load(name)
+    r = make_renderer(g, name)
+    r.train()
+    sd = state(name)
+    z = g["render:z_vals"]
+    R, S = z.shape
+    o, d = g["ray_o"], g["ray_d"]
+    pts = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32).reshape(-1, 3)
+    wp = O.warp(pts, None, g["xyz"], g["canonical_vertex"], g["faces"])
+    keep = np.nonzero(~wp["transparent"])[0][:1500]            # explicit points: the non-transparent samples
+    N = len(keep)
+    x_w, x_c = pts[keep], wp["x_c"][keep]
+    view = np.repeat(d[:, None, :], S, 1).reshape(-1, 3)[keep]
+    rng = np.random.default_rng(9)
+    gc = rng.standard_normal((N, 3)).astype(np.float32)
+    gs = (rng.standard_normal((N, 1)) * 0.1).astype(np.float32)
+    # oracle: N "rays" of one sample (z = 0) through train_oracle.render with the explicit geometry
+    params = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    cent = O.centroids(g["canonical_vertex"], g["faces"])
+    geom = {"x_c": torch.from_numpy(x_c), "transparent": torch.zeros(N, dtype=torch.bool),
+            "idx_canon": torch.from_numpy(O.nearest_face(x_c, cent).astype(np.int64))}
+    gg = dict(g.items())
+    gg["ray_o"], gg["ray_d"] = x_w, view
+    out = TO.render(params, gg, jitter_z=np.zeros((N, 1), np.float32), geom=geom)
+    L = (torch.from_numpy(gc) * out["colour"]).sum() + (torch.from_numpy(gs[:, 0]) * out["sigma"]).sum()
+    L.backward()
+    # the mirror
+    b = make_batch(g)
+    b["canonical_model"], b["face_idx"] = r.canonical_model, r.face_idx
+    pos = torch.from_numpy(np.concatenate([x_w, x_c], 1))
+    rays = torch.from_numpy(np.concatenate([view, np.zeros_like(view)], 1))
+    col, den, none = r.net(pos, rays, torch.full((N, 1), int(g["frame"])), batch_info=b)
+    assert none is None and col.requires_grad and den.requires_grad
+    dc = np.abs(col.detach().cpu().numpy() - out["colour"].detach().numpy()).max(-1)     # through normalize(d sigma/dx): per point
+    assert np.median(dc) < 2e-6 and np.mean(dc > 1e-4) < 5e-3, (np.median(dc), np.mean(dc > 1e-4))
+    assert maxdiff(den.detach().cpu().numpy()[:, 0], out["sigma"].detach().numpy()) < 1e-4
+    r.net.zero_grad()
+    ((T(gc) * col).sum() + (T(gs) * den).sum()).backward()
+    for k, p in r.net.named_parameters():
+        want = params[k].grad.numpy() if params[k].grad is not None else np.zeros_like(sd[k])
+        got = p.grad.detach().cpu().numpy()
+        e = np.linalg.norm((got - want).astype(np.float64)) / max(np.linalg.norm(want.astype(np.float64)), 1e-30)
+        assert e < 5e-3, (k, e)
+    # eval mode / no_grad: plain tensors, same values
+    r.eval()
+    col2, den2, _ = r.net(pos, rays, int(g["frame"]), batch_info=b)
+    assert not col2.requires_grad and torch.equal(den2, den.detach())
+
+
+def test_render_rays_refuses_to_pretend_it_is_differentiable():
+    g = load("small_train")
+    r = make_renderer(g, "small_train")
+    r.train()
+    b = make_batch(g)
+    S = int(g["S"])
+    dirs = np.repeat(g["ray_d"][:, None, :], S, 1)
+    pts6 = torch.from_numpy(np.concatenate([g["pts"].reshape(-1, S, 3), g["x_c"].reshape(-1, S, 3)], -1))
+    rays6 = torch.from_numpy(np.concatenate([dirs, g["ray_d_can"].reshape(-1, S, 3)], -1))
+    b["canonical_model"], b["face_idx"] = r.canonical_model, r.face_idx
+    b["transparent_mask"] = torch.from_numpy(g["transparent"]).reshape(-1, S)
+    fi = torch.full((g["ray_o"].shape[0], S), int(g["frame"]))
+    with pytest.raises(RuntimeError, match="autograd"):
+        r.batchify_pts(pts6, rays6, torch.from_numpy(g["z_vals"]), fi, batch_info=b)
+    r.eval()
+    out = r.batchify_pts(pts6, rays6, torch.from_numpy(g["z_vals"]), fi, batch_info=b)   # eval: noise-free compositing of the train fixture's points
+    assert torch.isfinite(out["color"]).all() and out["weights"].shape == (g["ray_o"].shape[0], S)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# advisor findings (round 1)
+# ------------------------------------------------------------------------------------------------------------------------
+def test_two_outstanding_renders_backpropagate_independently():
+    """o1 = render(b1); o2 = render(b2); loss1.backward(); loss2.backward() - the shared gradient workspace holds b2's
+    activations when loss1 goes first; each backward must still produce ITS batch's gradients (== a render + backward of that
+    batch alone)"""
+    g1, g2 = load("small_train_grads"), load("small_train_grads_nonoise")
+    r = make_renderer(g1)
+    r.cfg.MODEL.raw_noise_std = 0.0
+    r.cfg.MODEL.perturb = 0.0
+    r.train()
+    b1, b2 = make_batch(g1), make_batch(g2)
+    b2["ray_d"] = b2["ray_d"] * 1.01 + 0.003                  # a different batch
+    t1, t2 = T(g1["target_rgb"]), T(g2["target_rgb"]) * 0.5
+
+    def alone(b, t):
+        r.net.zero_grad()
+        torch.nn.functional.mse_loss(r.render(dict(b))["coarse"]["color"], t).backward()
+        return {k: p.grad.clone() for k, p in r.net.named_parameters()}
+
+    want1, want2 = alone(b1, t1), alone(b2, t2)
+    r.net.zero_grad()
+    o1 = r.render(dict(b1))["coarse"]
+    o2 = r.render(dict(b2))["coarse"]
+    l1 = torch.nn.functional.mse_loss(o1["color"], t1)
+    l2 = torch.nn.functional.mse_loss(o2["color"], t2)
+    l1.backward()
+    got1 = {k: p.grad.clone() for k, p in r.net.named_parameters()}
+    r.net.zero_grad()
+    l2.backward()
+    got2 = {k: p.grad.clone() for k, p in r.net.named_parameters()}
+    for k in want1:
+        n1, n2 = float(want1[k].norm()), float(want2[k].norm())
+        assert float((got1[k] - want1[k]).norm()) <= 1e-5 * n1 + 1e-12, k
+        assert float((got2[k] - want2[k]).norm()) <= 1e-5 * n2 + 1e-12, k
+    # an optimizer step between forward and backward is an error, as with an op-by-op graph
+    o3 = r.render(dict(b1))["coarse"]
+    with torch.no_grad():
+        next(r.net.parameters()).add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        o3["color"].sum().backward()
+
+
+def test_posed_mesh_is_keyed_on_tensor_identity_not_address():
+    """w2l_without_lbs per frame like utils/visualizer.py:47-66: a NEW xyz tensor that reuses the freed address of the
+    previous frame's, and an xyz updated in place, must both reach the scene"""
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    pts = torch.from_numpy(g["pts"])[None]                       # [1,R,S,3]
+    xyz_a = torch.from_numpy(g["xyz"].copy())[None]
+    out_a, mask_a = r.w2l_without_lbs(pts, {"xyz": xyz_a}, r.canonical_model)
+    assert np.array_equal(out_a.cpu().numpy(), g["x_c"])
+    ptr = xyz_a.data_ptr()
+    del xyz_a
+    moved = g["xyz"].copy()
+    moved[:, 0] += 0.05
+    xyz_b = None
+    for _ in range(64):                                          # allocate until the freed block is handed out again
+        cand = torch.empty(1, *moved.shape)
+        if cand.data_ptr() == ptr:
+            xyz_b = cand
+            break
+    if xyz_b is None:
+        xyz_b = torch.empty(1, *moved.shape)                      # could not provoke the reuse: the identity test still applies
+    xyz_b.copy_(torch.from_numpy(moved)[None])
+    out_b, _ = r.w2l_without_lbs(pts, {"xyz": xyz_b}, r.canonical_model)
+    want = O.warp(g["pts"].reshape(-1, 3), None, moved, g["canonical_vertex"], g["faces"])
+    assert np.array_equal(out_b.cpu().numpy(), want["x_c"])
+    xyz_b[0, :, 0] -= 0.05                                        # in place: same tensor, same address, new version
+    out_c, _ = r.w2l_without_lbs(pts, {"xyz": xyz_b}, r.canonical_model)
+    want_c = O.warp(g["pts"].reshape(-1, 3), None, xyz_b[0].numpy(), g["canonical_vertex"], g["faces"])
+    assert np.array_equal(out_c.cpu().numpy(), want_c["x_c"])
+
+
+def test_packed_params_force_repack():
+    """edits through param.data do not bump the version counter: net.packed(force=True) picks them up"""
+    g = load("small_eval")
+    r = make_renderer(g)
+    r.eval()
+    gen = r.net.packed(r.device).generation
+    r.net.nerf.density_net[0].bias.data += 1.0
+    assert r.net.packed(r.device).generation == gen             # invisible to the version counters
+    assert r.net.packed(r.device, force=True).generation == gen + 1
+    den = r.net(torch.from_numpy(g["x_c"]), None, int(g["frame"]), {"poses": torch.from_numpy(g["poses"])[None]}, density_only=True)
+    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"] + 1.0) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# (e): the RCCL code path on one GPU
+# ------------------------------------------------------------------------------------------------------------------------
+def test_ray_parallel_over_rccl_world_size_one():
+    """RayParallel.render / render_tiled / average_gradients on the `nccl` backend (= RCCL) with world_size 1 and the REAL fused
+    path as render_fn: the all-gather / all-reduce run (one rank), pixels equal the un-sharded render bit for bit"""
+    import torch.distributed as dist
+    import dsnerf_amd
+    from dsnerf_amd import _lib
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        canon, faces, batch = full_frame(hw=128)
+        r = renderer_with(state(), canon, faces)
+        r.eval()
+        r._set_frame(batch)
+        r._screen_usable()
+        S = 64
+        packed = r.net.packed(r.device)
+        o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+        n0, f0 = r._dev(batch["near"][0]), r._dev(batch["far"][0])
+
+        def render_fn(ro, rd, near, far):
+            return _lib.render_rays(r.scene, packed, r._ws, ro, rd, near.clone(), far.clone(), S, r._t_vals(S))
+
+        whole = {k: v.clone() for k, v in render_fn(o, d, n0, f0).items()}
+        rp = dsnerf_amd.RayParallel()
+        assert rp.enabled and rp.world == 1
+        for fn in (rp.render, lambda *a: rp.render_tiled(*a, tile=3072)):
+            got = fn(render_fn, o, d, n0, f0)
+            for k in ("color", "acc_map", "depth_map"):
+                assert torch.equal(got[k], whole[k]), k
+        # the exchange itself (world 1 short-cuts gather(); exercise the collective directly like bench.py does)
+        px = torch.cat([whole["color"], whole["disp_map"][:, None], whole["acc_map"][:, None], whole["depth_map"][:, None]], 1).contiguous()
+        out = torch.empty_like(px)
+        dist.all_gather_into_tensor(out, px)
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(px))
+        flat = torch.arange(10.0, device=DEV)
+        dist.all_reduce(flat)
+        assert torch.equal(flat, torch.arange(10.0, device=DEV))
+        ps = [torch.nn.Parameter(torch.ones(3, device=DEV)), torch.nn.Parameter(torch.ones(2, 2, device=DEV))]
+        ps[0].grad = torch.full((3,), 2.0, device=DEV)
+        rp.average_gradients(ps)
+        assert float(ps[0].grad.sum()) == 6.0
+    finally:
+        if created:
+            dist.destroy_process_group()

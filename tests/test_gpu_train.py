@@ -11,7 +11,7 @@ from test_gpu_render import make_batch, make_renderer
 
 pytestmark = pytest.mark.gpu
 
-GRAD_CASES = ["small_train_grads", "small_train_grads_nonoise", "full_train_grads"]
+GRAD_CASES = ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2", "full_train_grads_w2"]
 FULL_LIMIT, SAMPLE = 20000, 4096
 
 
@@ -36,7 +36,7 @@ def reference_loss(out, target, occ):
 @pytest.mark.parametrize("name", GRAD_CASES)
 def test_backward_matches_reference_autograd(name):
     g = load(name)
-    r = make_renderer(g)
+    r = make_renderer(g, name)
     r.cfg.MODEL.raw_noise_std = float(g["raw_noise_std"])
     r.train()
     torch.manual_seed(int(g["seed"]))
@@ -64,7 +64,8 @@ def test_backward_matches_reference_autograd(name):
 
 
 @pytest.mark.parametrize("name,nrays,nsamp", [("small_train_grads", None, None), ("full_train_grads", None, None),
-                                              ("full_train_grads", 37, None), ("full_train_grads", 37, 21)])
+                                              ("full_train_grads", 37, None), ("full_train_grads", 37, 21),
+                                              ("small_train_grads_w2", None, None), ("full_train_grads_w2", None, None)])
 def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
     """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) == autograd of the
     CPU oracle on the same inputs, full tensors."""
@@ -76,8 +77,8 @@ def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
     if nsamp is not None:                      # 37 x 21 = 777 samples: not a multiple of 16 (the weight-gradient kernels' ragged tail)
         for k in ("render:z_vals", "noise", "jitter"):
             g[k] = np.ascontiguousarray(g[k][:, :nsamp])
-    sd = state()
-    r = make_renderer(g)
+    sd = state(name)
+    r = make_renderer(g, name)
     z = g["render:z_vals"]
     R, S = z.shape
     noise = g["noise"] if float(g["raw_noise_std"]) > 0 else None

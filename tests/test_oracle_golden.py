@@ -124,6 +124,22 @@ def test_camera_rays_restatement():
     assert np.array_equal(near[mask], g["near"]) and np.array_equal(far[mask], g["far"])
 
 
+def test_camera_rays_h36m_restatement():
+    """SURVEY.md 8 f-2, Human3.6M convention (BASELINE configs[3]): utils/h36m_utils.py get_rays + get_near_far - numpy
+    restatement vs the reference's own get_rays_within_bounds output, small camera in full and 1024 x 1024 on every 37th pixel"""
+    g = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "camera_rays_h36m.npz"))
+    ro, rd, near, far, mask = O.camera_rays_h36m_np(g["K"], g["R"], g["T"], g["bounds"], int(g["H"]), int(g["W"]))
+    assert np.array_equal(mask, g["mask_at_box"]) and 0 < mask.sum() < mask.size
+    assert np.array_equal(ro, g["ray_o"]) and maxdiff(rd, g["ray_d"]) <= 6e-8
+    assert maxdiff(near[mask], g["near"]) <= 4.8e-7 and maxdiff(far[mask], g["far"]) <= 4.8e-7
+    assert abs(float(np.linalg.norm(rd, axis=1).mean()) - 1.0) < 1e-6          # unit directions (h36m_utils.py:26)
+    ro, rd, near, far, mask = O.camera_rays_h36m_np(g["K2"], g["R"], g["T2"], g["bounds"], int(g["H2"]), int(g["W2"]))
+    p = g["pick2"]
+    assert int(mask.sum()) == int(g["mask2_count"]) and np.array_equal(mask[p], g["mask2"])
+    assert maxdiff(rd[p], g["ray_d2"]) <= 6e-8
+    assert maxdiff(near[p], g["near2"]) <= 4.8e-7 and maxdiff(far[p], g["far2"]) <= 4.8e-7
+
+
 @pytest.mark.parametrize("name", ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2",
                                   "full_train_grads_w2"])
 def test_train_oracle_reproduces_reference_autograd(name):
