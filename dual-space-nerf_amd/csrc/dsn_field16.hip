@@ -45,6 +45,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_SGB_DS
 #define F16_SGB_DS 0          // 1: pin one operand ds_read behind each of the first four MFMAs of a block
 #endif
+#ifndef F16_MIX
+#define F16_MIX 1             // hi / lo split of the pipelined epilogues with v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 (inline asm)
+#endif
 #ifndef F16_PREFETCH
 #define F16_PREFETCH 1        // explicit one-block-ahead LDS operand reads
 #endif
@@ -265,11 +268,37 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
             v = dsn_keep_active(v, mword, r);
         }
         vv[e] = v;
+#if !F16_MIX
         const _Float16 hi = (_Float16)v;
         const float res = fmaf((float)hi, -1.0f, v);
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = FWD ? (_Float16)res : (_Float16)(res * DSN_LO_SCALE);
+#endif
     }
+#if F16_MIX
+    {   // the pair's split in 3 (forward) / 5 (reverse) VALU instructions: packed convert for the hi halves, then the residuals
+        // straight from the packed hi register with v_fma_mix{lo,hi}_f16 (f16 source x f32 constant + f32 addend -> f16 half of
+        // the destination; hipcc emits two converts, two subtractions and a pack for the same thing)
+        const int r = 2 * kb;
+        uint32_t H, L;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H) : "v"(vv[0]), "v"(vv[1]));
+        if (FWD) {
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L) : "v"(H), "v"(vv[0]));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L) : "v"(H), "v"(vv[1]));
+        } else {
+            const float k = -DSN_LO_SCALE;
+            const float s0 = vv[0] * DSN_LO_SCALE, s1 = vv[1] * DSN_LO_SCALE;      // lo = fp16((v - hi) * 2^12) = fp16(hi * -2^12 + v * 2^12)
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(L) : "v"(H), "s"(k), "v"(s0));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L) : "v"(H), "s"(k), "v"(s1));
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 th = __builtin_bit_cast(u32x4, yh[r >> 3]), tl = __builtin_bit_cast(u32x4, yl[r >> 3]);
+        th[(r & 7) >> 1] = H;
+        tl[(r & 7) >> 1] = L;
+        yh[r >> 3] = __builtin_bit_cast(half8, th);
+        yl[r >> 3] = __builtin_bit_cast(half8, tl);
+    }
+#endif
     ovf = FWD ? fmaxf(fmaxf(ovf, vv[0]), vv[1]) : fmaxf(fmaxf(ovf, fabsf(vv[0])), fabsf(vv[1]));   // v_max3_f32 (relu output >= 0)
     // Training stores.  The chunk boundary (w16_boundary: s_waitcnt vmcnt(0) for the LDS-DMA pieces) also waits for every
     // store in flight, and it sits right in front of slice 7 (blocks per output tile = blocks per chunk).  Stores issued slice
@@ -990,24 +1019,28 @@ __device__ __forceinline__ void dense16s(W16& w, int& blk, int lane, const half8
 // two accumulator elements (64 z) -> relu(z) as packed fp16: convert first, then packed max and packed scale by 2^-6
 // (exact; a |64 z| beyond the fp16 range becomes inf and the sample is simply kept for the accurate pass)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ half2v relu_pair16(float u, float v) {
+// `ovf` (range guard): running packed maximum of the activations.  An activation beyond the fp16 range is +inf here, and an
+// inf that meets a negative weight becomes -inf and then 0 in the next ReLU - a FINITE, wrong sigma~; so the overflow is
+// remembered and such a sample is kept for the accurate pass whatever its sigma~ says.
+__device__ __forceinline__ half2v relu_pair16(float u, float v, half2v& ovf) {
     half2v h = {(_Float16)u, (_Float16)v};
     const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
     const half2v s = {(_Float16)F16_FWD_INV, (_Float16)F16_FWD_INV};
     h = __builtin_elementwise_max(h, z);
+    ovf = __builtin_elementwise_max(ovf, h);          // before the exact 2^-6 scaling: 64 z is what has to fit
     return h * s;
 }
-__device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2]) {
+__device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2], half2v& ovf) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(a[r], a[r + 1]) : relu_pair16(a[r] + b[r], a[r + 1] + b[r + 1]);
+        const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(a[r], a[r + 1], ovf) : relu_pair16(a[r] + b[r], a[r + 1] + b[r + 1], ovf);
         y[r >> 3][r & 7] = h[0];
         y[r >> 3][(r & 7) + 1] = h[1];
     }
 }
 template <int NW>
 __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&xh)[8][2],
-                                         half8 (&yh)[8][2]) {
+                                         half8 (&yh)[8][2], half2v& ovf) {
     const int half = lane >> 5;
     f32x16 p0 = zero16(), p1 = zero16();
 #pragma unroll
@@ -1016,13 +1049,13 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
         if (m == 0) dense16s<NW, 8>(w, blk, lane, xh, a0, a1);
         else dense16s<NW, 8>(w, blk, lane, xh, a0, a1, [&](int kb) {
             const int r = 2 * kb;
-            const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(p0[r], p0[r + 1]) : relu_pair16(p0[r] + p1[r], p0[r + 1] + p1[r + 1]);
+            const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(p0[r], p0[r + 1], ovf) : relu_pair16(p0[r] + p1[r], p0[r + 1] + p1[r + 1], ovf);
             yh[m - 1][r >> 3][r & 7] = h[0];
             yh[m - 1][r >> 3][(r & 7) + 1] = h[1];
         });
         p0 = a0; p1 = a1;
     }
-    relu_half16(p0, p1, yh[7]);
+    relu_half16(p0, p1, yh[7], ovf);
 }
 
 // NW = 4: 256 threads, two workgroups per CU (58 KB of LDS each).  NW = 8: ONE workgroup of 512 threads per CU - the same eight
@@ -1066,6 +1099,7 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     int blk = 0;
     half8 ah[8][2], bh[8][2];
     half8 ph[2][2];
+    half2v ovf = {(_Float16)0.0f, (_Float16)0.0f};
     {
         f32x16 pe[2];
 #pragma unroll
@@ -1087,11 +1121,11 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     for (int m = 0; m < 8; ++m) {
         f32x16 a0 = rows16(s_vec, m, half), a1 = zero16();
         dense16s<NW, 2>(w, blk, lane, ph, a0, a1);
-        relu_half16(a0, a1, ah[m]);
+        relu_half16(a0, a1, ah[m], ovf);
     }
-    layer16s<NW>(w, blk, lane, v_b1 + 0 * 256, ah, bh);
-    layer16s<NW>(w, blk, lane, v_b1 + 1 * 256, bh, ah);
-    layer16s<NW>(w, blk, lane, v_b1 + 2 * 256, ah, bh);
+    layer16s<NW>(w, blk, lane, v_b1 + 0 * 256, ah, bh, ovf);
+    layer16s<NW>(w, blk, lane, v_b1 + 1 * 256, bh, ah, ovf);
+    layer16s<NW>(w, blk, lane, v_b1 + 2 * 256, ah, bh, ovf);
     // stage2.0 : [h, pe] -> 256
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -1100,9 +1134,9 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
         half8 qh[2][2];
         qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
         dense16s<NW, 2>(w, blk, lane, qh, a0, a1);
-        relu_half16(a0, a1, ah[m]);
+        relu_half16(a0, a1, ah[m], ovf);
     }
-    layer16s<NW>(w, blk, lane, v_b1 + 4 * 256, ah, bh);
+    layer16s<NW>(w, blk, lane, v_b1 + 4 * 256, ah, bh, ovf);
     // stage2.4 + density head: sigma~ and the magnitude of its terms
     float sg = 0.0f, s1 = 0.0f;
 #pragma unroll
@@ -1123,15 +1157,19 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     const float bd = s_vec[2560];
     sg += bd;
     s1 += fabsf(bd);
+    // range guard: the last layer's activations are fp32 here, every earlier one went through `ovf`
+    float omax = fmaxf((float)ovf[0], (float)ovf[1]);
+    omax = fmaxf(omax, __shfl_xor(omax, 32));
+    const bool in_range = omax < F16_RANGE;              // false for inf (and for the NaN an inf times 0 leaves)
     const bool mine = valid && half == 0;
     // margin: packed[OFF_SCAL + 5] - the conservative default written by dsn_pack_params (F16_SCREEN_REL) or the value
     // dsn_calibrate_screen measured for THESE parameters (10x the largest deviation seen, +inf = never declare anything
     // empty); DSN_SCREEN_MARGIN (experiments) overrides it
     const float margin = margin_override > 0.0f ? margin_override : s_vec[2560 + 5];
-    const bool empty = sg < -(margin * s1 + margin);
+    const bool empty = in_range && sg < -(margin * s1 + margin);
     if (mine) {
         if (empty) sigma[pt] = sg;
-        if (dbg_sigma) { dbg_sigma[pt] = sg; dbg_s1[pt] = s1; }
+        if (dbg_sigma) { dbg_sigma[pt] = in_range ? sg : dsn_nan_flag(); dbg_s1[pt] = in_range ? s1 : dsn_nan_flag(); }
     }
     // audit (DSN_SCREEN_AUDIT): a pseudo-random 1/128 of the samples declared empty go through the accurate pass anyway
     // and are remembered; k_screen_audit then counts those whose accurate density is positive (there must be none)

@@ -178,7 +178,7 @@ def test_field_forward_reverse_equals_single_launch(ctx, name, use_list):
     assert torch.equal(got, want)
     assert torch.equal(gr[want], d_gr[want])
     assert float(gr[~want].abs().sum()) == 0.0
-    assert 0 < n_pos < N          # the fixture exercises both branches
+    assert 0 < n_pos <= N and (n_pos < N or "_w2" in name)          # the fixtures exercise both branches (w2: all sigma > 0)
 
 
 @pytest.mark.parametrize("exhaustive,fp32", [(False, False), (True, False), (False, True)])
@@ -231,7 +231,8 @@ def test_composite(ctx, name):
     raw = g["raw"]
     rgb, disp, acc, w, dep = ctx["lib"].composite(T(raw[..., :3], dev), T(raw[..., 3], dev), None, T(g["z_vals"], dev),
                                                   T(g["ray_d"], dev), noise)
-    assert maxdiff(rgb.cpu().numpy(), g["rgb_map"]) < 2e-6
+    big = lambda k: max(1.0, float(np.abs(g[k]).max()))       # (w3: colours in the hundreds - float32 rounding of the sums)
+    assert maxdiff(rgb.cpu().numpy(), g["rgb_map"]) < 2e-6 * big("rgb_map")
     assert maxdiff(acc.cpu().numpy(), g["acc_map"]) < 2e-6
     assert maxdiff(w.cpu().numpy(), g["weights"]) < 2e-6
     assert maxdiff(dep.cpu().numpy(), g["depth_map"]) < 5e-6
