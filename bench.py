@@ -60,6 +60,9 @@ def parse():
                     help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
                          "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
     ap.add_argument("--train-rays", type=int, default=8192)
+    ap.add_argument("--weights", default="default", choices=["default", "w2", "w3"],
+                    help="parameter set: the hash-generated default, w2 = trained by the real reference (tests/golden/weights_w2.npz, "
+                         "dense near the surface: the density screen calibrates itself off), w3 = large-magnitude hash set")
     ap.add_argument("--strong", action="store_true",
                     help="strong-scaling mode (BASELINE configs[3]): ONE 1024 x 1024 x 128 frame, its rays dealt to the ranks in "
                          "round-robin 3072-ray tiles (RayParallel.tile_indices), rendered pixels all-gathered inside the timed "
@@ -72,6 +75,15 @@ def parse():
                          "the way the reference runs it (3072-ray chunks; 8192-ray training step), nearest-face searches "
                          "excluded - SURVEY 8d baseline (i)")
     return ap.parse_args()
+
+
+def load_weights(synth, name):
+    if name == "w2":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "weights_w2.npz"))
+        return {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    if name == "w3":
+        return synth.make_state_dict(seed=7, gain=3.5)
+    return synth.make_state_dict()
 
 
 def _flush_c_stdio():
@@ -116,7 +128,7 @@ def main():
     S = args.samples
     R = H * W
     canon, faces = synth.make_body()
-    sd = synth.make_state_dict()
+    sd = load_weights(synth, args.weights)
     poses = synth.make_poses(seed=5 + rank)
     xyz = synth.pose_body(canon, seed=3 + rank)          # every rank renders its own frame of the batch
     rays = synth.make_rays(H, W, xyz, fit_box=True)    # every ray crosses the padded body AABB (= mask_at_box rays)
@@ -222,7 +234,7 @@ def main():
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
             "density_screen": not (args.dense or args.fp32 or args.no_screen),
-            "density_screen_calibration": screen_info,
+            "density_screen_calibration": screen_info, "weights": args.weights,
             "accurate_pass_sample_fraction": n_kept / float(R * S),
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,

@@ -226,7 +226,7 @@ class Renderer:
         if packed.screen is None:
             info = packed.calibrate_screen(self.scene)
             self.screen_info = dict(info)
-            if not info["usable"]:
+            if not info["safe"]:
                 warnings.warn("dsnerf_amd: the plain-fp16 density screen deviates by %.3g of the term magnitude for these parameters "
                               "(cap 0.005): it stays off, every non-transparent sample takes the accurate pass" % info["deviation"])
         return packed.screen["usable"]

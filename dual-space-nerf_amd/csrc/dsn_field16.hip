@@ -1272,6 +1272,18 @@ __global__ void k_calib_finish(const uint32_t* __restrict__ acc, float* __restri
     *packed_margin = m;
     if (out4) { out4[0] = d; out4[1] = m; out4[2] = (float)acc[1] / n; out4[3] = n; }
 }
+// how many of the calibration points the screen drops with the margin just set (out4[4] = fraction): tells the caller whether
+// the screen pays for itself on this network (a network that is dense everywhere near the surface keeps every sample)
+__global__ void __launch_bounds__(256) k_calib_dropped(const float* __restrict__ sg, const float* __restrict__ s1, int64_t n,
+                                                       const float* __restrict__ packed_margin, uint32_t* __restrict__ acc) {
+    const float m = *packed_margin;
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c += sg[i] < -(m * s1[i] + m) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(acc + 2, (uint32_t)c);
+}
+__global__ void k_calib_dropped_finish(const uint32_t* __restrict__ acc, float* __restrict__ out, float n) { out[4] = (float)acc[2] / n; }
 size_t dsn_calibrate_workspace_size(int64_t n) { return 256 + dsn_align256(12 * (size_t)n) + 4 * dsn_align256(4 * (size_t)n); }
 void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st) {
     char* p = (char*)workspace;
@@ -1287,6 +1299,10 @@ void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n
     dsn_launch_field(packed, s.frame, x, n, nullptr, nullptr, sig, nullptr, nullptr, st);
     hipLaunchKernelGGL(k_calib_reduce, dim3(1024), dim3(256), 0, st, sg, s1, sig, n, acc);
     hipLaunchKernelGGL(k_calib_finish, dim3(1), dim3(1), 0, st, acc, packed + OFF_SCAL + 5, out4, (float)n);
+    if (out4) {
+        hipLaunchKernelGGL(k_calib_dropped, dim3(1024), dim3(256), 0, st, sg, s1, n, packed + OFF_SCAL + 5, acc);
+        hipLaunchKernelGGL(k_calib_dropped_finish, dim3(1), dim3(1), 0, st, acc, out4, (float)n);
+    }
 }
 __global__ void k_set_scalar(float* p, float v) { *p = v; }
 void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st) {

@@ -66,7 +66,8 @@ void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float*
                       const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                       int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);
 
-// dsn_train.hip: parameter gradients of Renderer.render (layer-wise, rocBLAS GEMMs + element-wise kernels)
+// dsn_train.hip: parameter gradients of Renderer.render / DualSpaceNeRF.forward (fused split-fp16 passes + in-tree fp32 / split-fp16
+// weight-gradient and small-GEMM kernels; no library calls)
 size_t dsn_train_workspace_size(int64_t N);
 // the part of that workspace a training FORWARD fills for its backward (dsn_render_rays_train -> dsn_render_rays_grad)
 struct DsnTrainCache {

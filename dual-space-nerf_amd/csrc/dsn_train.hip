@@ -24,9 +24,7 @@
 // batch, run on the hand-written exact-fp32 MFMA kernel k_t_wgrad below; everything else is element-wise kernels.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
-#include <rocblas/rocblas.h>
 
-#include <mutex>
 
 namespace {
 
@@ -47,41 +45,6 @@ const int kTrunkLd[7] = {87, 256, 256, 256, 319, 256, 256};
 #define W0_PE_COL 8       // stage1.0 input = [code 8 | pe 63 | pose 16]  (model/spacenet.py:125-131)
 #define W0_POSE_COL 71
 #define W4_PE_COL 256     // stage2.0 input = [h 256 | pe 63]              (model/spacenet.py:133-135)
-
-rocblas_handle g_handle = nullptr;
-std::mutex g_handle_mutex;
-
-rocblas_handle blas(hipStream_t st) {
-    std::lock_guard<std::mutex> lock(g_handle_mutex);
-    if (!g_handle) {
-        if (rocblas_create_handle(&g_handle) != rocblas_status_success) { g_handle = nullptr; return nullptr; }
-        rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
-    }
-    if (rocblas_set_stream(g_handle, st) != rocblas_status_success) return nullptr;
-    return g_handle;
-}
-
-// row-major views: X [N,in] (ldx), W [out,in] (ldw, torch Linear layout), Y [N,out] (ldy)
-bool lin_fwd(rocblas_handle h, int N, int in, int out, const float* X, int ldx, const float* W, int ldw, float* Y, int ldy,
-             float beta) {
-    const float one = 1.0f;
-    return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, out, N, in, &one, W, ldw, X, ldx, &beta, Y,
-                         ldy) == rocblas_status_success;
-}
-// dX [N,in] = dY [N,out] W
-bool lin_bwd(rocblas_handle h, int N, int in, int out, const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx,
-             float beta) {
-    const float one = 1.0f;
-    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, in, N, out, &one, W, ldw, dY, ldy, &beta, dX,
-                         ldx) == rocblas_status_success;
-}
-// dW [out,in] += dY^T X
-bool lin_wgrad(rocblas_handle h, int N, int in, int out, const float* X, int ldx, const float* dY, int ldy, float* dW,
-               int ldw) {
-    const float one = 1.0f;
-    return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, in, out, N, &one, X, ldx, dY, ldy, &one, dW,
-                         ldw) == rocblas_status_success;
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // element-wise kernels
@@ -154,28 +117,6 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe_reverse(const float* __restr
         acc += f * (cosf(arg) * d[3 + 6 * j + a] - sinf(arg) * d[6 + 6 * j + a]);
     }
     g[t] = acc;
-}
-
-// (the element-wise kernels below move float4 per thread: C and the totals are multiples of 4)
-__global__ void __launch_bounds__(T_THREADS) k_t_bias_relu(float* __restrict__ z, const float* __restrict__ bias, int C,
-                                                            int64_t total) {
-    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
-    if (t >= total) return;
-    float4 v = *reinterpret_cast<const float4*>(z + t);
-    const float* bp = bias + (int)(t % C);         // parameters come from the caller: no alignment assumed
-    const float4 bb = make_float4(bp[0], bp[1], bp[2], bp[3]);
-    v.x = fmaxf(v.x + bb.x, 0.0f); v.y = fmaxf(v.y + bb.y, 0.0f); v.z = fmaxf(v.z + bb.z, 0.0f); v.w = fmaxf(v.w + bb.w, 0.0f);
-    *reinterpret_cast<float4*>(z + t) = v;
-}
-
-// a = (h > 0) ? a : 0
-__global__ void __launch_bounds__(T_THREADS) k_t_mask(float* __restrict__ a, const float* __restrict__ h, int64_t total) {
-    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
-    if (t >= total) return;
-    float4 v = *reinterpret_cast<const float4*>(a + t);
-    const float4 hh = *reinterpret_cast<const float4*>(h + t);
-    v.x = hh.x > 0.0f ? v.x : 0.0f; v.y = hh.y > 0.0f ? v.y : 0.0f; v.z = hh.z > 0.0f ? v.z : 0.0f; v.w = hh.w > 0.0f ? v.w : 0.0f;
-    *reinterpret_cast<float4*>(a + t) = v;
 }
 
 // out[n,c] = (h[n,c] > 0) ? base[n,c] (optional) + scale[n] (optional, else 1) * w[c] : 0
@@ -1053,6 +994,84 @@ void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, c
     hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_t_lin : Y [N,M] = X [N,K] B  with the small 128 / 256-wide matrices of the lighting MLP and the colour head, exact fp32
+// (v_mfma_f32_32x32x2_f32 = an fp32 fma chain), with the element-wise step that follows each of them fused into the
+// store.  These three products were the last rocBLAS calls of the library (sgemm + a separate bias / mask / seed pass each).
+//   TRANS = false: B = W as stored  ([K,M] row-major: dX = dY W, W = torch Linear weight [out = K, in = M])
+//   TRANS = true : B = W^T          (Y = X W^T, W [M,K]: the forward Linear)
+// One workgroup per CU: B is staged in LDS once (K M floats, up to 128 KB), then every wave walks 32-row tiles of X: the A
+// operand (lane = row, half-wave = k parity group) comes as ONE float4 per 8 k-values - a contraction does not care about the
+// order of k, so step s of a group takes k0 + s from the low half-wave and k0 + 4 + s from the high one - and the B operand
+// from LDS (lanes = consecutive columns: conflict-free).  The accumulator layout puts 32 consecutive columns of one row in the
+// lanes of a half-wave, so every store instruction writes two full 128-byte row segments.
+// Epilogues: EPI_NONE; EPI_BIAS_RELU y = relu(y + bias[c]); EPI_MASK y = msrc[n,c] > 0 ? y : 0;
+//            EPI_SEED y = msrc[n,c] > 0 ? y + sc[n] wv[c] : 0   (the seed of the adjoint pass, what k_t_seed did on top of the GEMM)
+// ------------------------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_SEED = 3 };
+template <int K, int M, bool TRANS, int EPI>
+__global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
+                                                  int64_t N, const float* __restrict__ bias_or_wv, const float* __restrict__ msrc,
+                                                  const float* __restrict__ sc) {
+    __shared__ float sB[K * M];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * M; i += 256) {
+        const int k = i / M, m = i % M;
+        sB[i] = TRANS ? W[m * K + k] : W[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int64_t ntile = (N + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 32;
+        int64_t arow = row0 + col;
+        if (arow >= N) arow = N - 1;
+        const float* xr = X + arow * K + 4 * half;
+        t_f32x16 acc[M / 32];
+#pragma unroll
+        for (int t = 0; t < M / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        float4 a = *reinterpret_cast<const float4*>(xr);
+#pragma unroll
+        for (int kg = 0; kg < K / 8; ++kg) {
+            const float4 an = *reinterpret_cast<const float4*>(xr + 8 * (kg + 1 < K / 8 ? kg + 1 : kg));    // one group ahead
+            const float* brow = sB + (kg * 8 + 4 * half) * M + col;
+#define T_LIN_STEP(AV, S)                                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < M / 32; ++t)                                                                         \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV), brow[(S) * M + 32 * t], acc[t], 0, 0, 0);
+            T_LIN_STEP(a.x, 0) T_LIN_STEP(a.y, 1) T_LIN_STEP(a.z, 2) T_LIN_STEP(a.w, 3)
+#undef T_LIN_STEP
+            a = an;
+        }
+        // store: register r of lane (col, half) = row (r & 3) + 8 (r >> 2) + 4 half, column 32 t + col
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= N) continue;
+            float scn = 0.0f;
+            if (EPI == EPI_SEED) scn = sc[row];
+#pragma unroll
+            for (int t = 0; t < M / 32; ++t) {
+                const int c = 32 * t + col;
+                float v = acc[t][r];
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias_or_wv[c], 0.0f);
+                if (EPI == EPI_MASK) v = msrc[row * M + c] > 0.0f ? v : 0.0f;
+                if (EPI == EPI_SEED) v = msrc[row * M + c] > 0.0f ? v + scn * bias_or_wv[c] : 0.0f;
+                Y[row * M + c] = v;
+            }
+        }
+    }
+}
+template <int K, int M, bool TRANS, int EPI>
+void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_or_wv, const float* msrc, const float* sc, hipStream_t st) {
+    const int64_t ntile = (N + 31) / 32;
+    int groups = (int)((ntile + 3) / 4);
+    if (groups > 256) groups = 256;               // one workgroup per CU: B is staged once per workgroup
+    hipLaunchKernelGGL((k_t_lin<K, M, TRANS, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, W, Y, N, bias_or_wv, msrc, sc);
+}
+
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
@@ -1148,9 +1167,6 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     const bool module = ext_x_c != nullptr;
     const int64_t N64 = (int64_t)R * S;
     if (N64 > (int64_t)1 << 30) return "batch too large for the 32-bit GEMM interface";
-    const int N = (int)N64;
-    rocblas_handle h = blas(st);
-    if (!h) return "rocBLAS handle";
     TrainWs w = carve(workspace, N64);
     {
         TrainZero z;
@@ -1180,8 +1196,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     if (!cached) {      // (the training forward's k_light16 has left hl1, hl2 and pre in this workspace otherwise)
         hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
                            N64, 256, w.hl1);
-        T_CHECK(lin_fwd(h, N, 128, 128, w.hl1, 128, prm[P_L2_W], 128, w.hl2, 128, 0.0f));
-        hipLaunchKernelGGL(k_t_bias_relu, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L2_B], 128, N64 * 128);
+        lin<128, 128, true, EPI_BIAS_RELU>(w.hl1, prm[P_L2_W], w.hl2, N64, prm[P_L2_B], nullptr, nullptr, st);   // hl2 = relu(hl1 W2^T + b2)
         hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
     }
     hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
@@ -1200,8 +1215,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                        w.d_hl2);
     T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B]));
-    T_CHECK(lin_bwd(h, N, 128, 128, w.d_hl2, 128, prm[P_L2_W], 128, w.d_hl1, 128, 0.0f));
-    hipLaunchKernelGGL(k_t_mask, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_hl1, w.hl1, N64 * 128);
+    lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B]));
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
                        w.d_xl);
@@ -1233,8 +1247,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                        w.d_rr);
     T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B]));
     wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
-    T_CHECK(lin_bwd(h, N, 256, 128, w.d_rr, 128, prm[P_RGB1_W], 256, cur, 256, 0.0f));
-    hipLaunchKernelGGL(k_t_seed, grid_for((tot) / 4), dim3(T_THREADS), 0, st, w.h[6], prm[P_DEN_W], d_sig, cur, 256, tot, cur);
+    // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in
+    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;

@@ -187,8 +187,9 @@ DSN_EXPORT int dsn_field_screen(const void* scene, int V, int F, const void* pac
  * (0.01); dsn_calibrate_screen measures it for the packed parameters and the scene's current frame state - n_points points
  * around the canonical surface, screen vs exact-fp32 density, margin = max(10 x the largest deviation |sigma~ - sigma| /
  * (S1 + 1), 0.002), or +inf (nothing is ever declared empty) when that exceeds 0.05 - and writes it into `packed`, all on the
- * stream.  out4 (device, optional) = {largest deviation, margin, fraction of points the screen overflowed on, n_points}.
- * dsn_set_screen_margin sets it by hand.  workspace: dsn_calibrate_workspace_bytes(n_points). */
+ * stream.  out (device, optional, 8 floats) = {largest deviation, margin, fraction of points the screen overflowed on,
+ * n_points, fraction of the points the screen drops with that margin (the caller's cue whether the screen pays: it costs
+ * ~0.3 of an accurate forward pass per sample), 0, 0, 0}.  dsn_set_screen_margin sets it by hand.  workspace: dsn_calibrate_workspace_bytes(n_points). */
 DSN_EXPORT size_t dsn_calibrate_workspace_bytes(int64_t n_points);
 DSN_EXPORT int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t n_points, void* workspace, float* out4,
                          void* stream);

@@ -193,7 +193,10 @@ def test_screen_calibration_bounds_the_frame(wname):
     r._set_frame(batch)
     packed = r.net.packed(r.device)
     info = packed.calibrate_screen(r.scene)
-    assert info["usable"] and 0.002 <= info["margin"] <= 0.05 and info["overflow_fraction"] < 0.5, info
+    assert info["safe"] and 0.002 <= info["margin"] <= 0.05 and info["overflow_fraction"] < 0.5, info
+    # the screen pays only where it drops a good share of the samples: the default set yes, the trained set (dense near the
+    # surface: every calibration point has sigma > 0) no - Renderer leaves it off there
+    assert info["usable"] == (info["dropped_fraction"] >= 0.35) and (wname != "" or info["usable"]) and (wname != "_w2" or not info["usable"]), info
     S = 64
     o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
     n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
@@ -210,7 +213,8 @@ def test_screen_calibration_bounds_the_frame(wname):
     empty = ok & (sg < -(m * s1 + m))
     assert int((empty & (sig >= 0)).sum()) == 0
     assert m >= 4.0 * dev_frame, (m, dev_frame, info)
-    print(f"weights '{wname}': calibration deviation {info['deviation']:.2e} -> margin {m:.2e}; frame deviation {dev_frame:.2e}; "
+    print(f"weights '{wname}': calibration deviation {info['deviation']:.2e} -> margin {m:.2e} (drops {info['dropped_fraction']:.2f} of the "
+          f"calibration points); frame deviation {dev_frame:.2e}; "
           f"{float(empty.float().mean()):.3f} of {act.numel()} evaluated samples declared empty")
     outs = []
     for screen in (True, False):
@@ -245,7 +249,7 @@ def test_pathological_network_switches_the_screen_off():
     r.eval()
     with pytest.warns(UserWarning, match="density screen"):
         out = r.render(dict(batch))["coarse"]
-    assert r.screen_info is not None and not r.screen_info["usable"] and r.screen_info["deviation"] > 0.005, r.screen_info
+    assert r.screen_info is not None and not r.screen_info["safe"] and not r.screen_info["usable"] and r.screen_info["deviation"] > 0.005, r.screen_info
     r.density_screen = False
     ref = r.render(dict(batch))["coarse"]
     for k in ("color", "acc_map", "depth_map", "weights"):
