@@ -274,19 +274,16 @@ __device__ __forceinline__ void dsn_layer_bwd(DsnWStream& ws, const f32x16 (&in)
 #define FIELD_THREADS 256
 #define FIELD_PTS_PER_BLOCK 128
 
-__global__ void __launch_bounds__(FIELD_THREADS, 1)
-k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
-        int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
+// one wave's 32 points starting at list slot `slot0` (< count, wave-uniform)
+__device__ __forceinline__ void
+k_field_wave(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
+             const int32_t* __restrict__ active_list, int64_t count, int64_t slot0,
+             float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
     // fix_nan != 0: the range fallback of the split-fp16 kernels (dsn_field16.hip).  A sample whose activations left the
-    // fp16 range there carries sigma = NaN; this launch re-evaluates exactly those samples (waves without one leave at
+    // fp16 range there carries sigma = NaN; this launch re-evaluates exactly those samples (waves without one move on at
     // once, the other lanes of a wave with one compute but do not write) - sigma, essence and d sigma/dx in exact fp32.
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
-    const int64_t count = active_list ? (int64_t)(*active_count) : N;
-    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (slot0 >= count) return;   // wave-uniform
     int64_t slot = slot0 + (lane & 31);
     bool valid = slot < count;
     if (!valid) slot = count - 1;
@@ -436,6 +433,28 @@ k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, 
     }
 }
 
+__global__ void __launch_bounds__(FIELD_THREADS, 1)
+k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
+        int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
+        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    // normal launches: one 128-point tile per workgroup.  The range fallback (fix_nan) is launched with a small grid that
+    // strides over the list: it normally finds nothing, and 131 072 workgroups that only look cost 0.14 ms per frame
+#pragma nounroll
+    for (int64_t blk = blockIdx.x;; blk += gridDim.x) {
+        const int64_t slot0 = (blk * 4 + wave) * 32;
+        if (slot0 >= count) return;   // wave-uniform
+        // (the pointers are laundered through an empty asm: otherwise the loop-invariant loads of biases and head vectors
+        //  are hoisted out of the loop and the kernel spills thousands of registers)
+        const float* pk = packed;
+        const DsnFrameState* f = fs;
+        asm volatile("" : "+s"(pk), "+s"(f));
+        k_field_wave(pk, f, x_c, active_list, count, slot0, sigma, essence, grad, fix_nan);
+        if (!fix_nan) return;
+    }
+}
+
 void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                       const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                       float* grad, hipStream_t st) {
@@ -450,6 +469,7 @@ void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const fl
                           float* grad, hipStream_t st) {
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
+    if (blocks > 2048) blocks = 2048;        // grid-stride (see k_field)
     hipLaunchKernelGGL(k_field, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
                        active_count, sigma, essence, grad, 1);
 }

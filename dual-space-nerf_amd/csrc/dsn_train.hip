@@ -1014,53 +1014,89 @@ template <int K, int M, bool TRANS, int EPI>
 __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
                                                   int64_t N, const float* __restrict__ bias_or_wv, const float* __restrict__ msrc,
                                                   const float* __restrict__ sc) {
-    __shared__ float sB[K * M];
+    constexpr int NT = M / 32, NQ = NT / 4;
+    // B in LDS as [k][quad of column tiles][column in tile][tile in quad]: the 4 column tiles a lane feeds with one k come
+    // back with ONE ds_read_b128 (lanes 16 bytes apart: conflict-free)
+    __shared__ __attribute__((aligned(16))) float sB[K * M];
+    __shared__ float sV[M];
     const int tid = threadIdx.x;
     for (int i = tid; i < K * M; i += 256) {
-        const int k = i / M, m = i % M;
-        sB[i] = TRANS ? W[m * K + k] : W[i];
+        const int k = i / M, m = i % M, t = m >> 5, c = m & 31;
+        sB[((k * NQ + (t >> 2)) * 32 + c) * 4 + (t & 3)] = TRANS ? W[m * K + k] : W[i];
     }
+    if (EPI == EPI_BIAS_RELU || EPI == EPI_SEED)
+        for (int i = tid; i < M; i += 256) sV[i] = bias_or_wv[i];
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int64_t ntile = (N + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row0 = tile * 32;
-        int64_t arow = row0 + col;
-        if (arow >= N) arow = N - 1;
-        const float* xr = X + arow * K + 4 * half;
-        t_f32x16 acc[M / 32];
+        // D[feature][point] = sum_k B[k][feature] X[point][k]: lane = point `col`, registers = features
+        const int64_t prow = tile * 32 + col;
+        const bool valid = prow < N;
+        const int64_t crow = valid ? prow : N - 1;
+        const float* xr = X + crow * K + 4 * half;
+        // what the epilogue needs from memory is requested NOW and used after the products: its latency hides behind them
+        float4 mk[EPI == EPI_MASK || EPI == EPI_SEED ? NT : 1][4];
+        float scn = 0.0f;
+        if (EPI == EPI_MASK || EPI == EPI_SEED) {
+            const float* mr = msrc + crow * M + 4 * half;
 #pragma unroll
-        for (int t = 0; t < M / 32; ++t)
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mk[t][q] = *reinterpret_cast<const float4*>(mr + 32 * t + 8 * q);
+            if (EPI == EPI_SEED) scn = sc[crow];
+        }
+        t_f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         float4 a = *reinterpret_cast<const float4*>(xr);
+        const float4* wb = reinterpret_cast<const float4*>(sB) + (4 * half) * NQ * 32 + col;   // + (8 kg + s) * NQ * 32 + 32 tq
+        float4 wc[NQ];
+#pragma unroll
+        for (int tq = 0; tq < NQ; ++tq) wc[tq] = wb[32 * tq];
 #pragma unroll
         for (int kg = 0; kg < K / 8; ++kg) {
             const float4 an = *reinterpret_cast<const float4*>(xr + 8 * (kg + 1 < K / 8 ? kg + 1 : kg));    // one group ahead
-            const float* brow = sB + (kg * 8 + 4 * half) * M + col;
-#define T_LIN_STEP(AV, S)                                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < M / 32; ++t)                                                                         \
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV), brow[(S) * M + 32 * t], acc[t], 0, 0, 0);
-            T_LIN_STEP(a.x, 0) T_LIN_STEP(a.y, 1) T_LIN_STEP(a.z, 2) T_LIN_STEP(a.w, 3)
-#undef T_LIN_STEP
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep) {
+                const int nxt = kg * 8 + sstep + 1 < K - 4 ? (sstep < 3 ? kg * 8 + sstep + 1 : kg * 8 + 8) : kg * 8 + sstep;
+                float4 wn[NQ];
+#pragma unroll
+                for (int tq = 0; tq < NQ; ++tq) wn[tq] = wb[nxt * NQ * 32 + 32 * tq];       // one step ahead
+#pragma unroll
+                for (int tq = 0; tq < NQ; ++tq) {
+                    acc[4 * tq + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tq].x, av[sstep], acc[4 * tq + 0], 0, 0, 0);
+                    acc[4 * tq + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tq].y, av[sstep], acc[4 * tq + 1], 0, 0, 0);
+                    acc[4 * tq + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tq].z, av[sstep], acc[4 * tq + 2], 0, 0, 0);
+                    acc[4 * tq + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tq].w, av[sstep], acc[4 * tq + 3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tq = 0; tq < NQ; ++tq) wc[tq] = wn[tq];
+            }
             a = an;
         }
-        // store: register r of lane (col, half) = row (r & 3) + 8 (r >> 2) + 4 half, column 32 t + col
+        // store: registers 4 q .. 4 q + 3 of tile t = features 32 t + 8 q + 4 half + (0..3) of this lane's point: float4
+        if (valid) {
+            float* yr = Y + prow * M + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row >= N) continue;
-            float scn = 0.0f;
-            if (EPI == EPI_SEED) scn = sc[row];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < M / 32; ++t) {
-                const int c = 32 * t + col;
-                float v = acc[t][r];
-                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias_or_wv[c], 0.0f);
-                if (EPI == EPI_MASK) v = msrc[row * M + c] > 0.0f ? v : 0.0f;
-                if (EPI == EPI_SEED) v = msrc[row * M + c] > 0.0f ? v + scn * bias_or_wv[c] : 0.0f;
-                Y[row * M + c] = v;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * t + 8 * q + 4 * half;
+                    float v[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                    const float m4[4] = {mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].x, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].y,
+                                         mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].z, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e] + sV[f0 + e], 0.0f);
+                        if (EPI == EPI_MASK) v[e] = m4[e] > 0.0f ? v[e] : 0.0f;
+                        if (EPI == EPI_SEED) v[e] = m4[e] > 0.0f ? v[e] + scn * sV[f0 + e] : 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(yr + 32 * t + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
         }
     }
 }
