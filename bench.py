@@ -665,10 +665,10 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
 
 def measured_traffic(kern, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc.json, written by scripts/pmc_summary.py: (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction
-    of MI355X_MICROARCH.md); null when the counters were not collected for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or not os.path.exists(path):
+    (profiles/r02_pmc.json, written by scripts/pmc_summary.py from scripts/gpu_round2.sh: (2*FETCH_SIZE + WRITE_SIZE) KB,
+    the gfx950 correction of MI355X_MICROARCH.md); null when the counters were not collected for this configuration."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or args.weights != "default" or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f).get(kern)
@@ -709,7 +709,7 @@ def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     R = rays["ray_o"].shape[0]
-    n = 3072
+    n = 1024                     # a third of the reference's 3072-ray chunk: ~15 s on the GPU boxes' 256 host threads
     sel = np.arange(R // 2, R // 2 + n)
     tv = torch.linspace(0.0, 1.0, steps=S).numpy()
     params = {k: torch.from_numpy(v) for k, v in sd.items()}
@@ -723,10 +723,9 @@ def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
         TO.render(params, g, jitter_z=z)
         return time.perf_counter() - t0
 
-    run()
     dt = run()
     return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"one {n}-ray chunk of the same frame x {S} samples, torch {torch.__version__} CPU ops with {cores} threads "
+            "sample": f"{n} consecutive rays of the same frame x {S} samples, torch {torch.__version__} CPU ops with {cores} threads "
                       f"(networks, autograd d sigma/dx, normals, lighting, compositing) + C-oracle geometry, {dt:.1f} s"}
 
 
