@@ -6,8 +6,8 @@
 // and  W.x  is evaluated as   (W_hi x_hi)  +  2^-12 (W_hi x_lo + W_lo x_hi)   with
 // v_mfma_f32_32x32x16_f16 (fp32 accumulate; products of fp16 are exact in fp32).  The dropped
 // W_lo x_lo term is 2^-24 relative - the size of one fp32 rounding.  Measured against the float64
-// reference this is as accurate as the reference's own float32 run (tests/test_gpu_field16.py;
-// sigma 6e-6 abs).  Plain bf16 / fp16 inputs miss the 1e-4 bar by 10x, bf16 2-way split by 1.4x.
+// reference this is as accurate as the reference's own float32 run (tests/test_gpu_stages.py::test_field;
+// sigma 8e-6 abs).  Plain bf16 / fp16 inputs miss the 1e-4 bar by 10x, bf16 2-way split by 1.4x.
 // Range: the reverse pass runs on g * 2^-6 (exact rescale at the end) so that |g| up to 4e6 stays
 // inside fp16; forward activations must stay below 65504 (they are O(10) for NeRF trunks).  Every epilogue keeps a
 // running maximum of the values it splits (one v_max3 per two elements); a sample that reaches F16_RANGE anywhere is

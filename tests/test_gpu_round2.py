@@ -615,3 +615,64 @@ def test_ray_parallel_over_rccl_world_size_one():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs at their own sizes ("not covered at size")
+# ------------------------------------------------------------------------------------------------------------------------
+def _oracle_subset(batch, canon, faces, sd, S, sel, code, **kw):
+    o, d = batch["ray_o"][0].numpy(), batch["ray_d"][0].numpy()
+    n, f = batch["near"][0].numpy().copy(), batch["far"][0].numpy().copy()
+    return O.render(o[sel], d[sel], n[sel], f[sel], S, batch["xyz"][0].numpy(), canon, faces, O.Params(sd), batch["poses"][0].numpy(),
+                    code, t_vals=torch.linspace(0.0, 1.0, steps=S).numpy(), **kw)
+
+
+def test_config0_frame_128x128_at_32_samples():
+    """BASELINE configs[0] as a frame: 128 x 128 rays x 32 samples through Renderer.render_view (below the cell-major threshold:
+    the per-lane nearest-face path), against the oracle on 512 rays spread over the image + size-independent properties"""
+    canon, faces, batch = full_frame(hw=128)
+    S = 32
+    r = renderer_with(state(), canon, faces, S=S)
+    r.eval()
+    out = r.render_view(dict(batch), device_output=True)
+    col = out["coarse_color"].reshape(-1, 3)
+    acc = out["coarse_acc"].reshape(-1)
+    assert torch.isfinite(col).all() and float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5 and float(acc.max()) > 0.05
+    sel = np.linspace(0, 128 * 128 - 1, 512).astype(np.int64)
+    sd = state()
+    e = _oracle_subset(batch, canon, faces, sd, S, sel, sd["nerf.embedding.weight"][5])
+    assert maxdiff(col[torch.from_numpy(sel).cuda()].cpu().numpy(), e["color"]) < 1e-4
+    assert maxdiff(acc[torch.from_numpy(sel).cuda()].cpu().numpy(), e["acc_map"]) < 1e-4
+
+
+def test_novel_pose_relighting_at_512():
+    """BASELINE configs[4]'s knobs at the metric's frame size: test.py:193-196 (net.nerf.w = 0, set_light_center) and
+    vis_lighting.py:57-58 (set_rot / set_rot_center) on a 512 x 512 x 64 frame: the oracle on 768 rays with the frame code
+    zeroed and the light edits, screen on / off bit-identical"""
+    canon, faces, batch = full_frame(hw=512, seed=7, pose_seed=13)
+    S = 64
+    r = renderer_with(state(), canon, faces, S=S)
+    lc = torch.tensor([0.35, 0.05, 1.4])
+    ang = 0.7
+    rot = torch.tensor([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]], dtype=torch.float32)
+    rc = torch.tensor([[0.2, -0.1, 1.0]])
+    r.net.set_light_center(lc)
+    r.net.nerf.w = 0
+    r.net.set_rot_center(rc)
+    r.net.set_rot(rot)
+    r.eval()
+    out = {k: v.clone() for k, v in r.render(dict(batch))["coarse"].items()}
+    assert torch.isfinite(out["color"]).all() and float(out["acc_map"].max()) > 0.05
+    r.density_screen = False
+    ref = r.render(dict(batch))["coarse"]
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(out[k], ref[k]), k
+    sel = np.linspace(0, 512 * 512 - 1, 768).astype(np.int64)
+    sd = state()
+    th = batch["Th"][0].reshape(-1, 3).mean(0).numpy()
+    e = _oracle_subset(batch, canon, faces, sd, S, sel, sd["nerf.embedding.weight"][5] * 0, light_shift=lc.numpy() - th,
+                       rot=rot.numpy(), rot_center=rc.numpy()[0, :2])
+    si = torch.from_numpy(sel).cuda()
+    assert np.array_equal(out["z_vals"][si].cpu().numpy(), e["z_vals"])
+    assert maxdiff(out["color"][si].cpu().numpy(), e["color"]) < 1e-4
+    assert maxdiff(out["weights"][si].cpu().numpy(), e["weights"]) < 1e-4
