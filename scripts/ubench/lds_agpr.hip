@@ -1,0 +1,78 @@
+// microbenchmark: does it matter WHERE the LDS operand reads of k_field16's inner loop land?
+//   4 ds_read_b128 + 6 v_mfma_f32_32x32x16_f16 per 4 KB weight block, one wave per SIMD (256 threads, 1 workgroup / CU)
+//   variant V: operand reads into VGPRs, one block ahead          (what the kernel does: the 245-256 cycle floor of round 1)
+//   variant A: operand reads into AGPRs (ds_read_b128 a[..]), MFMA A operand read from the AGPRs, one block ahead
+//   variant A2 / V2: the same two blocks ahead
+//   variant M: MFMAs only (192-cycle floor at the clock the chip holds)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define BLOCKS 64
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+template <int AG, int DEPTH, int READS>
+__global__ void __launch_bounds__(256, 1) k(float* out, int reps) {
+    __shared__ __attribute__((aligned(16))) char ring[65536];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += 256) ((float*)ring)[i] = (float)(i & 7) * 0.001f;
+    __syncthreads();
+    f32x16 a0 = {0}, a1 = {0};
+    half8 x = {0};
+    for (int j = 0; j < 8; ++j) x[j] = (_Float16)(0.01f * (lane + j));
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    half8 q[DEPTH + 1][4];
+#pragma unroll
+    for (int d = 0; d <= DEPTH; ++d)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[d][p] = x;
+    for (int it = 0; it < reps; ++it) {
+#pragma unroll
+        for (int b = 0; b < BLOCKS; ++b) {
+            const int slot = (b + DEPTH) % (DEPTH + 1);      // register set the block b + DEPTH lands in
+            const int cur = b % (DEPTH + 1);
+            const unsigned a = base + (b & 15) * 4096;
+            if (READS) {
+                if (AG)
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                                 : "=a"(q[slot][0]), "=a"(q[slot][1]), "=a"(q[slot][2]), "=a"(q[slot][3]) : "v"(a) : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                                 : "=v"(q[slot][0]), "=v"(q[slot][1]), "=v"(q[slot][2]), "=v"(q[slot][3]) : "v"(a) : "memory");
+                if (DEPTH == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            }
+            a0 = MFMA(q[cur][0], x, a0);
+            a1 = MFMA(q[cur][1], x, a1);
+            a0 = MFMA(q[cur][0], x, a0);
+            a1 = MFMA(q[cur][2], x, a1);
+            a0 = MFMA(q[cur][3], x, a0);
+            a1 = MFMA(q[cur][2], x, a1);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    if (s == 123.456f) out[0] = s;
+}
+template <int AG, int DEPTH, int READS> void run(const char* name, float* d, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<AG, DEPTH, READS>), dim3(256 * 4), dim3(256), 0, 0, d, 1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<AG, DEPTH, READS>), dim3(256 * 4), dim3(256), 0, 0, d, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double us = ms * 1e3 / (4.0 * reps * BLOCKS);
+    printf("%-44s %8.3f ms  %.4f us / block / wave = %.0f cycles @2.1 GHz (6 MFMA = 192)\n", name, ms, us, us * 2100); fflush(stdout);
+}
+int main() {
+    float* d; hipMalloc(&d, 1024);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, 1, 0>("M : MFMA only", d, 40);
+        run<0, 1, 1>("V : reads -> VGPR, 1 block ahead", d, 40);
+        run<1, 1, 1>("A : reads -> AGPR, 1 block ahead", d, 40);
+        run<0, 2, 1>("V2: reads -> VGPR, 2 blocks ahead", d, 40);
+        run<1, 2, 1>("A2: reads -> AGPR, 2 blocks ahead", d, 40);
+    }
+    return 0;
+}
