@@ -329,7 +329,7 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
     rp = dsnerf_amd.RayParallel()
     idx_of = [rp.tile_indices(R, 3072, r) for r in range(world)]
     mine = idx_of[rank].numpy()
-    slab = max(int(i.numel()) for i in idx_of)
+    slab = rp.tile_slab(R, 3072)
     packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
     scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
     ws = _lib.RenderWorkspace(dev)
@@ -362,7 +362,7 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
         px[:Rl, 5] = out["depth_map"]
         if use_dist:
             dist.all_gather_into_tensor(allp, px)
-            for r_ in range(world):
+            for r_ in range(world):                  # = RayParallel.undeal_tiles with the index tensors kept on the device
                 full[dev_idx[r_]] = allp[r_ * slab: r_ * slab + dev_idx[r_].numel()]
         else:
             full[dev_idx[0]] = px[:Rl]

@@ -464,11 +464,18 @@ class Renderer:
         img = self._view_images(batch, chunk, self.scene, self._ws)
         if device_output:
             return img
-        # four contiguous device images -> four device->host copies (0.1-0.3 ms each).  Packing them into one [H,W,6] copy and
-        # splitting the channels on the host cost 19-25 ms per frame on the GPU boxes (strided CPU copies; scripts/d2h_probe.py)
-        # (fresh host tensors like the reference's; on the GPU boxes first-touch page faults of new host memory make this step
-        # vary between 1 and 20 ms per frame - `device_output=True` avoids it)
-        return {k: img[k].contiguous().cpu() for k in ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")}
+        # four contiguous device images -> one persistent page-locked staging set (asynchronous copies, one synchronisation),
+        # then fresh host tensors like the reference's `.cpu()` results.  A pageable `.cpu()` per image goes through the runtime's
+        # own bounce buffers and varies between 1 and 20 ms per frame on the GPU boxes (scripts/d2h_probe.py);
+        # `device_output=True` avoids the host side altogether.
+        keys = ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")
+        stage = getattr(self, "_d2h_stage", None)
+        if stage is None or any(stage[k].shape != img[k].shape for k in keys):
+            stage = self._d2h_stage = {k: torch.empty(img[k].shape, dtype=torch.float32).pin_memory() for k in keys}
+        for k in keys:
+            stage[k].copy_(img[k], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return {k: stage[k].clone() for k in keys}
 
     def render_views(self, batches, frames_in_flight=2, device_output=True, chunk=None):
         """The per-frame loop of novel_pose_vis.py:41-66 / test.py:55-64 (`for batch in loader: render.render_view(batch)`) as

@@ -51,6 +51,19 @@ class RayParallel:
         idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
         return idx[idx < R]
 
+    def tile_slab(self, R: int, tile: int = 3072) -> int:
+        """rows of the equal slabs the ranks exchange (= the largest share; rank 0 owns the most)"""
+        return max(self.tile_indices(R, tile, r).numel() for r in range(self.world))
+
+    def undeal_tiles(self, gathered: torch.Tensor, R: int, tile: int = 3072, out: torch.Tensor = None) -> torch.Tensor:
+        """gathered [world * slab, C] (rank-major slabs as all_gather_into_tensor leaves them) -> [R, C] in ray order"""
+        slab = gathered.shape[0] // self.world
+        full = out if out is not None else torch.empty(R, gathered.shape[1], dtype=gathered.dtype, device=gathered.device)
+        for r in range(self.world):
+            ir = self.tile_indices(R, tile, r).to(gathered.device)
+            full[ir] = gathered[r * slab: r * slab + ir.numel()]
+        return full
+
     def render_tiled(self, render_fn, ray_o, ray_d, near, far, tile: int = 3072):
         """like render(), with the round-robin tile partition.  NOTE: the geometry-guided sampler takes the FIRST ray's
         origin for the whole batch (utils/pts_utils.py:31), so this is meant for rays of one camera."""
@@ -65,16 +78,48 @@ class RayParallel:
         if self.world == 1:
             full = packed
         else:
-            slab = max(self.tile_indices(R, tile, r).numel() for r in range(self.world))   # rank 0 owns the most
+            slab = self.tile_slab(R, tile)
             pad = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
             pad[: packed.shape[0]] = packed
             allp = torch.empty(self.world * slab, 6, dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(allp, pad, group=self.group)
-            full = torch.empty(R, 6, dtype=torch.float32, device=dev)
-            for r in range(self.world):
-                ir = self.tile_indices(R, tile, r).to(dev)
-                full[ir] = allp[r * slab: r * slab + ir.numel()]
+            full = self.undeal_tiles(allp, R, tile)
         return {"color": full[:, 0:3], "disp_map": full[:, 3], "acc_map": full[:, 4], "depth_map": full[:, 5]}
+
+    # ---- multi-frame batches (BASELINE configs[4]: novel-pose sequences, novel_pose_vis.py:41-66) ----
+    def frames_of(self, n_frames: int, rank: int = None):
+        """frame indices of `rank` (default: this rank): frames are dealt round-robin, frame f -> rank f % world"""
+        rank = self.rank if rank is None else rank
+        return list(range(rank, n_frames, self.world))
+
+    def render_frames(self, render_frame_fn, n_frames: int, pixels: int, channels: int = 6):
+        """Every rank renders its frames of a sequence (render_frame_fn(f) -> [pixels, channels] device tensor, e.g. the packed
+        rgb / disp / acc / depth image of Renderer.render_view(device_output=True)); after each round of `world` frames ONE
+        all_gather_into_tensor brings that round's images to every rank - issued asynchronously, so the exchange of round k
+        overlaps the rendering of round k + 1.  Returns the list of n_frames images in sequence order on every rank."""
+        rounds = (n_frames + self.world - 1) // self.world
+        outs, works = [], []
+        dev = None
+        for r in range(rounds):
+            f = r * self.world + self.rank
+            img = render_frame_fn(f) if f < n_frames else None
+            if dev is None:
+                if img is None:
+                    raise ValueError("render_frames: more ranks than frames")
+                dev = img.device
+            if img is None:
+                img = torch.zeros(pixels, channels, dtype=torch.float32, device=dev)
+            img = img.reshape(pixels, channels).contiguous()
+            if self.world == 1:
+                outs.append(img[None])
+                continue
+            buf = torch.empty(self.world, pixels, channels, dtype=img.dtype, device=dev)
+            works.append(dist.all_gather_into_tensor(buf.reshape(self.world * pixels, channels), img, group=self.group, async_op=True))
+            outs.append(buf)
+        for w in works:
+            w.wait()
+        frames = [outs[f // self.world][f % self.world] for f in range(n_frames)]
+        return frames
 
     def render(self, render_fn, ray_o, ray_d, near, far):
         """render_fn(ray_o, ray_d, near, far) -> dict(color [r,3], disp_map [r], acc_map [r], depth_map [r])

@@ -120,11 +120,42 @@ def other_weight_sets():
         stage_case("full_eval_" + tag, canon, faces, xyz, poses, rays, sel, 64, state)
 
 
+def uniform_mode():
+    """cfg.MODEL.sample_points_mode = "uniform" (can_render.py:42-51, utils/pts_utils.py:3-16): Renderer.render of the real
+    reference with plain uniform sampling between the batch's near / far, eval and train (jitter + noise, seed 233)"""
+    import torch
+
+    torch.set_num_threads(8)
+    state = synth.make_state_dict()
+    poses = synth.make_poses()
+    canon_s, faces_s = synth.make_small_body()
+    xyz_s = synth.pose_body(canon_s)
+    rays_s = synth.make_rays(8, 8, xyz_s, cam_dist=2.2, focal_frac=2.0)
+    sel = np.arange(64)
+    arrs = inputs_dict(canon_s, faces_s, xyz_s, poses, rays_s, sel, 16)
+    for train in (False, True):
+        render = rh.build_reference(canon_s, faces_s, state, 16)
+        render.cfg.MODEL.sample_points_mode = "uniform"
+        render.sample_points_mode = "uniform"
+        batch = rh.make_batch(rays_s, xyz_s, poses, TH, FRAME, sel=sel)
+        tag = "train:" if train else "eval:"
+        if train:
+            torch.manual_seed(233)
+            arrs["jitter"] = torch.rand(1, 64, 16).numpy()
+            arrs["noise"] = torch.randn(64, 16).numpy()
+        e2e = rh.run_render(render, batch, train=train)
+        for k, v in e2e.items():
+            arrs[tag + k] = v
+    save("small_uniform", **arrs)
+
+
 def main():
     import torch
 
     if "--other-weights" in sys.argv:
         return other_weight_sets()
+    if "--uniform" in sys.argv:
+        return uniform_mode()
     torch.set_num_threads(8)
     state = synth.make_state_dict()
     poses = synth.make_poses()

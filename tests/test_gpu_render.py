@@ -242,6 +242,27 @@ def test_all_transparent_frame():
     assert bool(torch.isnan(out["disp_map"]).all())
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_uniform_sampling_mode_matches_reference(train):
+    """cfg.MODEL.sample_points_mode = 'uniform' end to end against the REAL reference's Renderer.render in that mode
+    (tests/golden/make_golden.py --uniform): z_vals bit-exact (eval: the plain lerp; train: stratified jitter from the CPU
+    generator, seed 233), colour / acc / weights within 1e-4"""
+    g = load("small_uniform")
+    r = make_renderer(g)
+    r.sample_points_mode = "uniform"
+    tag = "train:" if train else "eval:"
+    if train:
+        r.train()
+        torch.manual_seed(233)
+    else:
+        r.eval()
+    out = {k: v.detach().cpu().numpy() for k, v in r.render(make_batch(g))["coarse"].items()}
+    assert np.array_equal(out["z_vals"], g[tag + "z_vals"])
+    for k, tol in (("color", 1e-4), ("acc_map", 1e-4), ("weights", 1e-4), ("depth_map", 3e-4)):
+        assert maxdiff(out[k], g[tag + k]) < tol, (k, maxdiff(out[k], g[tag + k]))
+    assert np.array_equal(np.isnan(out["disp_map"]), np.isnan(g[tag + "disp_map"]))
+
+
 def test_uniform_sampling_mode():
     """cfg.MODEL.sample_points_mode = 'uniform' (can_render.py:42-51): z_vals are the plain lerp of the given near/far"""
     g = load("small_eval")

@@ -113,3 +113,59 @@ def test_gradient_average_world2():
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
 
+
+
+def _frames_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("par", os.path.join(root, "dual-space-nerf_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(par)
+    rp = par.RayParallel()
+    P = 12
+    rendered = []
+
+    def frame(f):                                 # a frame's packed image as a function of its index only
+        rendered.append(f)
+        return (torch.arange(P * 6, dtype=torch.float32).reshape(P, 6) + 1000.0 * f)
+
+    frames = rp.render_frames(frame, n_frames, P)
+    ok = len(frames) == n_frames and all(torch.equal(frames[f], torch.arange(P * 6, dtype=torch.float32).reshape(P, 6) + 1000.0 * f)
+                                         for f in range(n_frames))
+    ok = ok and rendered == rp.frames_of(n_frames)             # every rank rendered exactly its own frames, in order
+    # strong mode's exchange (bench.py --strong): equal slabs gathered, then put back into ray order
+    R, tile = 23, 4
+    mine = rp.tile_indices(R, tile)
+    slab = rp.tile_slab(R, tile)
+    pad = torch.zeros(slab, 2)
+    pad[: mine.numel(), 0] = mine.float()
+    pad[: mine.numel(), 1] = 10.0 * mine.float()
+    allp = torch.empty(world * slab, 2)
+    dist.all_gather_into_tensor(allp, pad)
+    full = rp.undeal_tiles(allp, R, tile)
+    ok = ok and torch.equal(full[:, 0], torch.arange(R, dtype=torch.float32)) and torch.equal(full[:, 1], 10.0 * torch.arange(R, dtype=torch.float32))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 4, 2])
+def test_frame_parallel_and_tile_undeal_world2(n_frames):
+    """BASELINE configs[4] (a sequence dealt frame by frame over the ranks, one asynchronous all-gather per round) and the
+    exchange of configs[3] (round-robin tiles of ONE frame: gather of equal slabs + un-dealing into ray order)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frames_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
