@@ -268,7 +268,15 @@ def main():
         ex = result["config"]
         ex["ms_per_frame_alone_no_screen"] = frame_ms(5, screen=False)
         ex["ms_per_frame_alone_fp32_exact"] = frame_ms(2, fp32=True)
+        # host batch -> host images.  Small host-side torch ops (a 1 MB clone is enough) fan out over torch's intra-op pool -
+        # 256 OpenMP threads on these boxes, which then spin for milliseconds and starve the thread that feeds the GPU
+        # (scripts/h2h_probe.py: 42-44 ms per frame with the default pool, 19-20 ms with 16 threads or OMP_WAIT_POLICY=passive):
+        # both are reported
         ex["host_to_host_ms"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(min(16, nthreads))
+        ex["host_to_host_ms_16_host_threads"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
+        torch.set_num_threads(nthreads)
         if not args.no_cpu_baseline:
             result["eager_gpu_baseline"] = eager_baseline(args, _lib, synth, dev, chunks=3, train=False)
             result["eager_gpu_baseline"]["x_faster_per_frame"] = result["eager_gpu_baseline"]["eval_ms_per_512x512_frame"] * \

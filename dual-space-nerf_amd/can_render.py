@@ -187,7 +187,13 @@ class Renderer:
         if slot["host"] is None or slot["host"].numel() < nbytes:
             slot["host"] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8).pin_memory()
         stage = slot["host"][:nbytes].view(dtype).view(t.shape)
-        stage.copy_(t)                                   # host memcpy (with the dtype conversion, if any)
+        # host memcpy (with the dtype conversion, if any) through numpy: ONE thread.  torch's copy_ fans a few MB out over its
+        # whole intra-op pool - 256 threads on the GPU boxes - and the wake-up costs more than the copy (47 ms instead of 19 ms per
+        # host-to-host frame once the pool has been spun up by other CPU work)
+        if t.device.type == "cpu" and not t.requires_grad and t.dtype != torch.bfloat16:
+            np.copyto(stage.numpy(), t.numpy(), casting="unsafe")
+        else:
+            stage.copy_(t)
         out = torch.empty(t.shape, dtype=dtype, device=self.device)
         out.copy_(stage, non_blocking=True)
         slot["done"].record()
@@ -475,11 +481,9 @@ class Renderer:
         for k in keys:
             stage[k].copy_(img[k], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        out = {}
-        for k in keys:          # (clone() of a page-locked tensor allocates page-locked memory again: 2-3 ms per image)
-            out[k] = torch.empty(stage[k].shape, dtype=torch.float32)
-            out[k].copy_(stage[k])
-        return out
+        # fresh pageable tensors (clone() of a page-locked tensor allocates page-locked memory again: 2-3 ms per image), copied
+        # by one thread (see _dev)
+        return {k: torch.from_numpy(stage[k].numpy().copy()) for k in keys}
 
     def render_views(self, batches, frames_in_flight=2, device_output=True, chunk=None):
         """The per-frame loop of novel_pose_vis.py:41-66 / test.py:55-64 (`for batch in loader: render.render_view(batch)`) as
