@@ -275,10 +275,11 @@ __device__ __forceinline__ void dsn_layer_bwd(DsnWStream& ws, const f32x16 (&in)
 #define FIELD_PTS_PER_BLOCK 128
 
 // one wave's 32 points starting at list slot `slot0` (< count, wave-uniform)
+template <bool fix_nan>
 __device__ __forceinline__ void
 k_field_wave(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
              const int32_t* __restrict__ active_list, int64_t count, int64_t slot0,
-             float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
+             float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
     // fix_nan != 0: the range fallback of the split-fp16 kernels (dsn_field16.hip).  A sample whose activations left the
     // fp16 range there carries sigma = NaN; this launch re-evaluates exactly those samples (waves without one move on at
     // once, the other lanes of a wave with one compute but do not write) - sigma, essence and d sigma/dx in exact fp32.
@@ -433,12 +434,19 @@ k_field_wave(const float* __restrict__ packed, const DsnFrameState* __restrict__
     }
 }
 
+template <bool FIX>
 __global__ void __launch_bounds__(FIELD_THREADS, 1)
 k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
         int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, int fix_nan) {
+        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    if (!FIX) {      // (its own instantiation: the loop below costs the plain kernel 6 % through register allocation)
+        const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+        if (slot0 >= count) return;   // wave-uniform
+        k_field_wave<false>(packed, fs, x_c, active_list, count, slot0, sigma, essence, grad);
+        return;
+    }
     // normal launches: one 128-point tile per workgroup.  The range fallback (fix_nan) is launched with a small grid that
     // strides over the list: it normally finds nothing, and 131 072 workgroups that only look cost 0.14 ms per frame
 #pragma nounroll
@@ -450,8 +458,7 @@ k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, 
         const float* pk = packed;
         const DsnFrameState* f = fs;
         asm volatile("" : "+s"(pk), "+s"(f));
-        k_field_wave(pk, f, x_c, active_list, count, slot0, sigma, essence, grad, fix_nan);
-        if (!fix_nan) return;
+        k_field_wave<true>(pk, f, x_c, active_list, count, slot0, sigma, essence, grad);
     }
 }
 
@@ -460,8 +467,8 @@ void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float*
                       float* grad, hipStream_t st) {
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_field, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad, 0);
+    hipLaunchKernelGGL(k_field<false>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
+                       active_count, sigma, essence, grad);
 }
 // range fallback of the split-fp16 kernels: exact-fp32 re-evaluation of the listed samples whose sigma is NaN
 void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -470,8 +477,8 @@ void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const fl
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
     if (blocks > 2048) blocks = 2048;        // grid-stride (see k_field)
-    hipLaunchKernelGGL(k_field, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad, 1);
+    hipLaunchKernelGGL(k_field<true>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
+                       active_count, sigma, essence, grad);
 }
 
 // ---------------------------------------------------------------------------------------------
