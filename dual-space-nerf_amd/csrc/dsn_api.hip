@@ -174,7 +174,7 @@ int dsn_field_forward(const void* scene, int V, int F, const void* packed, const
     DSN_REQUIRE(V > 0 && F > 0, "dsn_field_forward: bad V/F");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
     dsn_launch_field16_fwd((const float*)packed, s.frame, x_c, N, active_list, active_count, sigma, essence, records, pos_list,
-                           pos_count, (hipStream_t)stream);
+                           pos_count, (hipStream_t)stream, N);
     return dsn_check_launch("dsn_field_forward");
 }
 
@@ -184,7 +184,7 @@ int dsn_field_reverse(const void* scene, int V, int F, const void* packed, const
     DSN_REQUIRE(N > 0, "dsn_field_reverse: empty point batch");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_field_reverse: bad V/F");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    dsn_launch_field16_bwd((const float*)packed, s.frame, x_c, N, pos_list, pos_count, grad, records, (hipStream_t)stream, sigma);
+    dsn_launch_field16_bwd((const float*)packed, s.frame, x_c, N, pos_list, pos_count, grad, records, (hipStream_t)stream, sigma, N);
     // range fallback for what dsn_field_forward or the reverse pass flagged (sigma = NaN): exact fp32, all three outputs
     dsn_launch_field_fix((const float*)packed, s.frame, x_c, N, pos_list, pos_count, sigma, essence, grad, (hipStream_t)stream);
     return dsn_check_launch("dsn_field_reverse");
@@ -383,7 +383,8 @@ struct DsnWorkspace {
     float* n_w;           // [N,3]
     float* colour;        // [N,3]
     int32_t* pos;         // [N]   samples with sigma > 0 (eval-mode split of the field kernel)
-    void* masks;          // [N] x 224 B relu-mask records
+    void* masks;          // [rec_cap] x 224 B relu-mask records, indexed by the slot on the sigma > 0 list
+    int64_t rec_cap;
     void* nn_small;       // per-cell scratch of the cell-major nearest-face search
     int32_t* keep;        // [N]   samples the density screen could not rule out
     int32_t* audit;       // [audit_cap] samples declared empty that DSN_SCREEN_AUDIT sends through the accurate pass anyway
@@ -396,6 +397,16 @@ struct DsnWorkspace {
 #define DSN_CNT_KEEP 32       // samples the density screen sent to the accurate pass
 #define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: samples audited, [44] of those with accurate sigma > 0, [45] their max sigma (float bits)
 #define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
+// Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
+// pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for half of the samples of a
+// big frame (the bench frame puts 11.6 % of its samples there, a solid trained network 39 %); samples beyond the capacity
+// take the single-launch forward + reverse pass instead (dsn_launch_field16_from): same values, no records.
+// DSN_RECORD_CAP (tests) overrides the capacity.
+static int64_t dsn_record_cap(int64_t N) {
+    const char* e = getenv("DSN_RECORD_CAP");
+    if (e) { const long long v = atoll(e); return v < 1 ? 1 : (v > N ? N : v); }
+    return N <= ((int64_t)1 << 21) ? N : (N / 2 > ((int64_t)1 << 21) ? N / 2 : ((int64_t)1 << 21));
+}
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
     DsnWorkspace w;
     size_t N = (size_t)R * S;
@@ -411,7 +422,8 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.n_w = (float*)p;            p += dsn_align256(12 * N);
     w.colour = (float*)p;         p += dsn_align256(12 * N);
     w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
-    w.masks = (void*)p;           p += dsn_align256(224 * N);
+    w.rec_cap = dsn_record_cap((int64_t)N);
+    w.masks = (void*)p;           p += dsn_align256(224 * (size_t)w.rec_cap);
     w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
     w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
     w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
@@ -485,10 +497,15 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             list = w.keep;
             cnt = kcnt;
         }
-        dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st);
-        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma);
+        dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st,
+                               w.rec_cap);
+        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap);
         list = w.pos;
         cnt = pcnt;
+        // samples of the sigma > 0 list beyond the record capacity (none on ordinary frames: the launch is N - cap empty
+        // workgroups' worth of looking): forward + reverse in one launch, bit-identical values
+        if (w.rec_cap < N)
+            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, list, cnt, w.rec_cap, w.sigma, w.essence, w.grad, st);
         // range fallback: whatever either pass flagged (sigma = NaN; such samples are on the sigma > 0 list) in exact fp32
         dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
         if (audit) dsn_launch_screen_audit(w.audit, w.count + DSN_CNT_AUDIT, w.audit_cap, w.sigma, w.count + DSN_CNT_AUDIT + 4, st);

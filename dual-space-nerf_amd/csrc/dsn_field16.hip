@@ -388,7 +388,11 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
           int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
           float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad,
           uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count,
-          float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr) {
+          float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr, int64_t slot_base, int64_t rec_cap) {
+    // slot_base: the launch works on list slots slot_base ... (FULL mode as the overflow pass of the eval split, see dsn_render_rays)
+    // rec_cap  : capacity of the relu-record array in samples.  FWD / BWD index the records by the sample's slot on the
+    //            sigma > 0 list (FWD writes a record only for the samples it appends there, BWD reads slot s of the list it
+    //            walks); samples whose slot is >= rec_cap get no record and are left to the overflow pass.  TRAIN indexes by sample.
     constexpr bool ST = MODE == F16_TRAIN;
     // LDS map: weight ring 64 KB | relu masks 7 layers x 4 words x 256 threads = 28 KB | PE operands 8 x half8 x 256 = 32 KB
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
@@ -401,12 +405,13 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
-    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    int64_t count = (active_list ? (int64_t)(*active_count) : N) - slot_base;
+    if (MODE == F16_BWD && count > rec_cap) count = rec_cap;
     if ((int64_t)blockIdx.x * 128 >= count) return;   // block-uniform: the barriers below need all 4 waves
     int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
-    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
+    const int64_t pt = active_list ? (int64_t)active_list[slot_base + slot] : slot_base + slot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
 
     for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
@@ -435,7 +440,8 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     half8 ah[8][2], al[8][2], bh[8][2], bl[8][2];
     float ovf = 0.0f;          // range guard: running max of |value| over everything this lane splits into fp16
     // per-sample mask record: [half][layer] uint4, 224 B contiguous per sample
-    uint4* const mrec = masks ? masks + ((size_t)pt * 2 + half) * 7 : nullptr;
+    // TRAIN: indexed by sample; BWD: by the slot of the list it walks; FWD: by the slot the sample gets on the sigma > 0 list (below)
+    uint4* mrec = masks ? masks + ((size_t)(MODE == F16_BWD ? slot : pt) * 2 + half) * 7 : nullptr;
     // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
     const int64_t tr_ls = N * 256;
     float* const th = ST && valid ? tr_h + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : h_l
@@ -521,15 +527,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     // range guard, forward half: a flagged sample carries sigma = NaN until the exact-fp32 kernel has re-evaluated it
     const bool flag_fwd = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
     if (valid && half == 0) sigma[pt] = flag_fwd ? dsn_nan_flag() : sg;
-    if (MODE == F16_FWD || MODE == F16_TRAIN) {
-        // masks of all 7 layers -> the sample's record (read back by k_field16<reverse> / k_tangent16)
-        MK_STORE(6, mk)
-        if (valid) {
-#pragma unroll
-            for (int L = 0; L < 7; ++L)
-                mrec[L] = make_uint4(s_mask[L][0][tid], s_mask[L][1][tid], s_mask[L][2][tid], s_mask[L][3][tid]);
-        }
-    }
+    bool write_rec = ST && valid;
     if (MODE == F16_FWD) {
         // samples with positive density -> the reverse-pass list (flagged samples too: the fallback behind the reverse pass
         // walks this list, and whatever it finds their density to be, a normal and a colour for them cost nothing but time)
@@ -539,7 +537,21 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         int base = 0;
         if (lane == 0 && cnt) base = atomicAdd(pos_count, cnt);
         base = __shfl(base, 0);
-        if (pos) pos_list[base + __popcll(bm & ((1ull << lane) - 1ull))] = (int32_t)pt;
+        const int my = base + __popcll(bm & ((1ull << lane) - 1ull));
+        if (pos) pos_list[my] = (int32_t)pt;
+        // its relu record goes to the same slot (both half-waves hold a half of it); none beyond the capacity
+        const int rslot = __shfl(my, lane & 31);
+        write_rec = ((bm >> (lane & 31)) & 1ull) != 0 && (int64_t)rslot < rec_cap;
+        mrec = masks + ((size_t)rslot * 2 + half) * 7;
+    }
+    if (MODE == F16_FWD || MODE == F16_TRAIN) {
+        // masks of all 7 layers -> the sample's record (read back by k_field16<reverse> / k_tangent16)
+        MK_STORE(6, mk)
+        if (write_rec) {
+#pragma unroll
+            for (int L = 0; L < 7; ++L)
+                mrec[L] = make_uint4(s_mask[L][0][tid], s_mask[L][1][tid], s_mask[L][2][tid], s_mask[L][3][tid]);
+        }
     }
     // rgb_net: 256 -> 128 -> relu -> 3 (second layer as per-lane dots in the epilogue)
     {
@@ -664,7 +676,17 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0);
+}
+// the same single-launch evaluation on slots slot_base ... of a list: the overflow pass of the eval split (samples of the
+// sigma > 0 list whose relu record did not fit get forward AND reverse here; identical values, see dsn_render_rays)
+void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* list,
+                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st) {
+    int64_t blocks = (N - slot_base + 127) / 128;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, list, count, sigma,
+                       essence, grad, (uint4*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, slot_base, (int64_t)0);
 }
 // training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
@@ -676,28 +698,28 @@ void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, cons
     // range_count (optional): incremented once per sample whose activations / adjoints left the fp16 range
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
-                       range_count, tr_h, tr_a, tr_rr);
+                       range_count, tr_h, tr_a, tr_rr, (int64_t)0, N);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st) {
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap);
 }
 // ... reverse pass on the sigma > 0 samples only
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st, float* sigma) {
-    int64_t blocks = (N + 127) / 128;
+                            hipStream_t st, float* sigma, int64_t rec_cap) {
+    int64_t blocks = ((rec_cap < N ? rec_cap : N) + 127) / 128;
     if (blocks == 0) return;
     // sigma: only ever WRITTEN here, with the NaN flag of a sample whose adjoints left the fp16 range (see the header)
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        pos_list, pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,10 +30,12 @@ void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t
                           float* acc_map, float* weights, float* depth_map, hipStream_t st);
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st);
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap);
+void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* list,
+                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st);
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st, float* sigma);
+                            hipStream_t st, float* sigma, int64_t rec_cap);
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
                          float* dbg_s1, hipStream_t st, int32_t* audit_list = nullptr, int32_t* audit_count = nullptr,

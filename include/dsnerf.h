@@ -112,9 +112,9 @@ DSN_EXPORT int dsn_field(const void* scene, int V, int F, const void* packed, co
               const int32_t* active_count, float* sigma, float* essence, float* grad, int flags, void* stream);
 
 /* The same evaluation in two launches, for eval-mode rendering (what dsn_render_rays does under
- * DSN_SKIP_TRANSPARENT): dsn_field_forward writes sigma/essence for the listed points, keeps every point's ReLU
- * pattern in `records` (dsn_field_record_bytes(N) bytes) and appends the points with sigma > 0 to pos_list
- * (pos_count zeroed by the caller); dsn_field_reverse then writes grad = d sigma / d x_c for the points of
+ * DSN_SKIP_TRANSPARENT): dsn_field_forward writes sigma/essence for the listed points, appends the points with sigma > 0
+ * to pos_list (pos_count zeroed by the caller) and keeps THEIR ReLU patterns in `records` (dsn_field_record_bytes(N) bytes;
+ * record k belongs to pos_list[k]); dsn_field_reverse then writes grad = d sigma / d x_c for the points of
  * pos_list only - the others have alpha = 0 exactly (utils/nerf_net_utils.py:24-27: relu(sigma)), so their
  * normal and colour never reach a pixel.  Results are bit-identical to dsn_field's on the points both write. */
 DSN_EXPORT size_t dsn_field_record_bytes(int64_t N);

@@ -676,3 +676,33 @@ def test_novel_pose_relighting_at_512():
     assert np.array_equal(out["z_vals"][si].cpu().numpy(), e["z_vals"])
     assert maxdiff(out["color"][si].cpu().numpy(), e["color"]) < 1e-4
     assert maxdiff(out["weights"][si].cpu().numpy(), e["weights"]) < 1e-4
+
+
+@pytest.mark.parametrize("cap", ["1", "5000", "300000"])
+def test_relu_record_capacity_overflow_is_exact(cap, monkeypatch):
+    """the relu records are sized for a share of the samples (slot on the sigma > 0 list); samples beyond the capacity take the
+    single-launch forward + reverse pass.  With the capacity forced down to 1 / 5 000 / 300 000 records on a 160 x 160 x 64
+    frame (~190 k samples with sigma > 0) the frame is bit-identical to the un-capped one"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    r._screen_usable()
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+
+    def run():
+        n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        ws = _lib.RenderWorkspace(r.device)
+        out = _lib.render_rays(r.scene, r.net.packed(r.device), ws, o, d, n, f, S, r._t_vals(S))
+        return out, int(ws.buf[:256].view(torch.int32)[_lib.CNT_POS])
+
+    ref, npos = run()
+    monkeypatch.setenv("DSN_RECORD_CAP", cap)
+    got, npos2 = run()
+    monkeypatch.delenv("DSN_RECORD_CAP")
+    assert npos == npos2 and npos > int(cap) or int(cap) >= 300000
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(ref[k], got[k]), k
+    assert float(ref["acc_map"].max()) > 0.05
