@@ -47,6 +47,7 @@ FIELD_FP32 = 4
 SAMPLE_UNIFORM = 8
 NO_SCREEN = 16
 SCREEN_AUDIT = 32
+SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.05      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
 SCREEN_MIN_DROPPED = 0.35     # PackedParams.calibrate_screen: below this share of dropped calibration points the screen stays off
 RAYS_ZJU, RAYS_H36M = 0, 1
 # int32 words of the render workspace the library leaves diagnostics in (include/dsnerf.h)
@@ -130,21 +131,42 @@ class PackedParams:
         self.screen = None         # the packed image carries the conservative default margin again
         return self
 
-    def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20):
-        """Measure the density screen's margin for THESE parameters on the scene's current frame state
-        (dsn_calibrate_screen; synchronises: meant to run once per checkpoint, Renderer does it lazily before the first
-        eval-mode frame after the parameters changed).  Returns / stores dict(deviation, margin, overflow_fraction,
-        points, usable); usable = False means the screen would need a margin above the cap and is left out."""
+    def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20, other_frames=(0, 125, 250, 375, 499)):
+        """Measure the density screen's margin for THESE parameters (dsn_calibrate_screen; synchronises: meant to run once per
+        checkpoint, Renderer does it lazily before the first eval-mode frame after the parameters changed): on the scene's
+        current frame state with n_points points, and - the first layer's bias depends on the frame's embedding row - with the
+        same pose under a spread of other frame codes (`other_frames`, n_points / 4 points each).  The margin is 10x the
+        largest deviation seen anywhere.  Returns / stores dict(deviation, margin, overflow_fraction, points,
+        dropped_fraction, safe, usable); safe = False: the screen would need a margin above the cap; usable = safe and it
+        drops enough samples to pay for itself."""
         ws = torch.empty(lib().dsn_calibrate_workspace_bytes(C.c_int64(n_points)), dtype=torch.uint8, device=self.device)
         out = torch.zeros(8, dtype=torch.float32, device=self.device)
-        _check(lib().dsn_calibrate_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), C.c_int64(n_points), _ptr(ws), _ptr(out),
-                                          _stream()), "dsn_calibrate_screen")
-        d, m, ovf, n, dropped = (float(v) for v in out.cpu()[:5])
+
+        def run(n):
+            _check(lib().dsn_calibrate_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), C.c_int64(n), _ptr(ws), _ptr(out),
+                                              _stream()), "dsn_calibrate_screen")
+            return [float(v) for v in out.cpu()[:5]]
+
+        d, m, ovf, n, dropped = run(n_points)
+        state = getattr(scene, "_pose_args", None)          # (poses, frame_idx, zero_code, light_shift, rot, rot_center) of set_frame
+        total = n
+        if state is not None and not state[2] and other_frames:
+            poses, frame_idx, zero_code, ls, r, rc = state
+            for f in other_frames:
+                if f == frame_idx:
+                    continue
+                _set_pose(scene.buf, self, poses, None, f, zero_code, ls, r, rc, self.device)
+                d2, _, ovf2, n2, _ = run(max(n_points // 4, 1024))
+                d, ovf, total = max(d, d2), max(ovf, ovf2), total + n2
+            _set_pose(scene.buf, self, poses, None, frame_idx, zero_code, ls, r, rc, self.device)      # back to the frame's own state
+            m = max(10.0 * d, SCREEN_MARGIN_FLOOR)
+            m = m if m <= SCREEN_MARGIN_CAP else float("inf")
+            _check(lib().dsn_set_screen_margin(_ptr(self.buf), C.c_float(m), _stream()), "dsn_set_screen_margin")
         safe = bool(m < float("inf"))
         # The screen costs ~0.3 of an accurate forward pass per sample (k_screen16 0.71 us vs k_field16<forward> 2.36 us per
         # thousand samples): it pays only if it drops more than that share.  A network that is dense everywhere near the
         # surface (every calibration point sigma > 0) is better off without it.
-        self.screen = {"deviation": d, "margin": m, "overflow_fraction": ovf, "points": int(n), "dropped_fraction": dropped,
+        self.screen = {"deviation": d, "margin": m, "overflow_fraction": ovf, "points": int(total), "dropped_fraction": dropped,
                        "safe": safe, "usable": safe and dropped >= SCREEN_MIN_DROPPED}
         return self.screen
 
@@ -189,6 +211,7 @@ class Scene:
                                    int(frame_idx), int(bool(zero_code)), _ptr(ls), _ptr(r), _ptr(rc), _stream()),
                "dsn_set_frame")
         self._keep_frame = (xyz, poses, ls, r, rc)
+        self._pose_args = (poses, int(frame_idx), bool(zero_code), ls, r, rc)
         return self
 
 
@@ -206,6 +229,7 @@ def scene_set_pose(scene: Scene, packed: PackedParams, poses, frame_idx, zero_co
     """pose code / embedding row / light edits of a scene, mesh untouched (dsn_set_pose)."""
     scene._keep_pose = _set_pose(scene.buf, packed, poses, pose_feat, frame_idx, zero_code, light_shift, rot, rot_center, scene.device)
     scene.frame_key = None     # no longer the state a set_frame(reuse=True) left
+    scene._pose_args = None
     return scene
 
 
