@@ -48,6 +48,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_MIX
 #define F16_MIX 1             // hi / lo split of the pipelined epilogues with v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 (inline asm)
 #endif
+#ifndef F16_PIPE_LATE
+#define F16_PIPE_LATE 1       // stage2.0 / stage2.4 (forward) with software-pipelined epilogues like the plain 256 -> 256 layers
+#endif
 #ifndef F16_PREFETCH
 #define F16_PREFETCH 1        // explicit one-block-ahead LDS operand reads
 #endif
@@ -253,9 +256,11 @@ __device__ __forceinline__ float dsn_nan_flag() { return __uint_as_float(0x7fc00
 // the matrix pipe stays busy while the VALU retires the previous block.
 // ST (training kernel only): the element values also go to `st` = this lane's row-major slot of the output block
 // ([N,256] fp32 per layer: point row, features 32 m + 8 (r >> 2) + 4 half + (r & 3)), times `stscale`.
-template <bool FWD, bool ST = false>
+// HEAD (forward, stage2.4 only): the density head rides along - sg += w_den[feature] * relu value, in feature order
+template <bool FWD, bool ST = false, bool HEAD = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
-                                          half8 (&yh)[2], half8 (&yl)[2], float& ovf, float* st = nullptr, float stscale = 1.0f) {
+                                          half8 (&yh)[2], half8 (&yl)[2], float& ovf, float* st = nullptr, float stscale = 1.0f,
+                                          const float* wd = nullptr, float* sg = nullptr) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -268,6 +273,7 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
             v = dsn_keep_active(v, mword, r);
         }
         vv[e] = v;
+        if (HEAD) *sg = fmaf(wd[8 * (r >> 2) + (r & 3)], v, *sg);      // wd = this lane's 16 head weights of the block (rows16 order)
 #if !F16_MIX
         const _Float16 hi = (_Float16)v;
         const float res = fmaf((float)hi, -1.0f, v);
@@ -327,26 +333,40 @@ __device__ __forceinline__ void store16(float* st, const f32x16& v, float stscal
         *reinterpret_cast<float4*>(st + 8 * q) = make_float4(v[4 * q] * stscale, v[4 * q + 1] * stscale, v[4 * q + 2] * stscale, v[4 * q + 3] * stscale);
 }
 
-// 256 -> 256 forward layer (software-pipelined epilogues)
-template <bool ST = false>
+// 256 -> 256 forward layer (software-pipelined epilogues: the epilogue of output block m-1 issues under the MFMAs of block m)
+//   EXTRA: stage2.0 - every output block takes two more k-blocks, the positional encoding (operands back from LDS)
+//   HEAD : stage2.4 - the density head is accumulated in the epilogue (sg, feature order: bit-identical to a separate loop)
+template <bool ST = false, bool EXTRA = false, bool HEAD = false>
 __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const float* __restrict__ bias,
                                             const half8 (&xh)[8][2], const half8 (&xl)[8][2], half8 (&yh)[8][2],
-                                            half8 (&yl)[8][2], uint32_t (&mk)[4], float& ovf, float* st = nullptr) {
+                                            half8 (&yl)[8][2], uint32_t (&mk)[4], float& ovf, float* st = nullptr,
+                                            const half8 (*s_pe)[F16_THREADS] = nullptr, const float* wden = nullptr, float* sg = nullptr) {
     const int half = lane >> 5;
+    const int tid = threadIdx.x;
     f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(bias, m, half), aC = zero16();
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) {
+            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr, 1.0f,
+                                      HEAD ? wden + 32 * (m - 1) + 4 * half : nullptr, sg); });
+        if (EXTRA) {   // encoding operands come back from LDS just for these two blocks
+            half8 qh[2][2], ql[2][2];
+            qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
+            ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
+            dense16<2, false>(w, blk, lane, qh, ql, aM, aC);
+        }
         if (m > 0) { if ((m - 1) & 1) mk[(m - 1) >> 1] |= dsn_active_word(bits) << 16; else mk[(m - 1) >> 1] = dsn_active_word(bits); }
         pM = aM; pC = aC;
     }
     {   // last block: nothing left to hide it under
         uint32_t bits = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) epi_slice<true, ST>(pM, pC, kb, 0u, bits, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr);
+        for (int kb = 0; kb < 8; ++kb)
+            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr, 1.0f,
+                                      HEAD ? wden + 32 * 7 + 4 * half : nullptr, sg);
         mk[3] |= dsn_active_word(bits) << 16;
     }
 }
@@ -486,12 +506,22 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     layer16_fwd<ST>(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk, ovf, th ? th + 1 * tr_ls : nullptr); MK_STORE(1, mk)
     layer16_fwd<ST>(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk, ovf, th ? th + 2 * tr_ls : nullptr); MK_STORE(2, mk)
     layer16_fwd<ST>(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk, ovf, th ? th + 3 * tr_ls : nullptr); MK_STORE(3, mk)
+#if F16_PIPE_LATE
     // stage2.0 : [h, pe] -> 256
+    layer16_fwd<ST, true, false>(w, blk, lane, v_b1 + 3 * 256, bh, bl, ah, al, mk, ovf, th ? th + 4 * tr_ls : nullptr, s_pe);
+    MK_STORE(4, mk)
+    layer16_fwd<ST>(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk, ovf, th ? th + 5 * tr_ls : nullptr); MK_STORE(5, mk)
+    // stage2.4 with the density head fused into its epilogue
+    float sg_part = 0.0f;
+    layer16_fwd<ST, false, true>(w, blk, lane, v_b1 + 5 * 256, bh, bl, ah, al, mk, ovf, th ? th + 6 * tr_ls : nullptr, nullptr, v_wden,
+                                 &sg_part);
+#else
+    // (round 1's form, kept for A/B runs: the epilogues of stage2.0 and stage2.4 behind their MFMAs, not under the next block's)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = rows16(v_b1 + 3 * 256, m, half), aC = zero16();
         dense16<8, false>(w, blk, lane, bh, bl, aM, aC);
-        {   // encoding operands come back from LDS just for these two blocks
+        {
             half8 qh[2][2], ql[2][2];
             qh[0][0] = s_pe[0][tid]; qh[0][1] = s_pe[1][tid]; qh[1][0] = s_pe[2][tid]; qh[1][1] = s_pe[3][tid];
             ql[0][0] = s_pe[4][tid]; ql[0][1] = s_pe[5][tid]; ql[1][0] = s_pe[6][tid]; ql[1][1] = s_pe[7][tid];
@@ -506,7 +536,6 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     }
     MK_STORE(4, mk)
     layer16_fwd<ST>(w, blk, lane, v_b1 + 4 * 256, ah, al, bh, bl, mk, ovf, th ? th + 5 * tr_ls : nullptr); MK_STORE(5, mk)
-    // stage2.4 with the density head and the seed of the reverse pass fused into its epilogue
     float sg_part = 0.0f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -522,6 +551,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
+#endif
     sg_part += __shfl_xor(sg_part, 32);
     const float sg = sg_part + v_scal[0];
     // range guard, forward half: a flagged sample carries sigma = NaN until the exact-fp32 kernel has re-evaluated it
@@ -608,7 +638,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 5 * tr_ls : nullptr);
     MK_LOAD(4, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 4 * tr_ls : nullptr);
     MK_LOAD(3, mk)
-    // stage2.0^T : 256 -> [256 h | 64 pe]
+    // stage2.0^T : 256 -> [256 h | 64 pe]  (epilogues not pipelined: as a layer16_bwd the reverse-only kernel spills 267 registers)
     f32x16 dpe[2];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {

@@ -131,16 +131,32 @@ template <int DEPTH, int VALU> void rund(const char* name, float* d, const char*
     double us_per_block = ms * 1e3 / (4.0 * reps * BLOCKS);
     printf("%-34s %8.3f ms   %.4f us per block per wave = %.0f cycles @2.1 GHz (6 MFMA = 192)\n", name, ms, us_per_block, us_per_block * 2100); fflush(stdout);
 }
+template <int MODE> double t_run(float* d, const char* w, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256 * 4), dim3(256), 0, 0, d, w, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3 / (4.0 * reps * BLOCKS);
+}
 int main() {
     float* d; hipMalloc(&d, 1024);
     char* w; hipMalloc(&w, 4096 * (BLOCKS + 16)); hipMemset(w, 0, 4096 * (BLOCKS + 16));
-    run<0>("reads + mfma", d, w, 20);
-    run<4>("+ barrier per 8 blocks", d, w, 20);
-    run<3>("+ LDS-DMA refill (no barrier)", d, w, 20);
-    run<1>("+ LDS-DMA refill + barrier", d, w, 20);
-    run<2>("+ DMA + barrier + 30 VALU / block", d, w, 20);
-    run<5>("  same, VALU interleaved 1:5 (SGB)", d, w, 20);
-    run<6>("  18 VALU / block interleaved 1:3", d, w, 20);
-    rund<2, 0>("direct global, 2 blocks ahead", d, w, 5);
+    // round 2: interleaved rounds after a warm-up (the chip settles at ~1.7 GHz-equivalents under MFMA load; timing the variants
+    // one after the other from a cold start attributes the clock ramp to whatever runs first)
+    const char* name[7] = {"reads + mfma", "+ barrier per 8 blocks", "+ LDS-DMA refill (no barrier)", "+ LDS-DMA refill + barrier",
+                           "+ DMA + barrier + 30 VALU / block", "  same, VALU interleaved 1:5 (SGB)", "  18 VALU / block interleaved 1:3"};
+    const int R = 10;
+    double t[7][R];
+    for (int r = 0; r < 3; ++r) t_run<0>(d, w, 20);
+    for (int r = 0; r < R; ++r) {
+        t[0][r] = t_run<0>(d, w, 20); t[1][r] = t_run<4>(d, w, 20); t[2][r] = t_run<3>(d, w, 20); t[3][r] = t_run<1>(d, w, 20);
+        t[4][r] = t_run<2>(d, w, 20); t[5][r] = t_run<5>(d, w, 20); t[6][r] = t_run<6>(d, w, 20);
+    }
+    for (int v = 0; v < 7; ++v) {
+        double lo = 1e9, sum = 0;
+        for (int r = 0; r < R; ++r) { lo = t[v][r] < lo ? t[v][r] : lo; sum += t[v][r]; }
+        printf("%-38s mean %.4f  min %.4f us / block / wave\n", name[v], sum / R, lo);
+    }
     return 0;
 }

@@ -55,24 +55,30 @@ __global__ void __launch_bounds__(256, 1) k(float* out, int reps) {
     for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
     if (s == 123.456f) out[0] = s;
 }
-template <int AG, int DEPTH, int READS> void run(const char* name, float* d, int reps) {
+template <int AG, int DEPTH, int READS> double run(float* d, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<AG, DEPTH, READS>), dim3(256 * 4), dim3(256), 0, 0, d, 1);
     hipEventRecord(e0);
     hipLaunchKernelGGL((k<AG, DEPTH, READS>), dim3(256 * 4), dim3(256), 0, 0, d, reps);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    double us = ms * 1e3 / (4.0 * reps * BLOCKS);
-    printf("%-44s %8.3f ms  %.4f us / block / wave = %.0f cycles @2.1 GHz (6 MFMA = 192)\n", name, ms, us, us * 2100); fflush(stdout);
+    return ms * 1e3 / (4.0 * reps * BLOCKS);      // us per block per wave
 }
 int main() {
     float* d; hipMalloc(&d, 1024);
-    for (int rep = 0; rep < 2; ++rep) {
-        run<0, 1, 0>("M : MFMA only", d, 40);
-        run<0, 1, 1>("V : reads -> VGPR, 1 block ahead", d, 40);
-        run<1, 1, 1>("A : reads -> AGPR, 1 block ahead", d, 40);
-        run<0, 2, 1>("V2: reads -> VGPR, 2 blocks ahead", d, 40);
-        run<1, 2, 1>("A2: reads -> AGPR, 2 blocks ahead", d, 40);
+    const char* name[5] = {"M : MFMA only", "V : reads -> VGPR, 1 block ahead", "A : reads -> AGPR, 1 block ahead",
+                           "V2: reads -> VGPR, 2 blocks ahead", "A2: reads -> AGPR, 2 blocks ahead"};
+    const int R = 12;
+    double t[5][R];
+    for (int r = 0; r < 3; ++r) { run<0, 1, 1>(d, 40); }                       // warm the chip up to its steady clock
+    for (int r = 0; r < R; ++r) {                                             // interleaved rounds: clock drift hits all variants alike
+        t[0][r] = run<0, 1, 0>(d, 40); t[1][r] = run<0, 1, 1>(d, 40); t[2][r] = run<1, 1, 1>(d, 40);
+        t[3][r] = run<0, 2, 1>(d, 40); t[4][r] = run<1, 2, 1>(d, 40);
+    }
+    for (int v = 0; v < 5; ++v) {
+        double lo = 1e9, hi = 0, sum = 0;
+        for (int r = 0; r < R; ++r) { lo = t[v][r] < lo ? t[v][r] : lo; hi = t[v][r] > hi ? t[v][r] : hi; sum += t[v][r]; }
+        printf("%-38s mean %.4f  min %.4f  max %.4f us / block / wave  (6 MFMA = 192 cycles: %.2f GHz-equivalent)\n", name[v], sum / R, lo, hi,
+               0.192 / (sum / R));
     }
     return 0;
 }

@@ -8,7 +8,7 @@ while [ $# -gt 1 ]; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wno-unused-result -Wno-inline-asm $flags \
       -c $P/csrc/dsn_field16.hip -o $P/variants/$name.o 2> $P/variants/$name.log && \
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build/dsn_api.o $P/build/dsn_geom.o $P/build/dsn_nn.o $P/build/dsn_field.o \
-      $P/variants/$name.o $P/build/dsn_train.o $P/build/dsn_image.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $P/variants/$name.so && echo "built $name" ) &
+      $P/variants/$name.o $P/build/dsn_train.o $P/build/dsn_image.o -o $P/variants/$name.so && echo "built $name" ) &
 done
 wait
 rm -f $P/variants/*.o
