@@ -51,6 +51,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_PIPE_LATE
 #define F16_PIPE_LATE 1       // stage2.0 / stage2.4 (forward) with software-pipelined epilogues like the plain 256 -> 256 layers
 #endif
+#ifndef F16_ABL
+#define F16_ABL 0             // timing ablations (WRONG results): 1 no ring barrier, 2 no vmcnt wait, 4 no LDS-DMA, 8 no pipelined epilogue (MFMAs die too), 16 empty epilogue slices (MFMAs kept)
+#endif
+#ifndef F16_DMA_SPREAD
+#define F16_DMA_SPREAD 1      // LDS-DMA of the next chunk two pieces per block over four blocks instead of eight pieces behind the barrier
+#endif
+#ifndef F16_BIAS_AHEAD
+#define F16_BIAS_AHEAD 1      // forward layers: read the next output block's bias rows one block early
+#endif
+#ifndef F16_TIMING
+#define F16_TIMING 0          // 1 (debug variant): phase cycle counters of k_field16<forward>, read by dsn_debug_timing
+#endif
 #ifndef F16_PREFETCH
 #define F16_PREFETCH 1        // explicit one-block-ahead LDS operand reads
 #endif
@@ -63,6 +75,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define F16_GSCALE 0.015625f                         // reverse pass runs on g / 64
 #define F16_GUNSCALE 64.0f
 
+#if F16_TIMING
+__device__ unsigned long long g_f16_timing[16];
+#define F16_STAMP(i) do { if (MODE == F16_FWD) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tstamp[i] = __builtin_readcyclecounter(); rstamp[i] = wall_clock64(); } } while (0)
+extern "C" __attribute__((visibility("default"))) int dsn_debug_timing(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_f16_timing), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_timing), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define F16_STAMP(i) do { } while (0)
+#endif
 struct W16 {                 // weight stream state of one wave
     const char* g;           // this lane's source: stream base + wave * 8192 + 4096 + lane * 16 (chunk-major layout, dsn_stream16_index)
     char* ring;              // LDS ring base: [chunk parity][quarter][block in chunk][1 KB]
@@ -86,13 +109,30 @@ __device__ __forceinline__ void w16_stage(const W16& w, int c) {
                  "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
                  : : "v"(src), "s"(dst) : "memory", "m0");
 }
+// the same LDS-DMA two pieces at a time (F16_DMA_SPREAD): all four waves issuing their eight 1 KB pieces right behind the ring
+// barrier queue 32 KB on the CU's one address path while the matrix pipe runs dry (in-order issue: a wave sits in its VMEM
+// instructions); two pieces behind each of the first four blocks of a chunk keep that path a quarter busy instead
+template <int I>
+__device__ __forceinline__ void w16_stage_part(const W16& w, int c) {
+    const char* src = w.g + (size_t)c * 32768;
+    const unsigned dst = w.ring_off + (c & 1) * 32768 + w.wave * 8192 + 4096;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:%2\n\tglobal_load_lds_dwordx4 %0, off offset:%3"
+                 : : "v"(src), "s"(dst), "n"(-4096 + 2048 * I), "n"(-3072 + 2048 * I) : "memory", "m0");
+}
 // chunk boundary in front of block b (b % 8 == 0): after the barrier chunk b/8 has landed for everyone and chunk
 // b/8 - 1 has been read by everyone (its last block is already in registers) -> its half of the ring takes chunk b/8 + 1
 __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
+#if !(F16_ABL & 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of chunk b/8 have landed in LDS
+#endif
+#if !(F16_ABL & 1)
     __syncthreads();
+#endif
     const int c = b / F16_CHUNK;
+#if !(F16_ABL & 4) && !F16_DMA_SPREAD
     if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
+#endif
 }
 __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
     const char* s = w.ring + ((b >> 3) & 1) * 32768 + (b & 7) * 1024 + lane * 16;
@@ -104,6 +144,9 @@ __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h
 __device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
     w16_stage(w, first_blk / F16_CHUNK);
     w16_boundary(w, first_blk);
+#if F16_DMA_SPREAD && !(F16_ABL & 4)
+    if (first_blk / F16_CHUNK + 1 < F16_NCHUNK) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
+#endif
     w16_read(w, first_blk, lane, w.h0, w.l0, w.h1, w.l1);
 }
 
@@ -124,6 +167,17 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
         half8 n0 = w.h0, m0 = w.l0, n1 = w.h1, m1 = w.l1;
         if (blk + 1 < DSN_STREAM_BLOCKS) {
             if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16_boundary(w, blk + 1);
+#if F16_DMA_SPREAD && !(F16_ABL & 4)
+            {   // pieces of the chunk after the one block blk + 1 lives in, behind its first four blocks
+                const int pos = (blk + 1) & (F16_CHUNK - 1), cn = (blk + 1) / F16_CHUNK + 1;
+                if (cn < F16_NCHUNK) {
+                    if (pos == 0) w16_stage_part<0>(w, cn);
+                    if (pos == 1) w16_stage_part<1>(w, cn);
+                    if (pos == 2) w16_stage_part<2>(w, cn);
+                    if (pos == 3) w16_stage_part<3>(w, cn);
+                }
+            }
+#endif
             w16_read(w, blk + 1, lane, n0, m0, n1, m1);
         }
 #else
@@ -149,7 +203,9 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
             accM = MFMA16(w.l1, xh[kb][1], accM);
             accC = MFMA16(w.h1, xl[kb][1], accC);
         }
+#if !(F16_ABL & 8)
         hook(kb);   // independent VALU work (the previous output block's epilogue slice) issues under these MFMAs
+#endif
 #if F16_PREFETCH
         w.h0 = n0; w.l0 = m0; w.h1 = n1; w.l1 = m1;
 #endif
@@ -157,10 +213,13 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
 #if F16_SGB
         // pin the issue order inside this block: MFMA, 4 VALU (epilogue slice of the previous output block), MFMA, ...
         // (hipcc otherwise clusters all MFMAs of a chunk and leaves the VALU work as an unoverlapped tail)
+#if F16_SGB_DS == 2
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the next block's four operand reads first: a full block (6 MFMAs) of lead
+#endif
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#if F16_SGB_DS
+#if F16_SGB_DS == 1
             if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one operand ds_read behind each of 4 MFMAs
 #endif
             __builtin_amdgcn_sched_group_barrier(0x002, F16_SGB_VALU, 0);
@@ -261,6 +320,13 @@ template <bool FWD, bool ST = false, bool HEAD = false>
 __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, uint32_t& bits,
                                           half8 (&yh)[2], half8 (&yl)[2], float& ovf, float* st = nullptr, float stscale = 1.0f,
                                           const float* wd = nullptr, float* sg = nullptr) {
+#if F16_ABL & 16
+    {   // timing ablation: the accumulators stay live (no MFMA is dead), nothing is computed from them
+        asm volatile("" : : "a"(pM[2 * kb]), "a"(pM[2 * kb + 1]), "a"(pC[2 * kb]), "a"(pC[2 * kb + 1]));
+        if (kb == 0) { yh[0] = yh[1]; yl[0] = yl[1]; }
+        return;
+    }
+#endif
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -344,9 +410,19 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
     const int half = lane >> 5;
     const int tid = threadIdx.x;
     f32x16 pM = zero16(), pC = zero16();
+#if F16_BIAS_AHEAD
+    // the accumulator's start value (64 x bias, from LDS) is read one output block ahead: read right in front of its first MFMA it
+    // costs an s_waitcnt lgkmcnt(0) - a full LDS round trip with the matrix pipe idle - per output block
+    f32x16 bnext = rows16(bias, 0, half);
+#endif
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
+#if F16_BIAS_AHEAD
+        f32x16 aM = bnext, aC = zero16();
+        if (m + 1 < 8) bnext = rows16(bias, m + 1, half);
+#else
         f32x16 aM = rows16(bias, m, half), aC = zero16();
+#endif
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
         else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) {
@@ -433,6 +509,10 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     if (!valid) slot = count - 1;
     const int64_t pt = active_list ? (int64_t)active_list[slot_base + slot] : slot_base + slot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+#if F16_TIMING
+    unsigned long long tstamp[6], rstamp[6];
+#endif
+    F16_STAMP(0);
 
     for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
         s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
@@ -451,6 +531,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     w.wave = wave;
     w16_begin(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
     int blk = MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0;
+    F16_STAMP(1);
 
     // relu masks live in LDS between the forward and the reverse pass (28 VGPRs otherwise); lane-private slots,
     // so no barrier is needed around them
@@ -490,6 +571,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         s_pe[4][tid] = pl[0][0]; s_pe[5][tid] = pl[0][1]; s_pe[6][tid] = pl[1][0]; s_pe[7][tid] = pl[1][1];
     }
 
+    F16_STAMP(2);
     // stage1.0
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -552,6 +634,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         split16<false>(v, ah[m], al[m]);
     }
 #endif
+    F16_STAMP(3);
     sg_part += __shfl_xor(sg_part, 32);
     const float sg = sg_part + v_scal[0];
     // range guard, forward half: a flagged sample carries sigma = NaN until the exact-fp32 kernel has re-evaluated it
@@ -614,6 +697,13 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         }
     }
 
+#if F16_TIMING
+    F16_STAMP(4);
+    if (MODE == F16_FWD && tid == 0) {
+        for (int i = 0; i < 4; ++i) { atomicAdd(&g_f16_timing[i], tstamp[i + 1] - tstamp[i]); atomicAdd(&g_f16_timing[8 + i], rstamp[i + 1] - rstamp[i]); }
+        atomicAdd(&g_f16_timing[7], 1ull);
+    }
+#endif
     if (MODE == F16_FWD) return;
   } else {
     // MODE == BWD: masks come back from the sample's record

@@ -1,0 +1,123 @@
+// What does each KIND of vector instruction cost beside the MFMAs?  6 MFMA + 4 operand ds_read_b128 per 4 KB block as in k_field16, and
+// 5 vector instructions (inline asm, operands pinned) after each MFMA = 30 per block.  One wave per SIMD, interleaved rounds after a warm-up,
+// shader clock from s_memtime / s_memrealtime -> cycles per block; (cycles - those of the bare loop) / 30 = cycles per instruction.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define BLOCKS 128
+// five instructions on e0..e4 (in/out), sources f0..f4 (VGPR), g (AGPR block), c (SGPR)
+#define G5(I) asm volatile(I(0) I(1) I(2) I(3) I(4) : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) \
+                           : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "s"(c), "a"(g0), "a"(g1), "a"(g2), "a"(g3), "a"(g4))
+#define I_FMA1(n) "v_fma_f32 %" #n ", %" #n ", %10, 0.5\n\t"
+#define I_FMA2(n) "v_fma_f32 %" #n ", %" #n ", %5, 0.5\n\t"
+#define I_FMA2D(n) "v_fma_f32 %" #n ", %" #n ", %[f" #n "], 0.5\n\t"
+#define I_ADD2(n) "v_add_f32_e32 %" #n ", %5, %" #n "\n\t"
+#define I_MUL1(n) "v_mul_f32_e32 %" #n ", %10, %" #n "\n\t"
+#define I_MAX1(n) "v_max_f32_e32 %" #n ", 0, %" #n "\n\t"
+#define I_ACC(n) "v_accvgpr_read_b32 %" #n ", %" #n "+11\n\t"
+template <int KIND>
+__global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* clk, int reps) {
+    __shared__ __attribute__((aligned(16))) char ring[65536];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += 256) ((float*)ring)[i] = (float)(i & 7) * 0.001f;
+    __syncthreads();
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    f32x16 a0 = {0}, a1 = {0};
+    half8 h0 = {0}, l0 = {0}, h1 = {0}, l1 = {0}, x = {0};
+    float e0 = 1 + lane, e1 = 2 + lane, e2 = 3 + lane, e3 = 4 + lane, e4 = 5 + lane;
+    float f0 = 0.5f + lane, f1 = 0.25f + lane, f2 = 0.125f + lane, f3 = 0.75f + lane, f4 = 0.3f + lane;
+    float g0 = 1.5f + lane, g1 = 2.5f + lane, g2 = 3.5f + lane, g3 = 4.5f + lane, g4 = 5.5f + lane;
+    f32x2 p0 = {1.f + lane, 2.f}, p1 = {3.f + lane, 4.f}, p2 = {5.f + lane, 6.f}, p3 = {7.f + lane, 8.f}, p4 = {9.f + lane, 1.f};
+    f32x2 q0 = {0.5f + lane, 0.25f};
+    float c = 1.0001f;
+    for (int j = 0; j < 8; ++j) x[j] = (_Float16)(0.01f * (lane + j));
+    const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    const unsigned base = ring_off + lane * 16;
+#define VALU5()                                                                                                                      \
+    do {                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+        if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %5, 0.5\n\tv_fma_f32 %1, %1, %5, 0.5\n\tv_fma_f32 %2, %2, %5, 0.5\n\tv_fma_f32 %3, %3, %5, 0.5\n\tv_fma_f32 %4, %4, %5, 0.5" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "s"(c)); \
+        if (KIND == 2) asm volatile("v_fma_f32 %0, %0, %5, 0.5\n\tv_fma_f32 %1, %1, %6, 0.5\n\tv_fma_f32 %2, %2, %7, 0.5\n\tv_fma_f32 %3, %3, %8, 0.5\n\tv_fma_f32 %4, %4, %9, 0.5" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 3) asm volatile("v_fma_f32 %0, %0, %5, %6\n\tv_fma_f32 %1, %1, %6, %7\n\tv_fma_f32 %2, %2, %7, %8\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %9, %5" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 4) asm volatile("v_add_f32_e32 %0, %5, %0\n\tv_add_f32_e32 %1, %6, %1\n\tv_add_f32_e32 %2, %7, %2\n\tv_add_f32_e32 %3, %8, %3\n\tv_add_f32_e32 %4, %9, %4" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 5) asm volatile("v_mul_f32_e32 %0, %5, %0\n\tv_mul_f32_e32 %1, %5, %1\n\tv_mul_f32_e32 %2, %5, %2\n\tv_mul_f32_e32 %3, %5, %3\n\tv_mul_f32_e32 %4, %5, %4" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "s"(c)); \
+        if (KIND == 6) asm volatile("v_max_f32_e32 %0, 0, %0\n\tv_max_f32_e32 %1, 0, %1\n\tv_max_f32_e32 %2, 0, %2\n\tv_max_f32_e32 %3, 0, %3\n\tv_max_f32_e32 %4, 0, %4" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4)); \
+        if (KIND == 7) asm volatile("v_accvgpr_read_b32 %0, %5\n\tv_accvgpr_read_b32 %1, %6\n\tv_accvgpr_read_b32 %2, %7\n\tv_accvgpr_read_b32 %3, %8\n\tv_accvgpr_read_b32 %4, %9" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4) : "a"(g0), "a"(g1), "a"(g2), "a"(g3), "a"(g4)); \
+        if (KIND == 8) asm volatile("v_pk_fma_f32 %0, %0, %5, %5\n\tv_pk_fma_f32 %1, %1, %5, %5\n\tv_pk_fma_f32 %2, %2, %5, %5\n\tv_pk_fma_f32 %3, %3, %5, %5\n\tv_pk_fma_f32 %4, %4, %5, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4) : "v"(q0)); \
+        if (KIND == 9) asm volatile("v_pk_mul_f32 %0, %0, %5\n\tv_pk_mul_f32 %1, %1, %5\n\tv_pk_mul_f32 %2, %2, %5\n\tv_pk_mul_f32 %3, %3, %5\n\tv_pk_mul_f32 %4, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4) : "v"(q0)); \
+        if (KIND == 10) asm volatile("v_cvt_pk_f16_f32 %0, %0, %5\n\tv_cvt_pk_f16_f32 %1, %1, %6\n\tv_cvt_pk_f16_f32 %2, %2, %7\n\tv_cvt_pk_f16_f32 %3, %3, %8\n\tv_cvt_pk_f16_f32 %4, %4, %9" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 11) asm volatile("v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %7, %8\n\tv_max3_f32 %3, %3, %8, %9\n\tv_max3_f32 %4, %4, %9, %5" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 12) asm volatile("v_alignbit_b32 %0, %0, %5, 31\n\tv_alignbit_b32 %1, %1, %6, 31\n\tv_alignbit_b32 %2, %2, %7, 31\n\tv_alignbit_b32 %3, %3, %8, 31\n\tv_alignbit_b32 %4, %4, %9, 31" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 13) asm volatile("v_fma_mixlo_f16 %0, %5, 1.0, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %1, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %2, %7, 1.0, -%2 op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %3, %8, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixlo_f16 %4, %9, 1.0, -%4 op_sel_hi:[0,0,1]" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 14) asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0" ::: "memory");                              \
+        if (KIND == 15) asm volatile("v_mov_b32_e32 %0, %5\n\tv_mov_b32_e32 %1, %6\n\tv_mov_b32_e32 %2, %7\n\tv_mov_b32_e32 %3, %8\n\tv_mov_b32_e32 %4, %9" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 16) asm volatile("v_fma_f32 %0, %0, %5, 0.5\n\ts_nop 0\n\tv_fma_f32 %1, %1, %6, 0.5\n\ts_nop 0\n\tv_fma_f32 %2, %2, %7, 0.5" : "+v"(e0), "+v"(e1), "+v"(e2) : "v"(f0), "v"(f1), "v"(f2)); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    } while (0)
+    for (int it = 0; it < reps; ++it) {
+#pragma unroll
+        for (int b = 0; b < BLOCKS; ++b) {
+            half8 n0, m0, n1, m1;
+            const unsigned a = base + (b & 15) * 4096;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                         : "=v"(n0), "=v"(m0), "=v"(n1), "=v"(m1) : "v"(a) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, x, a0, 0, 0, 0); VALU5();
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, x, a1, 0, 0, 0); VALU5();
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, x, a0, 0, 0, 0); VALU5();
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, x, a1, 0, 0, 0); VALU5();
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1, x, a0, 0, 0, 0); VALU5();
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, x, a1, 0, 0, 0); VALU5();
+            h0 = n0; l0 = m0; h1 = n1; l1 = m1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+    s += e0 + e1 + e2 + e3 + e4 + p0[0] + p1[1] + p2[0] + p3[1] + p4[0];
+    s += (float)h0[0] + (float)l1[3];
+    if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 7 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+}
+struct Res { double us; double ghz; };
+template <int KIND> Res t_run(float* d, unsigned long long* clk, int reps) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<KIND>), dim3(256 * 4), dim3(256), 0, 0, d, clk, reps);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2]; (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    Res r;
+    r.us = ms * 1e3 / (4.0 * reps * BLOCKS);
+    r.ghz = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return r;
+}
+#define NV 17
+template <int V> void all(Res (*t)[8], int r, float* d, unsigned long long* clk) {
+    t[V][r] = t_run<V>(d, clk, 20);
+    if constexpr (V + 1 < NV) all<V + 1>(t, r, d, clk);
+}
+int main() {
+    float* d; (void)hipMalloc(&d, 1024);
+    unsigned long long* clk; (void)hipMalloc(&clk, 64);
+    const char* name[NV] = {"6 MFMA", "v_fma v,v,s,c (1 vgpr src)", "v_fma v,v,v',c (2 vgpr src)", "v_fma v,v,v',v'' (3 vgpr src)", "v_add_e32 (2 vgpr src)",
+                            "v_mul_e32 s,v (1 vgpr src)", "v_max_e32 0,v (1 vgpr src)", "v_accvgpr_read (idle agprs)", "v_pk_fma_f32 (3 x 64-bit src)",
+                            "v_pk_mul_f32 (2 x 64-bit src)", "v_cvt_pk_f16_f32 (2 src)", "v_max3_f32 (3 src)", "v_alignbit (2 src + imm)",
+                            "v_fma_mixlo_f16 (2 vgpr src)", "s_nop 0 x5", "v_mov_b32 (1 src)", "3 x v_fma (2 src) + 2 s_nop"};
+    const int R = 6;
+    static Res t[NV][8];
+    for (int r = 0; r < 3; ++r) t_run<0>(d, clk, 20);
+    for (int r = 0; r < R; ++r) all<0>(t, r, d, clk);
+    double base = 0;
+    for (int v = 0; v < NV; ++v) {
+        double sum = 0, g = 0;
+        for (int r = 0; r < R; ++r) { sum += t[v][r].us; g += t[v][r].ghz; }
+        const double cyc = sum / R * 1e3 * g / R;
+        if (v == 0) base = cyc;
+        printf("%-36s %.4f us / block  %.2f GHz  %4.0f cycles per block  -> %.2f cycles per instruction\n", name[v], sum / R, g / R, cyc, (cyc - base) / 30.0);
+    }
+    return 0;
+}
