@@ -54,6 +54,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_ABL
 #define F16_ABL 0             // timing ablations (WRONG results): 1 no ring barrier, 2 no vmcnt wait, 4 no LDS-DMA, 8 no pipelined epilogue (MFMAs die too), 16 empty epilogue slices (MFMAs kept)
 #endif
+#ifndef F16_EARLY_DMA
+#define F16_EARLY_DMA 1       // k_field16: the first chunk's LDS-DMA at the top of the kernel instead of behind the prologue's loads
+#endif
 #ifndef F16_DMA_SPREAD
 #define F16_DMA_SPREAD 1      // LDS-DMA of the next chunk two pieces per block over four blocks instead of eight pieces behind the barrier
 #endif
@@ -141,13 +144,19 @@ __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h
     h1 = *reinterpret_cast<const half8*>(s + 16384);
     l1 = *reinterpret_cast<const half8*>(s + 24576);
 }
-__device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
-    w16_stage(w, first_blk / F16_CHUNK);
+// w16_begin = w16_begin_issue (the first chunk's LDS-DMA: as early in the kernel as possible, its L2 round trip then runs under the
+// rest of the prologue) + w16_begin_wait
+__device__ __forceinline__ void w16_begin_issue(W16& w, int first_blk) { w16_stage(w, first_blk / F16_CHUNK); }
+__device__ __forceinline__ void w16_begin_wait(W16& w, int lane, int first_blk) {
     w16_boundary(w, first_blk);
 #if F16_DMA_SPREAD && !(F16_ABL & 4)
     if (first_blk / F16_CHUNK + 1 < F16_NCHUNK) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
 #endif
     w16_read(w, first_blk, lane, w.h0, w.l0, w.h1, w.l1);
+}
+__device__ __forceinline__ void w16_begin(W16& w, int lane, int first_blk) {
+    w16_begin_issue(w, first_blk);
+    w16_begin_wait(w, lane, first_blk);
 }
 
 // (accM, accC) += W[32 rows][32*KB k] * (xh, xl): consumes KB blocks starting at stream block `blk`.
@@ -504,15 +513,23 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     int64_t count = (active_list ? (int64_t)(*active_count) : N) - slot_base;
     if (MODE == F16_BWD && count > rec_cap) count = rec_cap;
     if ((int64_t)blockIdx.x * 128 >= count) return;   // block-uniform: the barriers below need all 4 waves
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
+    w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    w.wave = wave;
+#if F16_TIMING
+    unsigned long long tstamp[6], rstamp[6];
+#endif
+    F16_STAMP(0);
+#if F16_EARLY_DMA
+    w16_begin_issue(w, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);   // first: the weights' trip from L2 runs under the rest of the prologue
+#endif
     int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
     const int64_t pt = active_list ? (int64_t)active_list[slot_base + slot] : slot_base + slot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
-#if F16_TIMING
-    unsigned long long tstamp[6], rstamp[6];
-#endif
-    F16_STAMP(0);
 
     for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
         s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
@@ -524,12 +541,10 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
     const float* const v_wrgb3 = s_vec + 256 + (OFF_WRGB3 - OFF_B1);
     const float* const v_scal = s_vec + 2560;
-    W16 w;
-    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
-    w.ring = ring;
-    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
-    w.wave = wave;
-    w16_begin(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
+#if !F16_EARLY_DMA
+    w16_begin_issue(w, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
+#endif
+    w16_begin_wait(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
     int blk = MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0;
     F16_STAMP(1);
 
@@ -1169,7 +1184,9 @@ __device__ __forceinline__ half2v relu_pair16(float u, float v, half2v& ovf) {
     const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
     const half2v s = {(_Float16)F16_FWD_INV, (_Float16)F16_FWD_INV};
     h = __builtin_elementwise_max(h, z);
-    ovf = __builtin_elementwise_max(ovf, h);          // before the exact 2^-6 scaling: 64 z is what has to fit
+    // before the exact 2^-6 scaling: 64 z is what has to fit.  (asm: as a builtin the running maximum is re-associated into one
+    // tree at the end of the tile and every h stays live until then)
+    asm("v_pk_max_f16 %0, %0, %1" : "+v"(ovf) : "v"(h));
     return h * s;
 }
 __device__ __forceinline__ void relu_half16(const f32x16& a, const f32x16& b, half8 (&y)[2], half2v& ovf) {
@@ -1214,17 +1231,15 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     __shared__ __attribute__((aligned(16))) half8 s_pe[4][64 * NW];
     __shared__ int s_cnt[NW];
     __shared__ int s_base;
-    const int tid = threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int tid0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5;
+    int tid = tid0, lane = lane0;
     const int64_t count = active_list ? (int64_t)(*active_count) : N;
-    if ((int64_t)blockIdx.x * (32 * NW) >= count) return;
-    int64_t slot = ((int64_t)blockIdx.x * NW + wave) * 32 + (lane & 31);
-    const bool valid = slot < count;
-    if (!valid) slot = count - 1;
-    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
-    const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+    // persistent workgroups: tile t = samples [t * 32 NW, (t + 1) * 32 NW) of the list, tiles dealt round-robin.  The small vectors
+    // are fetched once per workgroup, the next tile's points and the next tile's first weight chunk travel under the current tile
+    const int64_t ntiles = (count + 32 * NW - 1) / (32 * NW);
+    if ((int64_t)blockIdx.x >= ntiles) return;
     for (int i = tid; i < 256 + 2304 + 8; i += 64 * NW)
         s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
     for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += 64 * NW) s_vec[i] *= F16_FWD_SCALE;
@@ -1236,6 +1251,26 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
     w16s_stage<NW>(w, 0);
+    auto tile_point = [&](int64_t t, bool& ok) -> int64_t {
+        int64_t sl = (t * NW + wave) * 32 + (lane & 31);
+        ok = sl < count;
+        if (!ok) sl = count - 1;
+        return active_list ? (int64_t)active_list[sl] : sl;
+    };
+    bool valid_n;
+    int64_t pt_n = tile_point(blockIdx.x, valid_n);
+    float xn[3] = {x_c[3 * pt_n], x_c[3 * pt_n + 1], x_c[3 * pt_n + 2]};
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // (opaque copies: the unrolled body holds hundreds of LDS addresses derived from these two; loop-invariant, the compiler
+    //  would hoist them all out of the tile loop and spill)
+    tid = tid0; lane = lane0;
+    asm volatile("" : "+v"(tid), "+v"(lane), "+v"(w.g));      // (w.g: one 64-bit DMA source address per chunk otherwise)
+    const int half = lane >> 5;
+    const bool valid = valid_n;
+    const int64_t pt = pt_n;
+    const float xa[3] = {xn[0], xn[1], xn[2]};
+    const bool more = tile + gridDim.x < ntiles;      // workgroup-uniform
+    if (more) pt_n = tile_point(tile + gridDim.x, valid_n);       // (its x_c follows further down, when the index has arrived)
     w16s_boundary<NW>(w, 0);
     w16s_read(w, 0, lane, w.h0, w.h1);
     int blk = 0;
@@ -1266,6 +1301,7 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
         relu_half16(a0, a1, ah[m], ovf);
     }
     layer16s<NW>(w, blk, lane, v_b1 + 0 * 256, ah, bh, ovf);
+    if (more) { xn[0] = x_c[3 * pt_n]; xn[1] = x_c[3 * pt_n + 1]; xn[2] = x_c[3 * pt_n + 2]; }
     layer16s<NW>(w, blk, lane, v_b1 + 1 * 256, bh, ah, ovf);
     layer16s<NW>(w, blk, lane, v_b1 + 2 * 256, ah, bh, ovf);
     // stage2.0 : [h, pe] -> 256
@@ -1329,6 +1365,8 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     const unsigned long long bm = __ballot(keep);
     if (lane == 0) s_cnt[wave] = __popcll(bm);
     __syncthreads();
+    // (every wave has read its last weight block: the ring is free for the next tile's first chunk)
+    if (more) w16s_stage<NW>(w, 0);
     if (tid == 0) {
         int tot = 0;
 #pragma unroll
@@ -1341,6 +1379,7 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
         for (int k = 0; k < wave; ++k) off += s_cnt[k];
         keep_list[off] = (int32_t)pt;
     }
+  }
 }
 
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
@@ -1351,10 +1390,10 @@ void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const flo
     // experiment switch: overrides the margin the packed parameters carry (default / calibrated, see k_screen16)
     static const float margin = getenv("DSN_SCREEN_MARGIN") ? (float)atof(getenv("DSN_SCREEN_MARGIN")) : 0.0f;
     if (four)
-        hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, st, packed, fs, x_c, N, active_list,
+        hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)std::min<int64_t>((N + 127) / 128, 2 * dsn_cu_count())), dim3(256), 0, st, packed, fs, x_c, N, active_list,
                            active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
     else
-        hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)((N + 255) / 256)), dim3(512), 0, st, packed, fs, x_c, N, active_list,
+        hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)std::min<int64_t>((N + 255) / 256, dsn_cu_count())), dim3(512), 0, st, packed, fs, x_c, N, active_list,
                            active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
 }
 

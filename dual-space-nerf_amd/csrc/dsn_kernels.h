@@ -2,6 +2,20 @@
 #pragma once
 #include "dsn_common.h"
 
+// persistent-workgroup kernels launch one workgroup per compute unit (DSN_PERSISTENT_GROUPS overrides the count: experiments)
+#include <algorithm>
+#include <cstdlib>
+inline int dsn_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        const char* e = getenv("DSN_PERSISTENT_GROUPS");
+        if (e && atoi(e) > 0) v = atoi(e);
+        return v;
+    }();
+    return n;
+}
+
 void dsn_launch_face_setup(const float* verts, const int32_t* faces, int F, DsnFaceRec* recs, float4* cent,
                            hipStream_t st);
 void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_idx, int zero_code,
