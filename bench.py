@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
     ap.add_argument("--no-screen", action="store_true", help="disable the plain-fp16 density screen (DSN_NO_SCREEN)")
+    ap.add_argument("--early-stop", default="auto", choices=["auto", "on", "off"],
+                    help="front-to-back slices with ray termination (DSN_EARLY_STOP): auto = like Renderer, from the statistics of one "
+                         "probe frame at set-up (used when it would leave out >= 4 %% of the non-transparent samples)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="frames in flight (each on its own HIP stream with its own scene / workspace): the per-frame setup, "
                          "sampling and warp kernels of frame k+1 run beside the field kernels of frame k; 1 = strictly serial")
@@ -161,6 +164,18 @@ def main():
         screen_info = packed.calibrate_screen(scene)
         if not screen_info["usable"]:
             args.no_screen = True
+    # front-to-back slices with ray termination: decided like Renderer does, from one probe frame (set-up, not a step)
+    stop_info = {"enabled": False}
+    if not (args.dense or args.fp32) and args.early_stop != "off":
+        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+        _lib.render_rays(scene, packed, ws, ray_o, ray_d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False,
+                         screen=not args.no_screen, stop_stats=True)
+        torch.cuda.synchronize()
+        st = _lib.read_stop_stats(ws)
+        frac = st["would_skip"] / max(st["active"], 1)
+        stop_info = {"enabled": args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED,
+                     "probe_frame_would_skip_fraction_of_non_transparent": frac, "eps": 2.0 ** -20}
+    early = stop_info["enabled"]
     torch.cuda.synchronize()
     k_step = 0
 
@@ -176,7 +191,7 @@ def main():
             scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
             outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                        skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
-                                       screen=not args.no_screen)
+                                       screen=not args.no_screen, early_stop=early)
             if use_dist:
                 packed_px[j][:, 0:3] = outs[j]["color"]
                 packed_px[j][:, 3] = outs[j]["disp_map"]
@@ -214,6 +229,11 @@ def main():
     n_active = int(ws.buf[:4].view(torch.int32)[0]) if not args.dense else R * S
     n_pos = int(ws.buf[64:68].view(torch.int32)[0]) if (not args.dense and not args.fp32) else n_active
     n_kept = int(ws.buf[128:132].view(torch.int32)[0]) if (not args.dense and not args.fp32 and not args.no_screen) else n_active
+    if early:       # sliced frame: word 32 holds the last slice's count only; report what the termination left out instead
+        st = _lib.read_stop_stats(ws)
+        stop_info["skipped_fraction_of_non_transparent"] = st["skipped"] / max(st["active"], 1)
+        stop_info["unshaded_fraction_of_positive_density"] = st["unshaded"] / max(n_pos, 1)
+        n_kept = None
     ms_step = 1e3 * dt / args.steps
     value = world * R * args.steps / dt
 
@@ -235,7 +255,8 @@ def main():
             "shaded_sample_fraction": n_pos / float(R * S),
             "density_screen": not (args.dense or args.fp32 or args.no_screen),
             "density_screen_calibration": screen_info, "weights": args.weights,
-            "accurate_pass_sample_fraction": n_kept / float(R * S),
+            "accurate_pass_sample_fraction": None if n_kept is None else n_kept / float(R * S),
+            "early_stop": stop_info,
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense

@@ -47,6 +47,9 @@ FIELD_FP32 = 4
 SAMPLE_UNIFORM = 8
 NO_SCREEN = 16
 SCREEN_AUDIT = 32
+EARLY_STOP, STOP_STATS = 64, 128
+CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
+EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
 SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.05      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
 SCREEN_MIN_DROPPED = 0.35     # PackedParams.calibrate_screen: below this share of dropped calibration points the screen stays off
 RAYS_ZJU, RAYS_H36M = 0, 1
@@ -113,6 +116,7 @@ class PackedParams:
         self._keep = None
         self.generation = 0        # bumped by every re-pack: what calibrations / caches of derived state key on
         self.screen = None         # dict(deviation, margin, overflow_fraction, points, usable) once calibrate_screen() has run
+        self.early_stop = None     # dict(skipped_fraction, usable) once a frame's DSN_STOP_STATS have been read (Renderer / bench.py)
 
     def update(self, state: dict, force=False):
         """state: name -> tensor (any device).  Re-packs only when a tensor changed (data pointer / version counter).
@@ -129,6 +133,7 @@ class PackedParams:
         self._versions = versions
         self.generation += 1
         self.screen = None         # the packed image carries the conservative default margin again
+        self.early_stop = None
         return self
 
     def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20, other_frames=(0, 125, 250, 375, 499)):
@@ -433,8 +438,10 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True, train_cache=None, audit=False):
-    """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors."""
+                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False):
+    """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors.
+    early_stop: DSN_EARLY_STOP (eval mode: front-to-back slices, rays end once their transmittance is below 2^-20).
+    stop_stats: DSN_STOP_STATS (count what early stop would leave out; read ws word CNT_STOP + 2)."""
     R = ray_o.shape[0]
     dev = scene.device
     if out is None:
@@ -458,6 +465,10 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= NO_SCREEN
     elif audit:
         flags |= SCREEN_AUDIT
+    if early_stop and (flags & SKIP_TRANSPARENT) and not fp32:
+        flags |= EARLY_STOP
+    if stop_stats:
+        flags |= STOP_STATS
     buf = ws.get(R, S)
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT
@@ -476,6 +487,15 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                  _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
            "dsn_render_rays")
     return out
+
+
+def read_stop_stats(ws):
+    """(synchronises) dict(active, would_skip, skipped, unshaded) of the last dsn_render_rays on this workspace (or of a copy of its
+    first 256 bytes): non-transparent samples; what DSN_STOP_STATS counted (samples early stop would leave out); what
+    DSN_EARLY_STOP left out / did not shade."""
+    buf = ws if isinstance(ws, torch.Tensor) else ws.buf
+    c = buf[:256].view(torch.int32).cpu()
+    return {"active": int(c[CNT_ACTIVE]), "would_skip": int(c[CNT_STOP + 2]), "skipped": int(c[CNT_STOP]), "unshaded": int(c[CNT_STOP + 1])}
 
 
 class GradWorkspace:

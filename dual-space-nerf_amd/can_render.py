@@ -131,6 +131,11 @@ class Renderer:
         self.density_screen = True        # eval mode: plain-fp16 screen in front of the accurate pass (exact by its margin)
         self.screen_audit = False         # eval mode: re-check 1/128 of the screened-out samples every frame
         self.screen_info = None           # what the last calibration of the screen found (PackedParams.calibrate_screen)
+        # eval mode: front-to-back slices with ray termination (DSN_EARLY_STOP; pixel error < 64 * 2^-20 x colour).  "auto": the first
+        # eval frame of a parameter version also counts what termination would leave out (DSN_STOP_STATS); from the next frame
+        # on it is used if that is at least _lib.EARLY_STOP_MIN_SKIPPED of the non-transparent samples.  True / False force it.
+        self.early_stop = "auto"
+        self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
 
     # ---- mode switches (reference :26-38) ----
     def train(self):
@@ -406,9 +411,43 @@ class Renderer:
         skip = self.skip_transparent and not self.net.training
         if screen is None:
             screen = skip and noise is None and self._screen_usable()
-        return _lib.render_rays(scene, self.net.packed(self.device), ws, o, d, near, far, S, self._t_vals(S), jitter, noise,
-                                skip_transparent=skip, uniform=(self.sample_points_mode == "uniform"), screen=screen,
-                                audit=self.screen_audit)
+        packed = self.net.packed(self.device)
+        stop, stats = False, False
+        if skip and noise is None:
+            if self.early_stop == "auto":
+                self._read_stop_probe()
+                if packed.early_stop is None:
+                    if self._stop_probe is None:
+                        stats = True
+                else:
+                    stop = packed.early_stop["usable"]
+            else:
+                stop = bool(self.early_stop)
+        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise,
+                               skip_transparent=skip, uniform=(self.sample_points_mode == "uniform"), screen=screen,
+                               audit=self.screen_audit, early_stop=stop, stop_stats=stats)
+        if stats:
+            snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stop_probe = (packed.generation, snap, ev)
+        return out
+
+    def _read_stop_probe(self, wait=False):
+        """early_stop = "auto": pick up the statistics of the probe frame once it has finished (no wait unless asked)."""
+        if self._stop_probe is None:
+            return
+        gen, snap, ev = self._stop_probe
+        if not wait and not ev.query():
+            return
+        ev.synchronize()
+        self._stop_probe = None
+        packed = self.net.packed(self.device)
+        if packed.generation != gen:
+            return
+        st = _lib.read_stop_stats(snap)
+        frac = st["would_skip"] / max(st["active"], 1)
+        packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED}
 
     def last_screen_audit(self, ws=None):
         """(screen_audit = True) what the audit of the last eval frame found - synchronises.  dict(audited, violations,

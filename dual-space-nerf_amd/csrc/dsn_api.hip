@@ -372,7 +372,7 @@ int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, co
 #define DSN_CELLMAJOR_MIN (1 << 20)   // below ~1 M samples the five extra launches cost more than they save (measured:
                                       // -0.12 ms at 128x128x32, +0.42 ms at 256x256x64)
 struct DsnWorkspace {
-    int32_t* count;       // [64] (first word = number of active samples)
+    int32_t* count;       // [128] (first word = number of active samples)
     int32_t* active;      // [N]
     uint8_t* transparent; // [N]
     float* z;             // [N] (used when the caller does not want z_vals)
@@ -389,6 +389,9 @@ struct DsnWorkspace {
     int32_t* keep;        // [N]   samples the density screen could not rule out
     int32_t* audit;       // [audit_cap] samples declared empty that DSN_SCREEN_AUDIT sends through the accurate pass anyway
     int audit_cap;
+    float* T;             // [R]   DSN_EARLY_STOP: transmittance of every ray after the slices evaluated so far
+    int32_t* slices;      // [N]   the active list split by slice (slice k at k * R * L); later the shading list
+    int32_t* alive;       // [N]   the current slice's samples on rays that are not finished
     size_t bytes;
 };
 // words of DsnWorkspace::count (device, int32): diagnostics the host mirror reads after a frame
@@ -397,6 +400,20 @@ struct DsnWorkspace {
 #define DSN_CNT_KEEP 32       // samples the density screen sent to the accurate pass
 #define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: samples audited, [44] of those with accurate sigma > 0, [45] their max sigma (float bits)
 #define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
+#define DSN_CNT_BYTES 512
+#define DSN_CNT_SLICE 64      // DSN_EARLY_STOP: [64..95] active samples per slice (at most 32 slices), [12] alive in the current slice,
+#define DSN_STOP_MAX_SLICES 32
+#define DSN_CNT_ALIVE 12      //                 [13] reverse-pass slots, [14] shaded samples
+#define DSN_CNT_SEL 13
+#define DSN_CNT_LIT 14
+#define DSN_CNT_STOP 56       // [56] samples left out by ray termination, [57] samples not shaded (weight < eps), [58] DSN_STOP_STATS
+#define DSN_STOP_EPS 9.5367431640625e-07f   // 2^-20
+static inline int dsn_slice_len(int S) {
+    const char* e = getenv("DSN_STOP_SLICE");      // experiments: samples per slice
+    int L = e ? atoi(e) : 8;
+    if (L < 1) L = 8;
+    return (S + L - 1) / L <= DSN_STOP_MAX_SLICES ? L : (S + DSN_STOP_MAX_SLICES - 1) / DSN_STOP_MAX_SLICES;
+}
 // Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
 // pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for half of the samples of a
 // big frame (the bench frame puts 11.6 % of its samples there, a solid trained network 39 %); samples beyond the capacity
@@ -411,7 +428,7 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     DsnWorkspace w;
     size_t N = (size_t)R * S;
     char* p = (char*)base;
-    w.count = (int32_t*)p;        p += 256;
+    w.count = (int32_t*)p;        p += DSN_CNT_BYTES;
     w.active = (int32_t*)p;       p += dsn_align256(4 * N);
     w.transparent = (uint8_t*)p;  p += dsn_align256(N);
     w.z = (float*)p;              p += dsn_align256(4 * N);
@@ -428,6 +445,9 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
     w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
     w.audit = (int32_t*)p;        p += dsn_align256(4 * (size_t)w.audit_cap);
+    w.T = (float*)p;              p += dsn_align256(4 * (size_t)R);
+    w.slices = (int32_t*)p;       p += dsn_align256(4 * N);
+    w.alive = (int32_t*)p;        p += dsn_align256(4 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -456,7 +476,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     int32_t* list = skip ? w.active : nullptr;
     int32_t* cnt = skip ? w.count : nullptr;
     if (skip) {
-        if (hipMemsetAsync(w.count, 0, 256, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
+        if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     const int32_t* nn_pre = nullptr;
@@ -482,7 +502,56 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     }
     if (flags & DSN_FIELD_FP32)
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
-    else if (skip) {
+    else if (skip && (flags & DSN_EARLY_STOP)) {
+        // eval mode, front to back: slices of L samples along the rays; a ray whose transmittance has fallen below eps is finished
+        const int L = dsn_slice_len(S), K = (S + L - 1) / L;
+        const int64_t cap = (int64_t)R * L;
+        const bool screen = !(flags & DSN_NO_SCREEN);
+        const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
+        int32_t* pcnt = w.count + DSN_CNT_POS;
+        dsn_launch_slice_bucket(w.active, w.count + DSN_CNT_ACTIVE, N, S, L, K, cap, w.slices, w.count + DSN_CNT_SLICE, st);
+        dsn_launch_fill_f32(w.T, R, 1.0f, st);
+        for (int k = 0; k < K; ++k) {
+            const int s0 = k * L, s1 = (k + 1) * L < S ? (k + 1) * L : S;
+            const int64_t Nk = (int64_t)R * (s1 - s0);
+            const int32_t* sl = w.slices + (int64_t)k * cap;
+            const int32_t* sc = w.count + DSN_CNT_SLICE + k;
+            if (k > 0) {
+                if (hipMemsetAsync(w.count + DSN_CNT_ALIVE, 0, 4, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
+                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, DSN_STOP_EPS, w.alive, w.count + DSN_CNT_ALIVE, w.count + DSN_CNT_STOP, st);
+                sl = w.alive;
+                sc = w.count + DSN_CNT_ALIVE;
+            }
+            if (screen) {
+                int32_t* kcnt = w.count + DSN_CNT_KEEP;
+                if (k > 0 && hipMemsetAsync(kcnt, 0, 4, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
+                dsn_launch_screen16((const float*)packed, s.frame, w.x_c, Nk, sl, sc, w.sigma, w.keep, kcnt, nullptr, nullptr, st,
+                                    audit ? w.audit : nullptr, audit ? w.count + DSN_CNT_AUDIT : nullptr, w.audit_cap);
+                sl = w.keep;
+                sc = kcnt;
+            }
+            // (the sigma > 0 list and its relu records keep growing from slice to slice)
+            dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, Nk, sl, sc, w.sigma, w.essence, w.masks, w.pos, pcnt, st,
+                                   w.rec_cap);
+            if (k + 1 < K) dsn_launch_advance_T(w.sigma, w.transparent, z, ray_d, R, S, s0, s1, w.T, st);
+        }
+        // shading list: weights from the densities alone (the compositor with a zero colour; flagged densities are still NaN and
+        // keep their rays' samples); scratch = the normal buffer, the output maps are rewritten by the real compositing below
+        float* wq = w.n_w;
+        dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, nullptr, R, S, out_rgb, out_disp, out_acc, wq, out_depth, st);
+        int32_t* sel = w.active;            // (both lists are dead by now)
+        int32_t* lit = w.slices;
+        dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, DSN_STOP_EPS, sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
+                            w.count + DSN_CNT_STOP + 1, st);
+        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, sel,
+                               w.count + DSN_CNT_SEL);
+        if (w.rec_cap < N)
+            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.rec_cap, w.sigma, w.essence, w.grad, st);
+        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.sigma, w.essence, w.grad, st);
+        if (audit) dsn_launch_screen_audit(w.audit, w.count + DSN_CNT_AUDIT, w.audit_cap, w.sigma, w.count + DSN_CNT_AUDIT + 4, st);
+        list = lit;
+        cnt = w.count + DSN_CNT_LIT;
+    } else if (skip) {
         // eval mode: forward for every non-transparent sample, then d sigma/dx, normals and lighting only where sigma > 0
         // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
         int32_t* pcnt = w.count + DSN_CNT_POS;
@@ -520,6 +589,8 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         dsn_launch_light16((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st);
+    if ((flags & DSN_STOP_STATS) && skip)
+        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), DSN_STOP_EPS, w.count + DSN_CNT_STOP + 2, st);
     return dsn_check_launch("dsn_render_rays");
 }
 
@@ -544,7 +615,7 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
     // (train mode has no exact-fp32 twin of the stored activations: samples outside the fp16 range are counted in count[48],
     //  which the host mirror checks - Renderer.range_overflow_count())
-    if (hipMemsetAsync(w.count, 0, 256, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays_train: memset failed");
+    if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays_train: memset failed");
     dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st,
                              w.count + DSN_CNT_RANGE);
     dsn_launch_normal(s, c.x_c, c.grad, N, nullptr, nullptr, c.idx_c, c.n_w, exh, st);

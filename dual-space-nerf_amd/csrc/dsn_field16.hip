@@ -493,7 +493,8 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
           int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
           float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad,
           uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count,
-          float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr, int64_t slot_base, int64_t rec_cap) {
+          float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr, int64_t slot_base, int64_t rec_cap,
+          const int32_t* __restrict__ sel) {
     // slot_base: the launch works on list slots slot_base ... (FULL mode as the overflow pass of the eval split, see dsn_render_rays)
     // rec_cap  : capacity of the relu-record array in samples.  FWD / BWD index the records by the sample's slot on the
     //            sigma > 0 list (FWD writes a record only for the samples it appends there, BWD reads slot s of the list it
@@ -528,7 +529,10 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
-    const int64_t pt = active_list ? (int64_t)active_list[slot_base + slot] : slot_base + slot;
+    // sel (BWD, early-stop shading list): entry `slot` names the SLOT of the sample on active_list (= the sigma > 0 list), which is
+    // also where its relu record lies; *active_count is then the length of sel
+    const int64_t lslot = sel ? (int64_t)sel[slot] : slot_base + slot;
+    const int64_t pt = active_list ? (int64_t)active_list[lslot] : lslot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
 
     for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
@@ -557,7 +561,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     float ovf = 0.0f;          // range guard: running max of |value| over everything this lane splits into fp16
     // per-sample mask record: [half][layer] uint4, 224 B contiguous per sample
     // TRAIN: indexed by sample; BWD: by the slot of the list it walks; FWD: by the slot the sample gets on the sigma > 0 list (below)
-    uint4* mrec = masks ? masks + ((size_t)(MODE == F16_BWD ? slot : pt) * 2 + half) * 7 : nullptr;
+    uint4* mrec = masks ? masks + ((size_t)(MODE == F16_BWD ? lslot : pt) * 2 + half) * 7 : nullptr;
     // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
     const int64_t tr_ls = N * 256;
     float* const th = ST && valid ? tr_h + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : h_l
@@ -811,7 +815,7 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0, (const int32_t*)nullptr);
 }
 // the same single-launch evaluation on slots slot_base ... of a list: the overflow pass of the eval split (samples of the
 // sigma > 0 list whose relu record did not fit get forward AND reverse here; identical values, see dsn_render_rays)
@@ -821,7 +825,7 @@ void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, list, count, sigma,
                        essence, grad, (uint4*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, slot_base, (int64_t)0);
+                       (float*)nullptr, slot_base, (int64_t)0, (const int32_t*)nullptr);
 }
 // training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
@@ -833,7 +837,7 @@ void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, cons
     // range_count (optional): incremented once per sample whose activations / adjoints left the fp16 range
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
-                       range_count, tr_h, tr_a, tr_rr, (int64_t)0, N);
+                       range_count, tr_h, tr_a, tr_rr, (int64_t)0, N, (const int32_t*)nullptr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -843,18 +847,19 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, (const int32_t*)nullptr);
 }
 // ... reverse pass on the sigma > 0 samples only
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st, float* sigma, int64_t rec_cap) {
+                            hipStream_t st, float* sigma, int64_t rec_cap, const int32_t* sel, const int32_t* sel_count) {
+    // sel / sel_count (DSN_EARLY_STOP): walk only the listed slots of pos_list (all below rec_cap); N bounds their number
     int64_t blocks = ((rec_cap < N ? rec_cap : N) + 127) / 128;
     if (blocks == 0) return;
     // sigma: only ever WRITTEN here, with the NaN flag of a sample whose adjoints left the fp16 range (see the header)
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
-                       pos_list, pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap);
+                       pos_list, sel ? sel_count : pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, sel);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -727,6 +727,216 @@ void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Front-to-back evaluation with exact ray termination (DSN_EARLY_STOP, eval mode).
+// utils/nerf_net_utils.py:24-39: weight_i = alpha_i * T_i with T_i = prod_{j<i}(1 - alpha_j + 1e-10) non-increasing along the ray, so
+// once T < eps every later sample has weight < eps and all of them together add less than eps to acc_map (eps * colour to the
+// pixel, eps * far to the depth).  The samples of a frame are therefore evaluated in slices of `L` samples along the rays; after
+// each slice T of every ray is advanced with the densities just computed (the compositor's own formula), and the next slice
+// leaves out the rays that are finished.  A density the split-fp16 pass flagged (NaN until the fp32 fallback has run) counts
+// as 0 here: T is then an upper bound and no ray ends early because of it.
+// ---------------------------------------------------------------------------------------------
+// List building is workgroup-aggregated: a workgroup takes DSN_AGG_ITEMS consecutive entries, places them with LDS atomics and
+// reserves its share of every output list with ONE global atomic per list (a global atomic per wavefront on a handful of hot
+// counters costs ~15 ns each: 9 ms for the 8-way split of a 6.6 M-entry list).
+#define DSN_AGG_PER_THREAD 8
+#define DSN_AGG_ITEMS (256 * DSN_AGG_PER_THREAD)
+// the active list split by slice: slice k = samples [k L, (k+1) L) of every ray -> lists + k * cap, counts[k]   (K <= 32)
+__global__ void __launch_bounds__(256) k_slice_bucket(const int32_t* __restrict__ active, const int32_t* __restrict__ active_count, int S,
+                                                       int L, int K, int64_t cap, int32_t* __restrict__ lists,
+                                                       int32_t* __restrict__ counts) {
+    __shared__ int s_cnt[32], s_base[32];
+    const int n = *active_count;
+    for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
+        if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int32_t idx[DSN_AGG_PER_THREAD];
+        int off[DSN_AGG_PER_THREAD], kk[DSN_AGG_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            kk[j] = -1;
+            if (i < n) {
+                idx[j] = active[i];
+                kk[j] = (idx[j] % S) / L;
+                off[j] = atomicAdd(&s_cnt[kk[j]], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < K && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(counts + threadIdx.x, s_cnt[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j)
+            if (kk[j] >= 0) lists[(int64_t)kk[j] * cap + s_base[kk[j]] + off[j]] = idx[j];
+        __syncthreads();
+    }
+}
+// the samples of a slice whose ray is still alive (T >= eps); stopped[0] += the others
+__global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__ list, const int32_t* __restrict__ count, int S,
+                                                      const float* __restrict__ T, float eps, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ out_count, int32_t* __restrict__ stopped) {
+    __shared__ int s_cnt[2], s_base;
+    const int n = *count;
+    for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int32_t idx[DSN_AGG_PER_THREAD];
+        int off[DSN_AGG_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            off[j] = -1;
+            if (i < n) {
+                idx[j] = list[i];
+                if (!(T[idx[j] / S] < eps)) off[j] = atomicAdd(&s_cnt[0], 1);
+                else atomicAdd(&s_cnt[1], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base = s_cnt[0] ? atomicAdd(out_count, s_cnt[0]) : 0;
+            if (s_cnt[1]) atomicAdd(stopped, s_cnt[1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j)
+            if (off[j] >= 0) out[s_base + off[j]] = idx[j];
+        __syncthreads();
+    }
+}
+// T[r] *= prod over the samples s0 <= i < s1 of (1 - alpha_i + 1e-10): k_composite's alpha (transparent samples and densities <= 0
+// give alpha = 0; NaN = flagged density counts as 0)
+__global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+                                                    const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
+                                                    int s0, int s1, float* __restrict__ T) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float t = T[r];
+    float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    const int64_t g0 = (int64_t)r * S;
+    float z = z_vals[g0 + s0];
+    for (int i = s0; i < s1; ++i) {
+        const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
+        const float dist = ((i + 1 < S) ? (zn - z) : 1e10f) * dn;
+        float s = sigma[g0 + i];
+        if (transparent && transparent[g0 + i]) s = 0.f;
+        s = s > 0.f ? s : 0.f;
+        const float alpha = 1.0f - expf(-s * dist);
+        t = t * ((1.0f - alpha) + 1e-10f);
+        z = zn;
+    }
+    T[r] = t;
+}
+__global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// Shading list: the samples of the sigma > 0 list whose compositing weight (k_composite's, from the densities alone) is not below
+// eps - the others add less than eps * colour each to their pixel, so d sigma/dx, the normal and the lighting MLP are skipped for
+// them (their colour stays 0).  sel = their SLOTS on the sigma > 0 list (the reverse pass reads the relu records by slot; only slots
+// below rec_cap, the rest takes the single-launch overflow pass), lit = their sample indices (normals, lighting).  A NaN weight
+// keeps the sample.
+__global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_count, int64_t rec_cap,
+                                                   const float* __restrict__ weight, const float* __restrict__ sigma, float eps,
+                                                   int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int32_t* __restrict__ lit,
+                                                   int32_t* __restrict__ lit_count, int32_t* __restrict__ culled) {
+    __shared__ int s_cnt[3], s_base[2];
+    const int n = *pos_count;
+    for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
+        if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int32_t idx[DSN_AGG_PER_THREAD];
+        int osel[DSN_AGG_PER_THREAD], olit[DSN_AGG_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            osel[j] = olit[j] = -1;
+            if (i < n) {
+                idx[j] = pos[i];
+                // (a flagged density is NaN until the fp32 fallback has run; the weights took it as 0, so the sample itself must stay)
+                const bool keep = i >= rec_cap || !(weight[idx[j]] < eps) || sigma[idx[j]] != sigma[idx[j]];
+                if (keep) {
+                    olit[j] = atomicAdd(&s_cnt[1], 1);
+                    if (i < rec_cap) osel[j] = atomicAdd(&s_cnt[0], 1);
+                } else
+                    atomicAdd(&s_cnt[2], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base[0] = s_cnt[0] ? atomicAdd(sel_count, s_cnt[0]) : 0;
+            s_base[1] = s_cnt[1] ? atomicAdd(lit_count, s_cnt[1]) : 0;
+            if (s_cnt[2]) atomicAdd(culled, s_cnt[2]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            if (osel[j] >= 0) sel[s_base[0] + osel[j]] = (int32_t)i;
+            if (olit[j] >= 0) lit[s_base[1] + olit[j]] = idx[j];
+        }
+        __syncthreads();
+    }
+}
+// statistics for the host's decision (DSN_STOP_STATS, a frame rendered WITHOUT early stop): out[0] += the non-transparent samples
+// that lie in a slice whose ray had T < eps when the slice began - what DSN_EARLY_STOP would have left out
+__global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+                                                     const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
+                                                     int L, float eps, int32_t* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int skipped = 0;
+    if (r < R) {
+        float t = 1.0f;
+        float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+        const float dn = dsn_norm3(d);
+        const int64_t g0 = (int64_t)r * S;
+        float z = z_vals[g0];
+        bool dead = false;
+        for (int i = 0; i < S; ++i) {
+            if (i % L == 0) dead = t < eps;
+            const bool tr = transparent && transparent[g0 + i];
+            if (dead && !tr) ++skipped;
+            const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
+            const float dist = ((i + 1 < S) ? (zn - z) : 1e10f) * dn;
+            float s = tr ? 0.f : sigma[g0 + i];
+            s = s > 0.f ? s : 0.f;
+            t = t * ((1.0f - (1.0f - expf(-s * dist))) + 1e-10f);
+            z = zn;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) skipped += __shfl_xor(skipped, off);
+    if ((threadIdx.x & 63) == 0 && skipped) atomicAdd(out, skipped);
+}
+
+void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int L, int K, int64_t cap,
+                             int32_t* lists, int32_t* counts, hipStream_t st) {
+    const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
+    hipLaunchKernelGGL(k_slice_bucket, dim3((unsigned)blocks), dim3(256), 0, st, active, active_count, S, L, K, cap, lists, counts);
+}
+void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, const float* T, float eps, int32_t* out,
+                            int32_t* out_count, int32_t* stopped, hipStream_t st) {
+    const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
+    hipLaunchKernelGGL(k_slice_alive, dim3((unsigned)blocks), dim3(256), 0, st, list, count, S, T, eps, out, out_count, stopped);
+}
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
+                          int s1, float* T, hipStream_t st) {
+    hipLaunchKernelGGL(k_advance_T, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, s0, s1, T);
+}
+void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
+                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled, hipStream_t st) {
+    const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
+    hipLaunchKernelGGL(k_cull_lit, dim3((unsigned)blocks), dim3(256), 0, st, pos, pos_count, rec_cap, weight, sigma, eps, sel, sel_count, lit,
+                       lit_count, culled);
+}
+void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
+                           float eps, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, eps, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // "next" row f-2: camera rays + AABB near/far on the device (whole-image path of
 // utils/rays_utils.py:16-30 get_rays, :63-97 get_near_far as used by my_sample_ray(nrays<=0), :176-184).
 // The reference does this in float64 numpy on the CPU and casts to float32: rays are produced in double,

@@ -49,7 +49,8 @@ void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const
                              const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st);
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st, float* sigma, int64_t rec_cap);
+                            hipStream_t st, float* sigma, int64_t rec_cap, const int32_t* sel = nullptr,
+                            const int32_t* sel_count = nullptr);
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
                          float* dbg_s1, hipStream_t st, int32_t* audit_list = nullptr, int32_t* audit_count = nullptr,
@@ -112,3 +113,15 @@ void dsn_launch_image_scatter(const float* rgb, const float* disp, const float* 
                               float* img_acc, float* img_depth, void* workspace, hipStream_t st);
 void dsn_launch_image_psnr(const float* img_rgb, const double* gt64, const float* gt32, const uint8_t* mask, int H, int W,
                            double* out4, void* workspace, hipStream_t st);
+// front-to-back slices with exact ray termination (dsn_geom.hip; DSN_EARLY_STOP in dsn_render_rays)
+void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int L, int K, int64_t cap,
+                             int32_t* lists, int32_t* counts, hipStream_t st);
+void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, const float* T, float eps, int32_t* out,
+                            int32_t* out_count, int32_t* stopped, hipStream_t st);
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
+                          int s1, float* T, hipStream_t st);
+void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
+void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
+                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled, hipStream_t st);
+void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
+                           float eps, int32_t* out, hipStream_t st);

@@ -706,3 +706,133 @@ def test_relu_record_capacity_overflow_is_exact(cap, monkeypatch):
     for k in ("color", "acc_map", "depth_map", "weights"):
         assert torch.equal(ref[k], got[k]), k
     assert float(ref["acc_map"].max()) > 0.05
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# front-to-back slices with ray termination (DSN_EARLY_STOP)
+# ------------------------------------------------------------------------------------------------------------------------
+STOP_EPS = 2.0 ** -20
+
+
+def _stop_pair(sd, hw=160, S=64, screen=True, **kw):
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=hw)
+    r = renderer_with(sd, canon, faces, S=S)
+    r.eval()
+    r._set_frame(batch)
+    if screen:
+        r._screen_usable()
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+
+    def run(**k2):
+        n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        ws = _lib.RenderWorkspace(r.device)
+        out = _lib.render_rays(r.scene, r.net.packed(r.device), ws, o, d, n, f, S, r._t_vals(S), screen=screen, **kw, **k2)
+        torch.cuda.synchronize()
+        return out, _lib.read_stop_stats(ws), ws
+
+    return run
+
+
+def _assert_stop_bound(ref, got, S):
+    """what DSN_EARLY_STOP may change: every left-out sample weighs < eps, all of a finished ray's together < eps in acc_map"""
+    cmax = max(1.0, float(ref["color"].abs().max()))
+    assert float((ref["acc_map"] - got["acc_map"]).abs().max()) <= 2 * STOP_EPS
+    assert float((ref["weights"] - got["weights"]).abs().max()) <= STOP_EPS
+    # (colour: < eps x the sample's colour per left-out sample; w3's per-sample colours reach a few times its largest pixel)
+    assert float((ref["color"] - got["color"]).abs().max()) <= 1e-4 * cmax
+    assert float((ref["depth_map"] - got["depth_map"]).abs().max()) <= 2 * STOP_EPS * float(ref["z_vals"].max())
+    assert torch.equal(ref["z_vals"], got["z_vals"])
+
+
+@pytest.mark.parametrize("S", [64, 128, 40])
+def test_early_stop_changes_nothing_when_no_ray_saturates(S):
+    """default parameters (a thin fog: no ray's transmittance gets near 2^-20): the sliced evaluation leaves nothing out and the
+    frame is bit-identical to the one-pass evaluation - slices of 16 (S = 64: 4, S = 128: 8, S = 40: 2 and a half)"""
+    run = _stop_pair(state(), hw=128, S=S)
+    ref, st0, _ = run(stop_stats=True)
+    got, st1, _ = run(early_stop=True)
+    assert st0["would_skip"] == 0 and st1["skipped"] == 0 and st1["active"] == st0["active"] > 0
+    assert st1["unshaded"] < 0.01 * st1["active"]      # (samples whose density is positive but so small that their weight is < 2^-20)
+    for k in ("acc_map", "depth_map", "disp_map", "weights"):       # every density is the one-pass density: same bits
+        assert torch.equal(torch.nan_to_num(ref[k], nan=-1.0), torch.nan_to_num(got[k], nan=-1.0)), k      # (disp: NaN where acc = 0)
+    assert float((ref["color"] - got["color"]).abs().max()) <= S * STOP_EPS * 2.5
+    assert float(ref["acc_map"].max()) > 0.05
+
+
+@pytest.mark.parametrize("screen", [True, False])
+def test_early_stop_on_a_solid_body_is_within_its_bound(screen):
+    """w3 (dense: sigma in the hundreds, rays saturate a few samples into the body): most samples behind the surface are
+    left out, the frame stays within the stated bound of the one-pass evaluation, and the statistics of a plain frame
+    (DSN_STOP_STATS) predict what the slicing leaves out"""
+    run = _stop_pair(state("x_w3"), hw=160, screen=screen)
+    ref, st0, _ = run(stop_stats=True)
+    got, st1, _ = run(early_stop=True)
+    assert st0["would_skip"] > 0.3 * st0["active"], st0
+    assert st1["skipped"] == st0["would_skip"], (st0, st1)          # same T (same densities, same formula) at the same slice borders
+    assert st1["unshaded"] > 0
+    _assert_stop_bound(ref, got, 64)
+    assert float(ref["acc_map"].max()) > 0.9
+
+
+def test_early_stop_matches_the_reference_golden():
+    """the reference's own rays of full_eval_w3 through the sliced path: same tolerances as the one-pass test"""
+    import test_gpu_render as TR
+    g = load("full_eval_w3")
+    r = TR.make_renderer(g, "full_eval_w3")
+    r.early_stop = True
+    r.eval()
+    out = r.render(TR.make_batch(g))["coarse"]
+    torch.cuda.synchronize()
+    st = __import__("dsnerf_amd")._lib.read_stop_stats(r._ws)
+    assert st["skipped"] > 0
+    for k, tol in (("color", 1e-4), ("acc_map", 1e-4), ("weights", 1e-4), ("depth_map", 3e-4)):
+        ref = g["render:" + k]
+        tol = max(tol, 2e-5 * float(np.abs(ref).max()), 3e-4 if k != "color" else 0) + 1e-4 * max(1.0, float(np.abs(ref).max())) * (k == "color")
+        assert maxdiff(out[k].cpu().numpy().reshape(ref.shape), ref) < tol, (k, tol)
+
+
+def test_early_stop_with_flagged_samples_and_small_record_capacity(monkeypatch):
+    """parameters that overflow fp16 (flagged samples: density NaN until the fp32 fallback has run - they count as 0 for the
+    termination and must stay on the shading list) and a relu-record capacity far below the number of sigma > 0 samples"""
+    run = _stop_pair(overflowing_state("nerf.stage1.4"), hw=128)
+    exact, _, _ = run(fp32=True)
+    monkeypatch.setenv("DSN_RECORD_CAP", "3000")
+    got, st, _ = run(early_stop=True)
+    monkeypatch.delenv("DSN_RECORD_CAP")
+    assert torch.isfinite(got["color"]).all()
+    assert float((got["color"] - exact["color"]).abs().max()) < 2e-4 * max(1.0, float(exact["color"].abs().max()))
+    assert float((got["weights"] - exact["weights"]).abs().max()) < 1e-4
+    run3 = _stop_pair(state("x_w3"), hw=128)
+    ref, _, _ = run3()
+    monkeypatch.setenv("DSN_RECORD_CAP", "3000")
+    got3, st3, _ = run3(early_stop=True)
+    monkeypatch.delenv("DSN_RECORD_CAP")
+    assert st3["skipped"] > 0
+    _assert_stop_bound(ref, got3, 64)
+
+
+def test_renderer_decides_early_stop_from_the_first_frame():
+    """Renderer.early_stop = "auto": the first eval frame of a parameter version is rendered in one pass and counts what
+    termination would leave out; with a solid body (w3) the following frames are sliced, with the default fog they are not"""
+    from dsnerf_amd import _lib
+    for name, want in (("x_w3", True), ("", False)):
+        canon, faces, batch = full_frame(hw=128)
+        r = renderer_with(state(name) if name else state(), canon, faces)
+        r.eval()
+        assert r.early_stop == "auto"
+        a = r.render_view(batch, device_output=True)
+        r._read_stop_probe(wait=True)
+        info = r.net.packed(r.device).early_stop
+        assert info is not None and info["usable"] is want, (name, info)
+        b = r.render_view(batch, device_output=True)
+        torch.cuda.synchronize()
+        st = _lib.read_stop_stats(r._ws)
+        assert (st["skipped"] > 0) is want
+        for k in a:
+            if torch.is_tensor(a[k]) and a[k].dtype == torch.float32:
+                bound = 1e-4 * max(1.0, float(torch.nan_to_num(a[k]).abs().max())) if want else 0.0
+                x, y = torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)      # (disp: NaN where acc = 0)
+                if "disp" in k:
+                    bound = bound * max(1.0, float(x.abs().max()))      # 1 / depth: relative
+                assert float((x - y).abs().max()) <= bound, (name, k)
