@@ -390,7 +390,7 @@ struct DsnWorkspace {
     int32_t* audit;       // [audit_cap] samples declared empty that DSN_SCREEN_AUDIT sends through the accurate pass anyway
     int audit_cap;
     float* T;             // [R]   DSN_EARLY_STOP: transmittance of every ray after the slices evaluated so far
-    int32_t* slices;      // [N]   the active list split by slice (slice k at k * R * L); later the shading list
+    int32_t* slices;      // [R (S + 64)] the active list split by slice (slice k at k * R * L); later the shading list
     int32_t* alive;       // [N]   the current slice's samples on rays that are not finished
     size_t bytes;
 };
@@ -412,8 +412,11 @@ static inline int dsn_slice_len(int S) {
     const char* e = getenv("DSN_STOP_SLICE");      // experiments: samples per slice
     int L = e ? atoi(e) : 8;
     if (L < 1) L = 8;
+    if (L > 64) L = 64;
     return (S + L - 1) / L <= DSN_STOP_MAX_SLICES ? L : (S + DSN_STOP_MAX_SLICES - 1) / DSN_STOP_MAX_SLICES;
 }
+// entries of the per-slice lists: K slices of R * L each, K * L < S + L whatever the slice length (above)
+static inline size_t dsn_slice_entries(size_t R, int S) { return R * ((size_t)S + (size_t)std::max(64, S / DSN_STOP_MAX_SLICES + 1)); }
 // Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
 // pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for half of the samples of a
 // big frame (the bench frame puts 11.6 % of its samples there, a solid trained network 39 %); samples beyond the capacity
@@ -446,7 +449,7 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
     w.audit = (int32_t*)p;        p += dsn_align256(4 * (size_t)w.audit_cap);
     w.T = (float*)p;              p += dsn_align256(4 * (size_t)R);
-    w.slices = (int32_t*)p;       p += dsn_align256(4 * N);
+    w.slices = (int32_t*)p;       p += dsn_align256(4 * dsn_slice_entries((size_t)R, S));
     w.alive = (int32_t*)p;        p += dsn_align256(4 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;

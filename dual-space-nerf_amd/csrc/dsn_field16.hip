@@ -314,7 +314,7 @@ __device__ __forceinline__ void mask16(f32x16& a, uint32_t m) {
 // running maximum of |v| over everything a lane splits into fp16 operands (range guard, see the header)
 __device__ __forceinline__ void track16(float& ovf, const f32x16& v) {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) ovf = fmaxf(fmaxf(ovf, fabsf(v[r])), fabsf(v[r + 1]));
+    for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(v[r]), "v"(v[r + 1]));   // (asm: see epi_slice)
 }
 __device__ __forceinline__ float dsn_nan_flag() { return __uint_as_float(0x7fc00000u); }
 
@@ -380,7 +380,10 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
         yl[r >> 3] = __builtin_bit_cast(half8, tl);
     }
 #endif
-    ovf = FWD ? fmaxf(fmaxf(ovf, vv[0]), vv[1]) : fmaxf(fmaxf(ovf, fabsf(vv[0])), fabsf(vv[1]));   // v_max3_f32 (relu output >= 0)
+    // v_max3_f32 (relu output >= 0).  As asm: written with fmaxf the running maximum is re-associated into one tree at the end of
+    // the tile inside the persistent tile loop, and every value stays live (spilled) until then
+    if (FWD) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(ovf) : "v"(vv[0]), "v"(vv[1]));
+    else asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(vv[0]), "v"(vv[1]));
     // Training stores.  The chunk boundary (w16_boundary: s_waitcnt vmcnt(0) for the LDS-DMA pieces) also waits for every
     // store in flight, and it sits right in front of slice 7 (blocks per output tile = blocks per chunk).  Stores issued slice
     // by slice were 1-3 blocks old at that wait and cost a full write latency per chunk (3.84 ms vs 2.34 ms without stores);
@@ -507,26 +510,42 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     // vmcnt wait would drain the LDS-DMA queue): [bias0 256 | OFF_B1.. 2304 (6 biases, rgb bias, W_den, W_rgb3) | scalars 8]
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
-    const int tid = threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int tid0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5;
     int64_t count = (active_list ? (int64_t)(*active_count) : N) - slot_base;
     if (MODE == F16_BWD && count > rec_cap) count = rec_cap;
-    if ((int64_t)blockIdx.x * 128 >= count) return;   // block-uniform: the barriers below need all 4 waves
+    // persistent workgroups: tile t = list slots [128 t, 128 t + 128), dealt round-robin over the grid (one workgroup per CU).  The
+    // small vectors are fetched once per workgroup; a launch sized for the worst case no longer pays for its empty workgroups
+    const int64_t ntiles = (count + 127) / 128;
+    if ((int64_t)blockIdx.x >= ntiles) return;   // block-uniform: the barriers below need all 4 waves
+    for (int i = tid0; i < 256 + 2304 + 8; i += F16_THREADS)
+        s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
+    // accumulators of the forward pass start from 64 x bias (6 trunk biases + rgb_net.1 bias follow bias0)
+    for (int i = tid0; i < 256 + (OFF_WDEN - OFF_B1); i += F16_THREADS) s_vec[i] *= F16_FWD_SCALE;
+    const float* const v_bias0 = s_vec;
+    const float* const v_b1 = s_vec + 256;                                  // + l * 256
+    const float* const v_brgb1 = s_vec + 256 + (OFF_BRGB1 - OFF_B1);
+    const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
+    const float* const v_wrgb3 = s_vec + 256 + (OFF_WRGB3 - OFF_B1);
+    const float* const v_scal = s_vec + 2560;
     W16 w;
-    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane * 16;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + wave * 8192 + 4096 + lane0 * 16;
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // (opaque copies: the unrolled body holds hundreds of LDS addresses derived from the thread index and one DMA source address per
+    //  chunk derived from w.g; loop-invariant, the compiler would hoist them all out of the tile loop and spill)
+    int tid = tid0, lane = lane0;
+    asm volatile("" : "+v"(tid), "+v"(lane), "+v"(w.g));
+    const int half = lane >> 5;
 #if F16_TIMING
     unsigned long long tstamp[6], rstamp[6];
 #endif
     F16_STAMP(0);
-#if F16_EARLY_DMA
     w16_begin_issue(w, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);   // first: the weights' trip from L2 runs under the rest of the prologue
-#endif
-    int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    int64_t slot = (tile * 4 + wave) * 32 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
     // sel (BWD, early-stop shading list): entry `slot` names the SLOT of the sample on active_list (= the sigma > 0 list), which is
@@ -534,20 +553,6 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const int64_t lslot = sel ? (int64_t)sel[slot] : slot_base + slot;
     const int64_t pt = active_list ? (int64_t)active_list[lslot] : lslot;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
-
-    for (int i = tid; i < 256 + 2304 + 8; i += F16_THREADS)
-        s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
-    // accumulators of the forward pass start from 64 x bias (6 trunk biases + rgb_net.1 bias follow bias0)
-    for (int i = tid; i < 256 + (OFF_WDEN - OFF_B1); i += F16_THREADS) s_vec[i] *= F16_FWD_SCALE;
-    const float* const v_bias0 = s_vec;
-    const float* const v_b1 = s_vec + 256;                                  // + l * 256
-    const float* const v_brgb1 = s_vec + 256 + (OFF_BRGB1 - OFF_B1);
-    const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
-    const float* const v_wrgb3 = s_vec + 256 + (OFF_WRGB3 - OFF_B1);
-    const float* const v_scal = s_vec + 2560;
-#if !F16_EARLY_DMA
-    w16_begin_issue(w, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
-#endif
     w16_begin_wait(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
     int blk = MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0;
     F16_STAMP(1);
@@ -723,7 +728,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         atomicAdd(&g_f16_timing[7], 1ull);
     }
 #endif
-    if (MODE == F16_FWD) return;
+    if (MODE == F16_FWD) { __syncthreads(); continue; }      // (tile done: every wave has read its last weight block)
   } else {
     // MODE == BWD: masks come back from the sample's record
 #pragma unroll
@@ -779,15 +784,18 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 
     // encoding backward (each lane re-derives its own sin / cos: both are needed for the derivative)
     {
+        // (opaque copy of the point: otherwise the forward pass's 60 sines and cosines are kept alive - spilled - across the tile)
+        float xb[3] = {xa[0], xa[1], xa[2]};
+        asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]));
         float g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 30; ++t) {
             const int j = t / 3, a = t % 3;
             float s, c;
 #if F16_SINCOS_OCML
-            sincosf(xa[a] * (float)(1 << j), &s, &c);
+            sincosf(xb[a] * (float)(1 << j), &s, &c);
 #else
-            dsn_sincos(xa[a] * (float)(1 << j), s, c);
+            dsn_sincos(xb[a] * (float)(1 << j), s, c);
 #endif
             const float d = dpe[t >> 4][t & 15];
             const float term = (d * (half ? s : c)) * (float)(1 << j);
@@ -806,6 +814,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         if (MODE == F16_TRAIN) { if (pos_count) atomicAdd(pos_count, 1); }    // training: counted, reported by the host mirror
         else sigma[pt] = dsn_nan_flag();
     }
+    if (MODE == F16_TRAIN) break;   // (the training kernel keeps one tile per workgroup: its extra live state leaves no room for the loop's)
+    __syncthreads();      // tile done: the ring is free for the next tile's first chunk
+  }
 }
 
 void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
@@ -813,7 +824,7 @@ void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const floa
                         float* grad, hipStream_t st) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
                        (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0, (const int32_t*)nullptr);
 }
@@ -823,7 +834,7 @@ void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const
                              const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st) {
     int64_t blocks = (N - slot_base + 127) / 128;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, list, count, sigma,
+    hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, list, count, sigma,
                        essence, grad, (uint4*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, slot_base, (int64_t)0, (const int32_t*)nullptr);
 }
@@ -845,7 +856,7 @@ void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const 
                             void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+    hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, (const int32_t*)nullptr);
 }
@@ -857,7 +868,7 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
     int64_t blocks = ((rec_cap < N ? rec_cap : N) + 127) / 128;
     if (blocks == 0) return;
     // sigma: only ever WRITTEN here, with the NaN flag of a sample whose adjoints left the fp16 range (see the header)
-    hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
+    hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        pos_list, sel ? sel_count : pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
                        (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, sel);
 }

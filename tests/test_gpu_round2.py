@@ -745,7 +745,7 @@ def _assert_stop_bound(ref, got, S):
     assert torch.equal(ref["z_vals"], got["z_vals"])
 
 
-@pytest.mark.parametrize("S", [64, 128, 40])
+@pytest.mark.parametrize("S", [64, 128, 40, 100])
 def test_early_stop_changes_nothing_when_no_ray_saturates(S):
     """default parameters (a thin fog: no ray's transmittance gets near 2^-20): the sliced evaluation leaves nothing out and the
     frame is bit-identical to the one-pass evaluation - slices of 16 (S = 64: 4, S = 128: 8, S = 40: 2 and a half)"""
