@@ -54,6 +54,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_ABL
 #define F16_ABL 0             // timing ablations (WRONG results): 1 no ring barrier, 2 no vmcnt wait, 4 no LDS-DMA, 8 no pipelined epilogue (MFMAs die too), 16 empty epilogue slices (MFMAs kept)
 #endif
+#ifndef F16_NEXT_POINT
+#define F16_NEXT_POINT 1      // k_field16: the next tile's list entry and coordinates are fetched under the current tile
+#endif
 #ifndef F16_EARLY_DMA
 #define F16_EARLY_DMA 1       // k_field16: the first chunk's LDS-DMA at the top of the kernel instead of behind the prologue's loads
 #endif
@@ -534,6 +537,20 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
+    // this tile's point comes from the previous tile's prefetch: list slot -> (slot on the list, sample index), then its coordinates
+    auto tile_point = [&](int64_t t, bool& ok, int64_t& ls) -> int64_t {
+        int64_t sl = (t * 4 + wave) * 32 + (lane0 & 31);
+        ok = sl < count;
+        if (!ok) sl = count - 1;
+        // sel (BWD, early-stop shading list): entry `sl` names the SLOT of the sample on active_list (= the sigma > 0 list), which
+        // is also where its relu record lies; *active_count is then the length of sel
+        ls = sel ? (int64_t)sel[sl] : slot_base + sl;
+        return active_list ? (int64_t)active_list[ls] : ls;
+    };
+    bool valid_n;
+    int64_t lslot_n;
+    int64_t pt_n = tile_point(blockIdx.x, valid_n, lslot_n);
+    float xn[3] = {x_c[3 * pt_n], x_c[3 * pt_n + 1], x_c[3 * pt_n + 2]};
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // (opaque copies: the unrolled body holds hundreds of LDS addresses derived from the thread index and one DMA source address per
     //  chunk derived from w.g; loop-invariant, the compiler would hoist them all out of the tile loop and spill)
@@ -545,14 +562,15 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #endif
     F16_STAMP(0);
     w16_begin_issue(w, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);   // first: the weights' trip from L2 runs under the rest of the prologue
-    int64_t slot = (tile * 4 + wave) * 32 + (lane & 31);
-    const bool valid = slot < count;
-    if (!valid) slot = count - 1;
-    // sel (BWD, early-stop shading list): entry `slot` names the SLOT of the sample on active_list (= the sigma > 0 list), which is
-    // also where its relu record lies; *active_count is then the length of sel
-    const int64_t lslot = sel ? (int64_t)sel[slot] : slot_base + slot;
-    const int64_t pt = active_list ? (int64_t)active_list[lslot] : lslot;
-    const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
+#if !F16_NEXT_POINT
+    if (tile != (int64_t)blockIdx.x) { pt_n = tile_point(tile, valid_n, lslot_n); xn[0] = x_c[3 * pt_n]; xn[1] = x_c[3 * pt_n + 1]; xn[2] = x_c[3 * pt_n + 2]; }
+#endif
+    const bool valid = valid_n;
+    const int64_t lslot = lslot_n, pt = pt_n;
+    const float xa[3] = {xn[0], xn[1], xn[2]};
+    const bool more = F16_NEXT_POINT && MODE != F16_TRAIN && tile + gridDim.x < ntiles;      // workgroup-uniform
+    if (more) pt_n = tile_point(tile + gridDim.x, valid_n, lslot_n);       // (its coordinates follow one layer into the tile: NEXT_POINT)
+#define NEXT_POINT() do { if (more) { xn[0] = x_c[3 * pt_n]; xn[1] = x_c[3 * pt_n + 1]; xn[2] = x_c[3 * pt_n + 2]; } } while (0)
     w16_begin_wait(w, lane, MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0);
     int blk = MODE == F16_BWD ? F16_FIRST_BWD_BLOCK : 0;
     F16_STAMP(1);
@@ -610,6 +628,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     }
     MK_STORE(0, mk)
     layer16_fwd<ST>(w, blk, lane, v_b1 + 0 * 256, ah, al, bh, bl, mk, ovf, th ? th + 1 * tr_ls : nullptr); MK_STORE(1, mk)
+    NEXT_POINT();
     layer16_fwd<ST>(w, blk, lane, v_b1 + 1 * 256, bh, bl, ah, al, mk, ovf, th ? th + 2 * tr_ls : nullptr); MK_STORE(2, mk)
     layer16_fwd<ST>(w, blk, lane, v_b1 + 2 * 256, ah, al, bh, bl, mk, ovf, th ? th + 3 * tr_ls : nullptr); MK_STORE(3, mk)
 #if F16_PIPE_LATE
@@ -750,6 +769,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         split16<true>(g, ah[m], al[m]);
     }
     MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 5 * tr_ls : nullptr);
+    if (MODE == F16_BWD) NEXT_POINT();
     MK_LOAD(4, mk) layer16_bwd<ST>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 4 * tr_ls : nullptr);
     MK_LOAD(3, mk)
     // stage2.0^T : 256 -> [256 h | 64 pe]  (epilogues not pipelined: as a layer16_bwd the reverse-only kernel spills 267 registers)
