@@ -20,3 +20,11 @@ python scripts/pmc_summary.py gpurun_out/pmcr ${O}_pmc.json | cut -c1-300 | head
 T="python bench.py --train --steps 5 --warmup 2"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_t -o t -- $T > ${O}_train_prof.log 2>&1
 python scripts/rocpd_summary.py gpurun_out/prof_t/t_results.db > ${O}_train_kernel_trace.txt; cut -c1-150 ${O}_train_kernel_trace.txt | head -24
+# the other bench lines kept under profiles/: strong scaling frame (configs[3]) alone and through RCCL with one rank, the weak line through RCCL,
+# the trained-like parameter sets
+timeout 600 python bench.py --strong --no-cpu-baseline 2>/dev/null | tail -1 > ${O}_strong.json
+DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --strong --no-cpu-baseline 2>/dev/null | tail -1 > ${O}_strong_rccl.json
+DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > ${O}_weak_rccl.json
+for wt in w2 w3; do timeout 600 python bench.py --weights $wt --no-cpu-baseline 2>/dev/null | tail -1 > ${O}_$wt.json; done
+for f in strong strong_rccl weak_rccl w2 w3; do python -c "
+import json; d = json.load(open('${O}_$f.json')); print('$f', round(d['ms_per_step'], 2), 'ms')"; done
