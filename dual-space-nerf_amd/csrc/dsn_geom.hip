@@ -805,27 +805,32 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
 }
 // T[r] *= prod over the samples s0 <= i < s1 of (1 - alpha_i + 1e-10): k_composite's alpha (transparent samples and densities <= 0
 // give alpha = 0; NaN = flagged density counts as 0)
+// One lane per (ray, sample of the slice): groups of G = 2^g >= s1 - s0 lanes share a ray (consecutive samples: coalesced reads),
+// the factors are multiplied by a butterfly inside the group.
+template <int G>
 __global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                     const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
                                                     int s0, int s1, float* __restrict__ T) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    float t = T[r];
-    float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
-    const float dn = dsn_norm3(d);
-    const int64_t g0 = (int64_t)r * S;
-    float z = z_vals[g0 + s0];
-    for (int i = s0; i < s1; ++i) {
-        const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
-        const float dist = ((i + 1 < S) ? (zn - z) : 1e10f) * dn;
-        float s = sigma[g0 + i];
-        if (transparent && transparent[g0 + i]) s = 0.f;
+    const int64_t gl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gl / G;
+    const int j = (int)(gl % G), i = s0 + j;
+    const bool in = r < R && i < s1;
+    float fac = 1.0f;
+    if (in) {
+        const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+        const float dn = dsn_norm3(d);
+        const int64_t g = r * S + i;
+        const float z = z_vals[g];
+        const float dist = ((i + 1 < S) ? (z_vals[g + 1] - z) : 1e10f) * dn;
+        float s = sigma[g];
+        if (transparent && transparent[g]) s = 0.f;
         s = s > 0.f ? s : 0.f;
         const float alpha = 1.0f - expf(-s * dist);
-        t = t * ((1.0f - alpha) + 1e-10f);
-        z = zn;
+        fac = (1.0f - alpha) + 1e-10f;
     }
-    T[r] = t;
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) fac *= __shfl_xor(fac, o);
+    if (r < R && j == 0) T[r] *= fac;
 }
 __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, int64_t n, float v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -920,7 +925,25 @@ void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N
 }
 void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
                           int s1, float* T, hipStream_t st) {
-    hipLaunchKernelGGL(k_advance_T, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, s0, s1, T);
+    const int n = s1 - s0;
+#define DSN_ADV(G)                                                                                                              \
+    hipLaunchKernelGGL(k_advance_T<G>, dim3((unsigned)(((int64_t)R * G + 255) / 256)), dim3(256), 0, st, sigma, transparent, z_vals, \
+                       ray_d, R, S, s0, s1, T)
+    if (n <= 1) DSN_ADV(1);
+    else if (n <= 2) DSN_ADV(2);
+    else if (n <= 4) DSN_ADV(4);
+    else if (n <= 8) DSN_ADV(8);
+    else if (n <= 16) DSN_ADV(16);
+    else if (n <= 32) DSN_ADV(32);
+    else if (n <= 64) DSN_ADV(64);
+    else {      // longer slices (S > 2048): 64 samples at a time
+        for (int q = s0; q < s1; q += 64) {
+            const int e = q + 64 < s1 ? q + 64 : s1;
+            hipLaunchKernelGGL(k_advance_T<64>, dim3((unsigned)(((int64_t)R * 64 + 255) / 256)), dim3(256), 0, st, sigma, transparent, z_vals,
+                               ray_d, R, S, q, e, T);
+        }
+    }
+#undef DSN_ADV
 }
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);

@@ -769,7 +769,8 @@ def test_early_stop_on_a_solid_body_is_within_its_bound(screen):
     ref, st0, _ = run(stop_stats=True)
     got, st1, _ = run(early_stop=True)
     assert st0["would_skip"] > 0.3 * st0["active"], st0
-    assert st1["skipped"] == st0["would_skip"], (st0, st1)          # same T (same densities, same formula) at the same slice borders
+    # same densities, same formula, same slice borders (the products are taken in a different order: borderline rays may differ)
+    assert abs(st1["skipped"] - st0["would_skip"]) <= 0.005 * st0["would_skip"] + 64, (st0, st1)
     assert st1["unshaded"] > 0
     _assert_stop_bound(ref, got, 64)
     assert float(ref["acc_map"].max()) > 0.9
