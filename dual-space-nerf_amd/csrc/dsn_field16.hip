@@ -97,6 +97,7 @@ struct W16 {                 // weight stream state of one wave
     char* ring;              // LDS ring base: [chunk parity][quarter][block in chunk][1 KB]
     unsigned ring_off;       // its LDS byte address (for M0)
     int wave;
+    int nchunk = F16_NCHUNK; // chunks [.., nchunk) are what this kernel streams (the forward-only kernel stops at the reverse layers)
     half8 h0, l0, h1, l1;    // the CURRENT block's operands: (hi, lo) for k-step 0 and 1
 };
 
@@ -137,7 +138,7 @@ __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
 #endif
     const int c = b / F16_CHUNK;
 #if !(F16_ABL & 4) && !F16_DMA_SPREAD
-    if (c + 1 < F16_NCHUNK) w16_stage(w, c + 1);
+    if (c + 1 < w.nchunk) w16_stage(w, c + 1);
 #endif
 }
 __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void w16_begin_issue(W16& w, int first_blk) { w16_sta
 __device__ __forceinline__ void w16_begin_wait(W16& w, int lane, int first_blk) {
     w16_boundary(w, first_blk);
 #if F16_DMA_SPREAD && !(F16_ABL & 4)
-    if (first_blk / F16_CHUNK + 1 < F16_NCHUNK) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
+    if (first_blk / F16_CHUNK + 1 < w.nchunk) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
 #endif
     w16_read(w, first_blk, lane, w.h0, w.l0, w.h1, w.l1);
 }
@@ -182,7 +183,7 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
 #if F16_DMA_SPREAD && !(F16_ABL & 4)
             {   // pieces of the chunk after the one block blk + 1 lives in, behind its first four blocks
                 const int pos = (blk + 1) & (F16_CHUNK - 1), cn = (blk + 1) / F16_CHUNK + 1;
-                if (cn < F16_NCHUNK) {
+                if (cn < w.nchunk) {
                     if (pos == 0) w16_stage_part<0>(w, cn);
                     if (pos == 1) w16_stage_part<1>(w, cn);
                     if (pos == 2) w16_stage_part<2>(w, cn);
@@ -537,6 +538,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
+    if (MODE == F16_FWD) w.nchunk = F16_FIRST_BWD_BLOCK / F16_CHUNK;
     // this tile's point comes from the previous tile's prefetch: list slot -> (slot on the list, sample index), then its coordinates
     auto tile_point = [&](int64_t t, bool& ok, int64_t& ls) -> int64_t {
         int64_t sl = (t * 4 + wave) * 32 + (lane0 & 31);
