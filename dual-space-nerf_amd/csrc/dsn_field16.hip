@@ -1420,15 +1420,273 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_screen16x2 : the same screen with TWO 32-sample tiles per wave (4 waves x 64 samples = the same 256-sample workgroup tile).
+// Every weight operand read from LDS now feeds two MFMAs (one per tile) instead of one: half the LDS operand bytes and half the
+// LDS-DMA instructions per sample, four waves instead of eight at the ring barrier, and the two tiles' accumulators alternate,
+// so no MFMA waits for its predecessor.  Per sample the sequence of products and roundings is the one of k_screen16 (its own
+// accumulator takes k-step 0 then k-step 1 of every block): sigma~ and S1 are bit-identical.  One wave per SIMD (the activations
+// of two tiles fill the registers), persistent workgroups.  MEASURED SLOWER than k_screen16<8> (see dsn_launch_screen16): kept as
+// the DSN_SCREEN_WAVES=2 experiment, not the default.
+// ---------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void w16x_stage_part(const W16& w, int c) {      // piece I of 4: wave's (k-step, half of the blocks) share
+    const char* src = w.g + (size_t)c * 32768;
+    const unsigned dst = w.ring_off + (c & 1) * 16384 + (w.wave & 1) * 8192 + (w.wave >> 1) * 4096;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(src), "s"(dst), "n"(1024 * I) : "memory", "m0");
+}
+__device__ __forceinline__ void w16x_boundary(const W16& w) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+template <int KB, class Hook = NoHook>
+__device__ __forceinline__ void dense16x(W16& w, int& blk, int lane, const half8 (&x0)[KB][2], const half8 (&x1)[KB][2], f32x16& a0,
+                                         f32x16& a1, Hook&& hook = NoHook()) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        half8 n0 = w.h0, n1 = w.h1;
+        if (blk + 1 < F16_SCREEN_BLOCKS) {
+            if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16x_boundary(w);
+            {   // the chunk after the one block blk + 1 lives in: one 1 KB piece behind each of its first four blocks
+                const int pos = (blk + 1) & (F16_CHUNK - 1), cn = (blk + 1) / F16_CHUNK + 1;
+                if (cn < F16_SCREEN_BLOCKS / F16_CHUNK) {
+                    if (pos == 0) w16x_stage_part<0>(w, cn);
+                    if (pos == 1) w16x_stage_part<1>(w, cn);
+                    if (pos == 2) w16x_stage_part<2>(w, cn);
+                    if (pos == 3) w16x_stage_part<3>(w, cn);
+                }
+            }
+            w16s_read(w, blk + 1, lane, n0, n1);
+        }
+        a0 = MFMA16(w.h0, x0[kb][0], a0);
+        a1 = MFMA16(w.h0, x1[kb][0], a1);
+        a0 = MFMA16(w.h1, x0[kb][1], a0);
+        a1 = MFMA16(w.h1, x1[kb][1], a1);
+        hook(kb);
+        w.h0 = n0; w.h1 = n1;
+        ++blk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void relu_slice16x(const f32x16& p, int kb, half8 (&y)[2], half2v& ovf) {
+    const int r = 2 * kb;
+    const half2v h = relu_pair16(p[r], p[r + 1], ovf);
+    y[r >> 3][r & 7] = h[0];
+    y[r >> 3][(r & 7) + 1] = h[1];
+}
+__device__ __forceinline__ void layer16x(W16& w, int& blk, int lane, const float* __restrict__ bias, const half8 (&x0)[8][2],
+                                         const half8 (&x1)[8][2], half8 (&y0)[8][2], half8 (&y1)[8][2], half2v& ovf) {
+    const int half = lane >> 5;
+    f32x16 p0 = zero16(), p1 = zero16();
+    f32x16 bnext = rows16(bias, 0, half);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = bnext, a1 = bnext;
+        if (m + 1 < 8) bnext = rows16(bias, m + 1, half);
+        if (m == 0) dense16x<8>(w, blk, lane, x0, x1, a0, a1);
+        else dense16x<8>(w, blk, lane, x0, x1, a0, a1, [&](int kb) {
+            relu_slice16x(p0, kb, y0[m - 1], ovf);
+            relu_slice16x(p1, kb, y1[m - 1], ovf);
+        });
+        p0 = a0; p1 = a1;
+    }
+    f32x16 z = zero16();
+    relu_half16(p0, z, y0[7], ovf);
+    relu_half16(p1, z, y1[7], ovf);
+}
+__global__ void __launch_bounds__(256, 1)
+k_screen16x2(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
+             const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
+             int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
+             float* __restrict__ dbg_s1, float margin_override, int32_t* __restrict__ audit_list, int32_t* __restrict__ audit_count,
+             int audit_cap) {
+    static_assert(F16_SCREEN_ACC == 1, "k_screen16x2 keeps one accumulator per tile");
+    __shared__ __attribute__((aligned(16))) char ring[2 * 16384];
+    __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
+    __shared__ __attribute__((aligned(16))) half8 s_pe[2][4][256];
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    const int tid0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t count = active_list ? (int64_t)(*active_count) : N;
+    const int64_t ntiles = (count + 255) / 256;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    for (int i = tid0; i < 256 + 2304 + 8; i += 256)
+        s_vec[i] = i < 256 ? fs->bias0[i] : (i < 2560 ? packed[OFF_B1 + (i - 256)] : packed[OFF_SCAL + (i - 2560)]);
+    for (int i = tid0; i < 256 + (OFF_WDEN - OFF_B1); i += 256) s_vec[i] *= F16_FWD_SCALE;
+    const float* const v_b1 = s_vec + 256;
+    const float* const v_wden = s_vec + 256 + (OFF_WDEN - OFF_B1);
+    W16 w;
+    w.g = reinterpret_cast<const char*>(packed + OFF16_BASE) + (wave & 1) * 16384 + (wave >> 1) * 4096 + lane0 * 16;
+    w.ring = ring;
+    w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    w.wave = wave;
+    w16s_stage<4>(w, 0);
+    // wave `wave` of tile t owns list slots (4 t + wave) * 64 ... + 63: lane & 31 of its tile 0, + 32 of its tile 1
+    auto tile_point = [&](int64_t t, int which, bool& ok) -> int64_t {
+        int64_t sl = (t * 4 + wave) * 64 + 32 * which + (lane0 & 31);
+        ok = sl < count;
+        if (!ok) sl = count - 1;
+        return active_list ? (int64_t)active_list[sl] : sl;
+    };
+    bool valid_n[2];
+    int64_t pt_n[2];
+    float xn[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pt_n[q] = tile_point(blockIdx.x, q, valid_n[q]);
+        xn[q][0] = x_c[3 * pt_n[q]]; xn[q][1] = x_c[3 * pt_n[q] + 1]; xn[q][2] = x_c[3 * pt_n[q] + 2];
+    }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int tid = tid0, lane = lane0;
+    asm volatile("" : "+v"(tid), "+v"(lane), "+v"(w.g));      // (opaque copies: see k_field16)
+    const int half = lane >> 5;
+    const bool valid[2] = {valid_n[0], valid_n[1]};
+    const int64_t pt[2] = {pt_n[0], pt_n[1]};
+    const float xa[2][3] = {{xn[0][0], xn[0][1], xn[0][2]}, {xn[1][0], xn[1][1], xn[1][2]}};
+    const bool more = tile + gridDim.x < ntiles;      // workgroup-uniform
+    if (more) { pt_n[0] = tile_point(tile + gridDim.x, 0, valid_n[0]); pt_n[1] = tile_point(tile + gridDim.x, 1, valid_n[1]); }
+    w16x_boundary(w);
+    w16x_stage_part<0>(w, 1);
+    w16s_read(w, 0, lane, w.h0, w.h1);
+    int blk = 0;
+    half8 ah0[8][2], ah1[8][2], bh0[8][2], bh1[8][2];
+    half8 ph0[2][2], ph1[2][2];
+    half2v ovf = {(_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        f32x16 pe[2];
+#pragma unroll
+        for (int t = 0; t < 30; ++t) {
+            float sn, cs;
+            dsn_sincos(xa[q][t % 3] * (float)(1 << (t / 3)), sn, cs);
+            pe[t >> 4][t & 15] = half ? cs : sn;
+        }
+        pe[1][14] = half ? xa[q][1] : xa[q][0];
+        pe[1][15] = half ? 0.0f : xa[q][2];
+        half8 (&ph)[2][2] = q ? ph1 : ph0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ph[b][r >> 3][r & 7] = (_Float16)pe[b][r];
+        s_pe[q][0][tid] = ph[0][0]; s_pe[q][1][tid] = ph[0][1]; s_pe[q][2][tid] = ph[1][0]; s_pe[q][3][tid] = ph[1][1];
+    }
+    f32x16 zz = zero16();
+    // stage1.0
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(s_vec, m, half), a1 = a0;
+        dense16x<2>(w, blk, lane, ph0, ph1, a0, a1);
+        relu_half16(a0, zz, ah0[m], ovf);
+        relu_half16(a1, zz, ah1[m], ovf);
+    }
+    layer16x(w, blk, lane, v_b1 + 0 * 256, ah0, ah1, bh0, bh1, ovf);
+    if (more) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { xn[q][0] = x_c[3 * pt_n[q]]; xn[q][1] = x_c[3 * pt_n[q] + 1]; xn[q][2] = x_c[3 * pt_n[q] + 2]; }
+    }
+    layer16x(w, blk, lane, v_b1 + 1 * 256, bh0, bh1, ah0, ah1, ovf);
+    layer16x(w, blk, lane, v_b1 + 2 * 256, ah0, ah1, bh0, bh1, ovf);
+    // stage2.0 : [h, pe] -> 256
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(v_b1 + 3 * 256, m, half), a1 = a0;
+        dense16x<8>(w, blk, lane, bh0, bh1, a0, a1);
+        half8 q0[2][2], q1[2][2];
+        q0[0][0] = s_pe[0][0][tid]; q0[0][1] = s_pe[0][1][tid]; q0[1][0] = s_pe[0][2][tid]; q0[1][1] = s_pe[0][3][tid];
+        q1[0][0] = s_pe[1][0][tid]; q1[0][1] = s_pe[1][1][tid]; q1[1][0] = s_pe[1][2][tid]; q1[1][1] = s_pe[1][3][tid];
+        dense16x<2>(w, blk, lane, q0, q1, a0, a1);
+        relu_half16(a0, zz, ah0[m], ovf);
+        relu_half16(a1, zz, ah1[m], ovf);
+    }
+    layer16x(w, blk, lane, v_b1 + 4 * 256, ah0, ah1, bh0, bh1, ovf);
+    // stage2.4 + density head: sigma~ and the magnitude of its terms, per tile
+    float sgv[2] = {0.0f, 0.0f}, s1v[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 a0 = rows16(v_b1 + 5 * 256, m, half), a1 = a0;
+        dense16x<8>(w, blk, lane, bh0, bh1, a0, a1);
+        const f32x16 wd = rows16(v_wden, m, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = fmaxf(a0[r] * F16_FWD_INV, 0.0f), h1 = fmaxf(a1[r] * F16_FWD_INV, 0.0f);
+            const float t0 = wd[r] * h0, t1 = wd[r] * h1;
+            sgv[0] += t0; s1v[0] += fabsf(t0);
+            sgv[1] += t1; s1v[1] += fabsf(t1);
+        }
+    }
+    // range guard: the last layer's activations are fp32 here, every earlier one went through `ovf` (shared by the lane's two
+    // samples: an overflow in either keeps both for the accurate pass - conservative)
+    float omax = fmaxf((float)ovf[0], (float)ovf[1]);
+    omax = fmaxf(omax, __shfl_xor(omax, 32));
+    const bool in_range = omax < F16_RANGE;
+    const float bd = s_vec[2560];
+    const float margin = margin_override > 0.0f ? margin_override : s_vec[2560 + 5];
+    bool keep[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float sg = sgv[q] + __shfl_xor(sgv[q], 32);
+        float s1 = s1v[q] + __shfl_xor(s1v[q], 32);
+        sg += bd;
+        s1 += fabsf(bd);
+        const bool mine = valid[q] && half == 0;
+        const bool empty = in_range && sg < -(margin * s1 + margin);
+        if (mine) {
+            if (empty) sigma[pt[q]] = sg;
+            if (dbg_sigma) { dbg_sigma[pt[q]] = in_range ? sg : dsn_nan_flag(); dbg_s1[pt[q]] = in_range ? s1 : dsn_nan_flag(); }
+        }
+        bool audit = false;
+        if (audit_list && mine && empty) {
+            uint32_t hsh = (uint32_t)pt[q] * 2654435761u;
+            hsh ^= hsh >> 15;
+            if ((hsh & 127u) == 5u) {
+                const int a = atomicAdd(audit_count, 1);
+                if (a < audit_cap) { audit_list[a] = (int32_t)pt[q]; audit = true; }
+            }
+        }
+        keep[q] = mine && (!empty || audit);
+    }
+    const unsigned long long bm0 = __ballot(keep[0]), bm1 = __ballot(keep[1]);
+    if (lane == 0) s_cnt[wave] = __popcll(bm0) + __popcll(bm1);
+    __syncthreads();
+    if (more) w16s_stage<4>(w, 0);      // (every wave has read its last weight block: the ring is free for the next tile)
+    if (tid == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(keep_count, tot) : 0;
+    }
+    __syncthreads();
+    {
+        int off = s_base;
+        for (int k = 0; k < wave; ++k) off += s_cnt[k];
+        if (keep[0]) keep_list[off + __popcll(bm0 & ((1ull << lane) - 1ull))] = (int32_t)pt[0];
+        if (keep[1]) keep_list[off + __popcll(bm0) + __popcll(bm1 & ((1ull << lane) - 1ull))] = (int32_t)pt[1];
+    }
+  }
+}
+
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
                          float* dbg_s1, hipStream_t st, int32_t* audit_list, int32_t* audit_count, int audit_cap) {
     if (N == 0) return;
-    static const bool four = getenv("DSN_SCREEN_WAVES") && atoi(getenv("DSN_SCREEN_WAVES")) == 4;
+    // DSN_SCREEN_WAVES (experiments): 4 = four one-tile waves, two workgroups per CU; 2 = k_screen16x2 (four two-tile waves: half the
+    // LDS operand reads and DMA instructions per sample, bit-identical results - and 1.7 % SLOWER, 4.86 vs 4.78 ms in one call,
+    // profiles/r02_screen_x2_ab.txt: what the second wave per SIMD hides is worth more than the operand bytes); default = eight
+    // one-tile waves, one persistent workgroup per CU
+    const char* wenv = getenv("DSN_SCREEN_WAVES");      // (read per launch: tests switch it)
+    const int waves = wenv ? atoi(wenv) : 8;
     // experiment switch: overrides the margin the packed parameters carry (default / calibrated, see k_screen16)
     static const float margin = getenv("DSN_SCREEN_MARGIN") ? (float)atof(getenv("DSN_SCREEN_MARGIN")) : 0.0f;
-    if (four)
+    if (waves == 4)
         hipLaunchKernelGGL(k_screen16<4>, dim3((unsigned)std::min<int64_t>((N + 127) / 128, 2 * dsn_cu_count())), dim3(256), 0, st, packed, fs, x_c, N, active_list,
+                           active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
+    else if (waves == 2)
+        hipLaunchKernelGGL(k_screen16x2, dim3((unsigned)std::min<int64_t>((N + 255) / 256, dsn_cu_count())), dim3(256), 0, st, packed, fs, x_c, N, active_list,
                            active_count, sigma, keep_list, keep_count, dbg_sigma, dbg_s1, margin, audit_list, audit_count, audit_cap);
     else
         hipLaunchKernelGGL(k_screen16<8>, dim3((unsigned)std::min<int64_t>((N + 255) / 256, dsn_cu_count())), dim3(512), 0, st, packed, fs, x_c, N, active_list,

@@ -837,3 +837,29 @@ def test_renderer_decides_early_stop_from_the_first_frame():
                 if "disp" in k:
                     bound = bound * max(1.0, float(x.abs().max()))      # 1 / depth: relative
                 assert float((x - y).abs().max()) <= bound, (name, k)
+
+
+@pytest.mark.parametrize("waves", ["2", "4"])
+def test_screen_kernel_variants_are_bit_identical(waves, monkeypatch):
+    """DSN_SCREEN_WAVES = 2 (k_screen16x2: two 32-sample tiles per wave, every weight operand read feeds both) and 4 (four one-tile
+    waves) run the same products in the same order per sample as the default eight-wave kernel: sigma~ and S1 equal bit for bit,
+    on a point count that is not a multiple of the workgroup tile"""
+    from dsnerf_amd import _lib
+    g = load("full_eval")
+    import test_gpu_render as TR
+    r = TR.make_renderer(g, "full_eval")
+    r.eval()
+    r._set_frame(TR.make_batch(g))
+    rng = np.random.default_rng(5)
+    x = np.concatenate([g["x_c"], g["x_c"][rng.integers(0, g["x_c"].shape[0], 5000)] + rng.normal(0, 0.02, (5000, 3)).astype(np.float32)], 0)
+    x = T(x[: x.shape[0] - 37].astype(np.float32))
+    packed = r.net.packed(r.device)
+    sg0, s10 = _lib.screen_debug(r.scene, packed, x)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("DSN_SCREEN_WAVES", waves)
+    sg1, s11 = _lib.screen_debug(r.scene, packed, x)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("DSN_SCREEN_WAVES")
+    assert torch.equal(torch.nan_to_num(sg0, nan=-7.0), torch.nan_to_num(sg1, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(s10, nan=-7.0), torch.nan_to_num(s11, nan=-7.0))
+    assert float(s10.abs().max()) > 0
