@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA field kernel instead of split-fp16")
     ap.add_argument("--no-screen", action="store_true", help="disable the plain-fp16 density screen (DSN_NO_SCREEN)")
+    ap.add_argument("--force-screen", action="store_true", help="(kernel experiments) keep the density screen on whatever its calibration says")
     ap.add_argument("--early-stop", default="auto", choices=["auto", "on", "off"],
                     help="front-to-back slices with ray termination (DSN_EARLY_STOP): auto = like Renderer, from the statistics of one "
                          "probe frame at set-up (used when it would leave out >= 4 %% of the non-transparent samples)")
@@ -162,7 +163,7 @@ def main():
     if not (args.dense or args.fp32 or args.no_screen):
         scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
         screen_info = packed.calibrate_screen(scene)
-        if not screen_info["usable"]:
+        if not screen_info["usable"] and not args.force_screen:
             args.no_screen = True
     # front-to-back slices with ray termination: decided like Renderer does, from one probe frame (set-up, not a step)
     stop_info = {"enabled": False}

@@ -1171,12 +1171,19 @@ __device__ __forceinline__ void w16s_stage(const W16& w, int c) {
                      "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
                      : : "v"(src), "s"(dst) : "memory", "m0");
 }
+#ifndef F16_SABL
+#define F16_SABL 0            // screen timing ablations (WRONG results): 1 no ring barrier, 4 no LDS-DMA, 16 empty epilogue slices
+#endif
 template <int NW>
 __device__ __forceinline__ void w16s_boundary(const W16& w, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(F16_SABL & 1)
     __syncthreads();
+#endif
     const int c = b / F16_CHUNK;
+#if !(F16_SABL & 4)
     if (c + 1 < F16_SCREEN_BLOCKS / F16_CHUNK) w16s_stage<NW>(w, c + 1);
+#endif
 }
 __device__ __forceinline__ void w16s_read(const W16& w, int b, int lane, half8& h0, half8& h1) {
     const char* s = w.ring + ((b >> 3) & 1) * 16384 + (b & 7) * 1024 + lane * 16;
@@ -1246,6 +1253,11 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
         if (m == 0) dense16s<NW, 8>(w, blk, lane, xh, a0, a1);
         else dense16s<NW, 8>(w, blk, lane, xh, a0, a1, [&](int kb) {
             const int r = 2 * kb;
+#if F16_SABL & 16
+            asm volatile("" : : "v"(p0[r]), "v"(p0[r + 1]));
+            if (kb == 0) yh[m - 1][0] = xh[m - 1][0];
+            return;
+#endif
             const half2v h = F16_SCREEN_ACC == 1 ? relu_pair16(p0[r], p0[r + 1], ovf) : relu_pair16(p0[r] + p1[r], p0[r + 1] + p1[r + 1], ovf);
             yh[m - 1][r >> 3][r & 7] = h[0];
             yh[m - 1][r >> 3][(r & 7) + 1] = h[1];
