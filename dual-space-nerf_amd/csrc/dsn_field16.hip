@@ -98,6 +98,9 @@ struct W16 {                 // weight stream state of one wave
     unsigned ring_off;       // its LDS byte address (for M0)
     int wave;
     int nchunk = F16_NCHUNK; // chunks [.., nchunk) are what this kernel streams (the forward-only kernel stops at the reverse layers)
+    bool spread = F16_DMA_SPREAD != 0;   // LDS-DMA of the next chunk two pieces per block over four blocks (false: all eight behind the ring
+                                         // barrier - the kernels that also STORE activations every chunk run 2-3 % faster that way: their
+                                         // stores and the spread pieces share one queue in front of the boundary's vmcnt(0))
     half8 h0, l0, h1, l1;    // the CURRENT block's operands: (hi, lo) for k-step 0 and 1
 };
 
@@ -137,8 +140,8 @@ __device__ __forceinline__ void w16_boundary(const W16& w, int b) {
     __syncthreads();
 #endif
     const int c = b / F16_CHUNK;
-#if !(F16_ABL & 4) && !F16_DMA_SPREAD
-    if (c + 1 < w.nchunk) w16_stage(w, c + 1);
+#if !(F16_ABL & 4)
+    if (!w.spread && c + 1 < w.nchunk) w16_stage(w, c + 1);
 #endif
 }
 __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h0, half8& l0, half8& h1, half8& l1) {
@@ -153,8 +156,8 @@ __device__ __forceinline__ void w16_read(const W16& w, int b, int lane, half8& h
 __device__ __forceinline__ void w16_begin_issue(W16& w, int first_blk) { w16_stage(w, first_blk / F16_CHUNK); }
 __device__ __forceinline__ void w16_begin_wait(W16& w, int lane, int first_blk) {
     w16_boundary(w, first_blk);
-#if F16_DMA_SPREAD && !(F16_ABL & 4)
-    if (first_blk / F16_CHUNK + 1 < w.nchunk) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
+#if !(F16_ABL & 4)
+    if (w.spread && first_blk / F16_CHUNK + 1 < w.nchunk) w16_stage_part<0>(w, first_blk / F16_CHUNK + 1);   // (dense16 issues parts 1..3 and every later chunk)
 #endif
     w16_read(w, first_blk, lane, w.h0, w.l0, w.h1, w.l1);
 }
@@ -180,8 +183,8 @@ __device__ __forceinline__ void dense16(W16& w, int& blk, int lane, const half8 
         half8 n0 = w.h0, m0 = w.l0, n1 = w.h1, m1 = w.l1;
         if (blk + 1 < DSN_STREAM_BLOCKS) {
             if (((blk + 1) & (F16_CHUNK - 1)) == 0) w16_boundary(w, blk + 1);
-#if F16_DMA_SPREAD && !(F16_ABL & 4)
-            {   // pieces of the chunk after the one block blk + 1 lives in, behind its first four blocks
+#if !(F16_ABL & 4)
+            if (w.spread) {   // pieces of the chunk after the one block blk + 1 lives in, behind its first four blocks
                 const int pos = (blk + 1) & (F16_CHUNK - 1), cn = (blk + 1) / F16_CHUNK + 1;
                 if (cn < w.nchunk) {
                     if (pos == 0) w16_stage_part<0>(w, cn);
@@ -539,6 +542,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
     if (MODE == F16_FWD) w.nchunk = F16_FIRST_BWD_BLOCK / F16_CHUNK;
+    if (MODE == F16_TRAIN) w.spread = false;
     // this tile's point comes from the previous tile's prefetch: list slot -> (slot on the list, sample index), then its coordinates
     auto tile_point = [&](int64_t t, bool& ok, int64_t& ls) -> int64_t {
         int64_t sl = (t * 4 + wave) * 32 + (lane0 & 31);
@@ -971,6 +975,7 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
+    w.spread = false;
     w16_begin(w, lane, 0);
     int blk = 0;
     const int64_t ls = N * 256;
@@ -1095,6 +1100,7 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
     w.ring = ring;
     w.ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     w.wave = wave;
+    w.spread = false;
     w16_begin(w, lane, F16_FIRST_BWD_BLOCK);
     int blk = F16_FIRST_BWD_BLOCK;
     const int64_t ls = N * 256;
