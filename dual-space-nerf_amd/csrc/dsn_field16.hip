@@ -57,9 +57,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef F16_NEXT_POINT
 #define F16_NEXT_POINT 1      // k_field16: the next tile's list entry and coordinates are fetched under the current tile
 #endif
-#ifndef F16_EARLY_DMA
-#define F16_EARLY_DMA 1       // k_field16: the first chunk's LDS-DMA at the top of the kernel instead of behind the prologue's loads
-#endif
 #ifndef F16_DMA_SPREAD
 #define F16_DMA_SPREAD 1      // LDS-DMA of the next chunk two pieces per block over four blocks instead of eight pieces behind the barrier
 #endif
