@@ -19,7 +19,9 @@ What differs from the reference, on purpose (DESIGN.md "boundary"):
 Eval-mode safety nets: the plain-fp16 density screen runs with a margin CALIBRATED for the loaded
 parameters (first eval frame after the parameters changed: `screen_info`), can be audited on every frame
 (`screen_audit = True`, `last_screen_audit()`), and samples whose activations leave the fp16 range of the split-fp16
-kernels are re-evaluated in exact fp32 inside the library.
+kernels are re-evaluated in exact fp32 inside the library.  `early_stop` ("auto" | True | False): eval frames front to back
+in slices of 8 samples with ray termination at a transmittance of 2^-20 (DSN_EARLY_STOP: within 64 * 2^-20 x colour of the
+one-pass frame) - "auto" decides per parameter version from the statistics of the first eval frame, without a wait.
 """
 from __future__ import annotations
 
