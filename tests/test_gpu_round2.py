@@ -863,3 +863,18 @@ def test_screen_kernel_variants_are_bit_identical(waves, monkeypatch):
     assert torch.equal(torch.nan_to_num(sg0, nan=-7.0), torch.nan_to_num(sg1, nan=-7.0))
     assert torch.equal(torch.nan_to_num(s10, nan=-7.0), torch.nan_to_num(s11, nan=-7.0))
     assert float(s10.abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", ["default", "no_screen", "w3_early_stop"])
+def test_eval_frames_are_reproducible_bit_for_bit(case):
+    """30 renders of one frame: list orders (atomics) differ from run to run, per-sample values and the compositing order must not.
+    Guards the weight ring across the persistent workgroups' tiles and the workgroup-aggregated list building against rare races
+    (scripts/soak_determinism.py is the long version)"""
+    sd = state("x_w3") if case.startswith("w3") else state()
+    run = _stop_pair(sd, hw=160, screen=case != "no_screen")
+    kw = {"early_stop": True} if case.endswith("early_stop") else {}
+    ref, _, _ = run(**kw)
+    for i in range(30):
+        got, _, _ = run(**kw)
+        for k in ("color", "acc_map", "depth_map", "weights"):
+            assert torch.equal(torch.nan_to_num(ref[k], nan=-1.0), torch.nan_to_num(got[k], nan=-1.0)), (case, i, k)
