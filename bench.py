@@ -177,6 +177,10 @@ def main():
         stop_info = {"enabled": args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                      "probe_frame_would_skip_fraction_of_non_transparent": frac, "eps": 2.0 ** -20}
     early = stop_info["enabled"]
+    if early and screen_info is not None and not args.force_screen:
+        # with termination in use the screen's dropped share counts among the samples still evaluated (PackedParams.screen_pays)
+        packed.early_stop = {"skipped_fraction": stop_info.get("probe_frame_would_skip_fraction_of_non_transparent", 0.0), "usable": True}
+        args.no_screen = not packed.screen_pays(True)
     torch.cuda.synchronize()
     k_step = 0
 

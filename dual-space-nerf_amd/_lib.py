@@ -136,6 +136,18 @@ class PackedParams:
         self.early_stop = None
         return self
 
+    def screen_pays(self, early_stop_on: bool = False) -> bool:
+        """Is the (calibrated) density screen worth running?  `usable` of calibrate_screen, except that with ray termination in use
+        the share of samples it drops counts among the samples that are still evaluated: what termination leaves out is the dense
+        interior, which the screen could never drop - dropped / (1 - skipped) >= SCREEN_MIN_DROPPED."""
+        sc = self.screen
+        if not sc:
+            return False
+        if not early_stop_on or not self.early_stop or sc.get("dropped_fraction") is None or not sc.get("safe"):
+            return bool(sc["usable"])
+        f = min(max(float(self.early_stop.get("skipped_fraction", 0.0)), 0.0), 0.99)
+        return sc["dropped_fraction"] / (1.0 - f) >= SCREEN_MIN_DROPPED
+
     def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20, other_frames=(0, 125, 250, 375, 499)):
         """Measure the density screen's margin for THESE parameters (dsn_calibrate_screen; synchronises: meant to run once per
         checkpoint, Renderer does it lazily before the first eval-mode frame after the parameters changed): on the scene's

@@ -242,7 +242,12 @@ class Renderer:
             if not info["safe"]:
                 warnings.warn("dsnerf_amd: the plain-fp16 density screen deviates by %.3g of the term magnitude for these parameters "
                               "(cap 0.005): it stays off, every non-transparent sample takes the accurate pass" % info["deviation"])
-        return packed.screen["usable"]
+        return packed.screen_pays(self._early_stop_in_use(packed))
+
+    def _early_stop_in_use(self, packed):
+        if self.early_stop == "auto":
+            return bool(packed.early_stop and packed.early_stop["usable"])
+        return bool(self.early_stop)
 
     def _draws(self, R, S):
         """Train-mode random draws from the CPU default generator in the reference's order:
@@ -411,13 +416,14 @@ class Renderer:
 
     def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None):
         skip = self.skip_transparent and not self.net.training
+        if skip and noise is None and self.early_stop == "auto":
+            self._read_stop_probe()      # (first: whether the screen pays depends on it)
         if screen is None:
             screen = skip and noise is None and self._screen_usable()
         packed = self.net.packed(self.device)
         stop, stats = False, False
         if skip and noise is None:
             if self.early_stop == "auto":
-                self._read_stop_probe()
                 if packed.early_stop is None:
                     if self._stop_probe is None:
                         stats = True
@@ -488,8 +494,8 @@ class Renderer:
         chunk = R if chunk is None else int(chunk)
         screen = None
         if scene is not self.scene:      # calibration runs on the renderer's own scene (any frame state of these parameters)
-            screen = (self.skip_transparent and not self.net.training and self.density_screen
-                      and bool((self.net.packed(self.device).screen or {}).get("usable", False)))
+            pk = self.net.packed(self.device)
+            screen = self.skip_transparent and not self.net.training and self.density_screen and pk.screen_pays(self._early_stop_in_use(pk))
         outs = []
         for i in range(0, R, chunk):
             j = min(R, i + chunk)

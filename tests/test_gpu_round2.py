@@ -826,6 +826,10 @@ def test_renderer_decides_early_stop_from_the_first_frame():
         r._read_stop_probe(wait=True)
         info = r.net.packed(r.device).early_stop
         assert info is not None and info["usable"] is want, (name, info)
+        # with termination in use the screen's dropped share counts among the samples still evaluated: w3's 34 % of all points is
+        # 68 % of what is left once the dense interior is gone, so the screen comes on although its calibration alone said no
+        pk = r.net.packed(r.device)
+        assert r._screen_usable() and (pk.screen["usable"] is (not want))
         b = r.render_view(batch, device_output=True)
         torch.cuda.synchronize()
         st = _lib.read_stop_stats(r._ws)
