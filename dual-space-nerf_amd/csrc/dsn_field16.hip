@@ -298,8 +298,17 @@ __device__ __forceinline__ uint32_t dsn_push_sign(uint32_t word, float v) {
     return __builtin_amdgcn_alignbit(word, __float_as_uint(v), 31);
 }
 __device__ __forceinline__ uint32_t dsn_active_word(uint32_t signs) { return ~signs & 0xffffu; }
+#ifndef F16_KEEP_ASM
+#define F16_KEEP_ASM 1        // relu mask of the reverse pass as v_bfe_i32 + v_and_b32 (hipcc turns the C form into v_and + v_cmp + v_cndmask through VCC)
+#endif
 __device__ __forceinline__ float dsn_keep_active(float v, uint32_t word, int r) {
+#if F16_KEEP_ASM
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "s"(15 - r));      // all ones where bit (15 - r) of the pattern word is set
+    return __uint_as_float(__float_as_uint(v) & m);
+#else
     return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)word, 15 - r, 1));
+#endif
 }
 __device__ __forceinline__ uint32_t relu_bits16(f32x16& a) {
     uint32_t s = 0;

@@ -60,6 +60,10 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* clk,
         if (KIND == 21) asm volatile("v_cvt_f32_f16_e32 %0, %5\n\tv_cvt_f32_f16_e32 %1, %6\n\tv_cvt_f32_f16_e32 %2, %7\n\tv_cvt_f32_f16_e32 %3, %8\n\tv_cvt_f32_f16_e32 %4, %9" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
         if (KIND == 22) asm volatile("v_cndmask_b32_e32 %0, %0, %5, vcc\n\tv_cndmask_b32_e32 %1, %1, %6, vcc\n\tv_cndmask_b32_e32 %2, %2, %7, vcc\n\tv_cndmask_b32_e32 %3, %3, %8, vcc\n\tv_cndmask_b32_e32 %4, %4, %9, vcc" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4) : "vcc"); \
         if (KIND == 23) asm volatile("v_fmamk_f32 %0, %0, 0x39800000, %5\n\tv_fmamk_f32 %1, %1, 0x39800000, %6\n\tv_fmamk_f32 %2, %2, 0x39800000, %7\n\tv_fmamk_f32 %3, %3, 0x39800000, %8\n\tv_fmamk_f32 %4, %4, 0x39800000, %9" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 24) asm volatile("v_cmp_ne_u32_e32 vcc, 0, %0\n\tv_cmp_ne_u32_e32 vcc, 0, %1\n\tv_cmp_ne_u32_e32 vcc, 0, %2\n\tv_cmp_ne_u32_e32 vcc, 0, %3\n\tv_cmp_ne_u32_e32 vcc, 0, %4" : : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4) : "vcc"); \
+        if (KIND == 25) asm volatile("v_bfe_i32 %0, %5, 3, 1\n\tv_bfe_i32 %1, %6, 4, 1\n\tv_bfe_i32 %2, %7, 5, 1\n\tv_bfe_i32 %3, %8, 6, 1\n\tv_bfe_i32 %4, %9, 7, 1" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
+        if (KIND == 26) asm volatile("v_and_b32_e32 %0, 64, %5\n\tv_cmp_ne_u32_e32 vcc, 0, %0\n\ts_nop 0\n\tv_cndmask_b32_e32 %1, 0, %6, vcc\n\tv_and_b32_e32 %2, 32, %7\n\tv_cmp_ne_u32_e32 vcc, 0, %2\n\ts_nop 0\n\tv_cndmask_b32_e32 %3, 0, %8, vcc" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4) : "vcc"); \
+        if (KIND == 27) asm volatile("v_cvt_f32_f16_sdwa %0, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %1, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %2, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_cvt_f32_f16_sdwa %4, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4)); \
         if (KIND == 16) asm volatile("v_fma_f32 %0, %0, %5, 0.5\n\ts_nop 0\n\tv_fma_f32 %1, %1, %6, 0.5\n\ts_nop 0\n\tv_fma_f32 %2, %2, %7, 0.5" : "+v"(e0), "+v"(e1), "+v"(e2) : "v"(f0), "v"(f1), "v"(f2)); \
         __builtin_amdgcn_sched_barrier(0);                                                                                           \
     } while (0)
@@ -102,7 +106,7 @@ template <int KIND> Res t_run(float* d, unsigned long long* clk, int reps) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return r;
 }
-#define NV 24
+#define NV 28
 template <int V> void all(Res (*t)[8], int r, float* d, unsigned long long* clk) {
     t[V][r] = t_run<V>(d, clk, 20);
     if constexpr (V + 1 < NV) all<V + 1>(t, r, d, clk);
@@ -113,7 +117,7 @@ int main() {
     const char* name[NV] = {"6 MFMA", "v_fma v,v,s,c (1 vgpr src)", "v_fma v,v,v',c (2 vgpr src)", "v_fma v,v,v',v'' (3 vgpr src)", "v_add_e32 (2 vgpr src)",
                             "v_mul_e32 s,v (1 vgpr src)", "v_max_e32 0,v (1 vgpr src)", "v_accvgpr_read (idle agprs)", "v_pk_fma_f32 (3 x 64-bit src)",
                             "v_pk_mul_f32 (2 x 64-bit src)", "v_cvt_pk_f16_f32 (2 src)", "v_max3_f32 (3 src)", "v_alignbit (2 src + imm)",
-                            "v_fma_mixlo_f16 (2 vgpr src)", "s_nop 0 x5", "v_mov_b32 (1 src)", "3 x v_fma (2 src) + 2 s_nop", "v_pk_max_f16", "v_pk_mul_f16", "v_pk_add_f16", "v_pk_add_f32", "v_cvt_f32_f16", "v_cndmask_b32 (vcc)", "v_fmamk_f32"};
+                            "v_fma_mixlo_f16 (2 vgpr src)", "s_nop 0 x5", "v_mov_b32 (1 src)", "3 x v_fma (2 src) + 2 s_nop", "v_pk_max_f16", "v_pk_mul_f16", "v_pk_add_f16", "v_pk_add_f32", "v_cvt_f32_f16", "v_cndmask_b32 (vcc)", "v_fmamk_f32", "v_cmp_ne_u32 (vcc)", "v_bfe_i32", "2 x (v_and, v_cmp, s_nop, v_cndmask)", "v_cvt_f32_f16_sdwa"};
     const int R = 6;
     static Res t[NV][8];
     for (int r = 0; r < 3; ++r) t_run<0>(d, clk, 20);
