@@ -294,15 +294,12 @@ def main():
         ex = result["config"]
         ex["ms_per_frame_alone_no_screen"] = frame_ms(5, screen=False)
         ex["ms_per_frame_alone_fp32_exact"] = frame_ms(2, fp32=True)
-        # host batch -> host images.  Small host-side torch ops (a 1 MB clone is enough) fan out over torch's intra-op pool -
-        # 256 OpenMP threads on these boxes, which then spin for milliseconds and starve the thread that feeds the GPU
-        # (scripts/h2h_probe.py: 42-44 ms per frame with the default pool, 19-20 ms with 16 threads or OMP_WAIT_POLICY=passive):
-        # both are reported
+        # host batch -> host images (see host_to_host: the second key is the same frame when the CALLER runs a small torch CPU op on
+        # the main thread right before it - torch's intra-op pool, `host_threads` OpenMP threads here, then spins beside the GPU feeder)
         ex["host_to_host_ms"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
-        nthreads = torch.get_num_threads()
-        torch.set_num_threads(min(16, nthreads))
-        ex["host_to_host_ms_16_host_threads"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
-        torch.set_num_threads(nthreads)
+        ex["host_to_host_ms_after_a_caller_torch_cpu_op"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
+                                                                         caller_torch_op=True)
+        ex["host_threads"] = torch.get_num_threads()
         if not args.no_cpu_baseline:
             result["eager_gpu_baseline"] = eager_baseline(args, _lib, synth, dev, chunks=3, train=False)
             result["eager_gpu_baseline"]["x_faster_per_frame"] = result["eager_gpu_baseline"]["eval_ms_per_512x512_frame"] * \
@@ -316,9 +313,13 @@ def main():
         print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
 
 
-def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S):
+def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S, caller_torch_op=False):
     """The reference's render_view contract (can_render.py:248-278): a batch of HOST tensors in (what its DataLoader hands
-    over), four HOST images out, one frame at a time through the Renderer mirror.  PCIe-inclusive: never `value`."""
+    over), four HOST images out, one frame at a time through the Renderer mirror.  PCIe-inclusive: never `value`.
+    The fresh per-frame near / far tensors (render_view updates them in place) are made with numpy, like the product of a DataLoader
+    worker process; caller_torch_op=True makes them with torch .clone() on the main thread instead - a 1 MB torch CPU op right before
+    the frame wakes torch's intra-op OpenMP pool, whose spinning threads then starve the thread that feeds the GPU
+    (scripts/h2h_caller_probe.py: 18.3 ms vs 25-33 ms per frame on the same renderer)."""
     from types import SimpleNamespace
     cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
                           MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0, raw_noise_std=1.0,
@@ -335,7 +336,10 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
     ms = []
     for i in range(6):
         b = dict(batch)
-        b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        if caller_torch_op:
+            b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        else:
+            b["near"], b["far"] = torch.from_numpy(batch["near"].numpy().copy()), torch.from_numpy(batch["far"].numpy().copy())
         torch.cuda.synchronize()
         t = time.perf_counter()
         out = r.render_view(b)
