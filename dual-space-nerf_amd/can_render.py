@@ -195,8 +195,8 @@ class Renderer:
             slot["host"] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8).pin_memory()
         stage = slot["host"][:nbytes].view(dtype).view(t.shape)
         # host memcpy (with the dtype conversion, if any) through numpy: ONE thread.  torch's copy_ fans a few MB out over its
-        # whole intra-op pool - 256 threads on the GPU boxes - and the wake-up costs more than the copy (47 ms instead of 19 ms per
-        # host-to-host frame once the pool has been spun up by other CPU work)
+        # whole intra-op pool - 128-256 threads on the GPU boxes - whose threads then spin beside the thread that feeds the GPU:
+        # a 1 MB torch CPU op in front of a frame costs the frame 7-14 ms (scripts/h2h_caller_probe.py)
         if t.device.type == "cpu" and not t.requires_grad and t.dtype != torch.bfloat16:
             np.copyto(stage.numpy(), t.numpy(), casting="unsafe")
         else:
