@@ -19,8 +19,8 @@
 // This round's implementation: activations of one training batch resident in HBM (23 KB per sample - 12 GB for the
 // 8192 x 64 batch of BASELINE configs[2], sized for 288 GB).  The forward pass, the sigma reverse pass and the tangent
 // pass and the adjoint pass are fused split-fp16 kernels of dsn_field16.hip (k_field16<train> stores h_l, a_l and the relu
-// records as it goes; k_tangent16 stores hdot_l; k_adjoint16 stores ahat_l below its seed); rocBLAS is left with the small
-// lighting / rgb-head GEMMs; the weight-gradient products, which contract over the half-million samples of the
+// records as it goes; k_tangent16 stores hdot_l; k_adjoint16 stores ahat_l below its seed); the small lighting / rgb-head
+// products run on k_t_lin (fp32 MFMA, fused bias / mask / seed epilogues; no library GEMM is left); the weight-gradient products, which contract over the half-million samples of the
 // batch, run on the hand-written exact-fp32 MFMA kernel k_t_wgrad below; everything else is element-wise kernels.
 #include "dsn_common.h"
 #include "dsn_kernels.h"
