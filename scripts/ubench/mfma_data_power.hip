@@ -2,6 +2,8 @@
 // one wave per SIMD, 1024 workgroups; operands per MFMA cycle through NSET different register sets whose contents are
 //   KIND 0: all zero                1: one small constant          2: random fp16 in [-1, 1) (full-entropy mantissas)
 //   KIND 3: random, but every MFMA uses the SAME operand set (values random, no toggling between consecutive MFMAs)
+//   KIND 4: random with the low 5 mantissa bits of both operands cleared      5: random, half of the B values zero (post-ReLU activations)
+//   KIND 6: A random in [-1, 1), B = small residuals (random x 2^-11: what the lo halves of a hi / lo split look like)
 // Prints ms, shader clock (s_memtime / s_memrealtime) and the fraction of the nominal 2.4 GHz rate.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,14 +21,20 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* clk, in
             float v = 0.f;
             if (KIND == 1) v = 0.01f;
             if (KIND >= 2) v = (float)(int)(rng(s) >> 8) * (1.0f / 8388608.0f) - 1.0f;
-            A[q][j] = (_Float16)v;
+            _Float16 hv = (_Float16)v;
+            if (KIND == 4) { unsigned short b = __builtin_bit_cast(unsigned short, hv) & 0xffe0u; hv = __builtin_bit_cast(_Float16, b); }
+            A[q][j] = hv;
         }
     for (int q = 0; q < 4; ++q)
         for (int j = 0; j < 8; ++j) {
             float v = 0.f;
             if (KIND == 1) v = 0.02f;
             if (KIND >= 2) v = (float)(int)(rng(s) >> 8) * (1.0f / 8388608.0f) - 1.0f;
-            B[q][j] = (_Float16)v;
+            if (KIND == 5 && (rng(s) & 0x10000u)) v = 0.f;
+            if (KIND == 6) v *= (1.0f / 2048.0f);
+            _Float16 hv = (_Float16)v;
+            if (KIND == 4) { unsigned short b = __builtin_bit_cast(unsigned short, hv) & 0xffe0u; hv = __builtin_bit_cast(_Float16, b); }
+            B[q][j] = hv;
         }
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
@@ -60,16 +68,19 @@ template <int KIND> void run(const char* name, float* d, unsigned long long* clk
 int main() {
     float* d; (void)hipMalloc(&d, 1024);
     unsigned long long* clk; (void)hipMalloc(&clk, 64);
-    const char* name[4] = {"operands all zero", "one small constant", "random fp16, 8 x 4 operand sets in rotation", "random fp16, the same operands every MFMA"};
-    const int iters = 40000;      // 32 MFMAs per iteration, 4 workgroups per CU back to back: ~100 ms per run
-    double ms[4][5], g[4][5];
+    const char* name[7] = {"operands all zero", "one small constant", "random fp16, 8 x 4 operand sets in rotation", "random fp16, the same operands every MFMA",
+                           "random, low 5 mantissa bits cleared", "random, half of B zero (post-ReLU)", "A random, B random x 2^-11 (lo halves)"};
+    const int iters = 25000;      // 32 MFMAs per iteration, 4 workgroups per CU back to back: ~100 ms per run
+    double ms[7][5], g[7][5];
     double dm, dg;
     run<0>("", d, clk, 4000, &dm, &dg);
     for (int r = 0; r < 5; ++r) {
         run<0>(name[0], d, clk, iters, &ms[0][r], &g[0][r]); run<1>(name[1], d, clk, iters, &ms[1][r], &g[1][r]);
         run<2>(name[2], d, clk, iters, &ms[2][r], &g[2][r]); run<3>(name[3], d, clk, iters, &ms[3][r], &g[3][r]);
+        run<4>(name[4], d, clk, iters, &ms[4][r], &g[4][r]); run<5>(name[5], d, clk, iters, &ms[5][r], &g[5][r]);
+        run<6>(name[6], d, clk, iters, &ms[6][r], &g[6][r]);
     }
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 7; ++v) {
         double m = 0, c = 0; for (int r = 1; r < 5; ++r) { m += ms[v][r]; c += g[v][r]; } m /= 4; c /= 4;
         // 1024 workgroups x 4 waves x iters x 32 MFMAs x 32768 flop
         const double tf = 1024.0 * 4 * iters * 32 * 32768.0 / (m * 1e-3) / 1e12;
