@@ -193,7 +193,7 @@ def main():
         with torch.cuda.stream(streams[j]):
             nears[j].copy_(near0)
             fars[j].copy_(far0)
-            scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+            scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)   # what Renderer does per frame
             outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                        skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
                                        screen=not args.no_screen, early_stop=early)
@@ -285,7 +285,7 @@ def main():
                 n_.copy_(near0); f_.copy_(far0)
                 torch.cuda.synchronize()
                 t = time.perf_counter()
-                scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+                scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
                 _lib.render_rays(scene, packed, ws, ray_o, ray_d, n_, f_, S, t_vals, None, None, want_weights=False, out=outs[0], **kw)
                 torch.cuda.synchronize()
                 if i:
@@ -391,7 +391,7 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
         nonlocal out
         near.copy_(near0)
         far.copy_(far0)
-        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
         out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
                                screen=info["usable"])
         px[:Rl, 0:3] = out["color"]

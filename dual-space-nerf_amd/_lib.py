@@ -32,7 +32,7 @@ PARAM_ORDER = [
 
 EXPORTS = [
     "dsn_abi_version", "dsn_last_error", "dsn_packed_param_bytes", "dsn_pack_params",
-    "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_sample_gg",
+    "dsn_pack_params_host_image", "dsn_scene_bytes", "dsn_set_body", "dsn_set_frame", "dsn_set_frame_ex", "dsn_sample_gg",
     "dsn_sample_uniform", "dsn_warp", "dsn_field", "dsn_field_record_bytes",
     "dsn_field_forward", "dsn_field_reverse", "dsn_shade", "dsn_composite",
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
@@ -53,6 +53,7 @@ EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transpare
 SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.05      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
 SCREEN_MIN_DROPPED = 0.35     # PackedParams.calibrate_screen: below this share of dropped calibration points the screen stays off
 RAYS_ZJU, RAYS_H36M = 0, 1
+FRAME_FINE_ONLY = 1           # dsn_set_frame_ex: only the fine nearest-face level of the posed mesh (points beyond it: exhaustive sweep)
 # int32 words of the render workspace the library leaves diagnostics in (include/dsnerf.h)
 CNT_ACTIVE, CNT_POS, CNT_KEEP, CNT_AUDIT, CNT_RANGE = 0, 16, 32, 40, 48
 
@@ -71,8 +72,8 @@ def lib():
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 2:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 2 - rebuild it "
+        if L.dsn_abi_version() != 3:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 3 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -209,12 +210,15 @@ class Scene:
         self.frame_key = None
 
     def set_frame(self, packed: PackedParams, xyz, poses, frame_idx: int, zero_code: bool = False,
-                  light_shift=None, rot=None, rot_center=None, reuse: bool = False):
+                  light_shift=None, rot=None, rot_center=None, reuse: bool = False, fine_only: bool = False):
         """reuse=True: skip the call when the scene already holds exactly this frame for these parameters (same tensors at
-        the same versions) - used by the backward of a training step, which follows its own forward."""
+        the same versions) - used by the backward of a training step, which follows its own forward.
+        fine_only=True (DSN_FRAME_FINE_ONLY): build only the fine nearest-face level of the posed mesh - enough for every sample
+        of rays clipped to the body's bounds (what Renderer.render / render_view produce); points further than 0.12 m outside the
+        posed centroids' box then take the exhaustive sweep (same index)."""
         vkey = lambda a: None if a is None else (a.data_ptr(), a._version, tuple(a.shape))
         key = (vkey(xyz), vkey(poses), int(frame_idx), bool(zero_code), vkey(light_shift), vkey(rot), vkey(rot_center),
-               id(packed), packed._versions)
+               id(packed), packed._versions, bool(fine_only))
         if reuse and key == self.frame_key:
             return self
         self.frame_key = key
@@ -224,9 +228,9 @@ class Scene:
         ls = None if light_shift is None else _f32(light_shift.reshape(-1)[:3], self.device)
         r = None if rot is None else _f32(rot.reshape(-1)[:4], self.device)
         rc = None if rot_center is None else _f32(rot_center.reshape(-1)[:2], self.device)
-        _check(lib().dsn_set_frame(_ptr(self.buf), self.V, self.F, _ptr(packed.buf), _ptr(xyz), _ptr(poses),
-                                   int(frame_idx), int(bool(zero_code)), _ptr(ls), _ptr(r), _ptr(rc), _stream()),
-               "dsn_set_frame")
+        _check(lib().dsn_set_frame_ex(_ptr(self.buf), self.V, self.F, _ptr(packed.buf), _ptr(xyz), _ptr(poses),
+                                      int(frame_idx), int(bool(zero_code)), _ptr(ls), _ptr(r), _ptr(rc),
+                                      FRAME_FINE_ONLY if fine_only else 0, _stream()), "dsn_set_frame")
         self._keep_frame = (xyz, poses, ls, r, rc)
         self._pose_args = (poses, int(frame_idx), bool(zero_code), ls, r, rc)
         return self
@@ -523,6 +527,23 @@ class GradWorkspace:
             self.buf = None
             self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self.buf
+
+
+GRAD_CNT_RANGE = 303          # float word of the training workspace's last 4 KB (dsn_train.hip: w.small) that dsn_render_rays_grad uses as
+                              # an int32 counter of samples whose tangent / adjoint pass left the fp16 range (their second-order /
+                              # adjoint contributions are dropped from that step's weight gradients)
+
+
+def grad_range_word(ws: "GradWorkspace", R, S):
+    """1-element int32 device view of that counter for a backward over R x S samples (no synchronisation)"""
+    need = lib().dsn_grad_workspace_bytes(int(R), int(S))
+    off = need - 4096 + 4 * GRAD_CNT_RANGE
+    return ws.buf[off:off + 4].view(torch.int32)
+
+
+def grad_range_overflow(ws: "GradWorkspace", R, S) -> int:
+    """(synchronises) the counter's value after the last dsn_render_rays_grad on this workspace"""
+    return int(grad_range_word(ws, R, S).item())
 
 
 def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, d_rgb, d_disp=None,

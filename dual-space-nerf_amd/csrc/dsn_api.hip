@@ -69,19 +69,25 @@ int dsn_set_body(void* scene, const float* canon_vertex, const int32_t* faces, i
 int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
                   int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
                   void* stream) {
-    DSN_REQUIRE(scene && packed && xyz && poses24x3, "dsn_set_frame: null argument");
-    DSN_REQUIRE(V > 0 && F > 0, "dsn_set_frame: bad V/F");
-    DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_set_frame: frame index outside the embedding table (maxFrame=500)");
+    return dsn_set_frame_ex(scene, V, F, packed, xyz, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2, 0, stream);
+}
+
+int dsn_set_frame_ex(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
+                     int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2, int flags,
+                     void* stream) {
+    DSN_REQUIRE(scene && packed && xyz && poses24x3, "dsn_set_frame_ex: null argument");
+    DSN_REQUIRE(V > 0 && F > 0, "dsn_set_frame_ex: bad V/F");
+    DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_set_frame_ex: frame index outside the embedding table (maxFrame=500)");
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view(scene, V, F);
     if (hipMemcpyAsync(s.xyz, xyz, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return dsn_fail("%s", "dsn_set_frame: copy failed");
+        return dsn_fail("%s", "dsn_set_frame_ex: copy failed");
     dsn_launch_face_setup(s.xyz, s.faces, F, s.face_world, s.cent_world, st);
     // world-space queries lie inside the (padded) body AABB the rays were clipped to; coarse level beyond
-    dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st);
+    dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st, (flags & DSN_FRAME_FINE_ONLY) != 0);
     dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2,
                           s.frame, st);
-    return dsn_check_launch("dsn_set_frame");
+    return dsn_check_launch("dsn_set_frame_ex");
 }
 
 size_t dsn_pose_state_bytes(void) { return dsn_pose_state_size(); }
@@ -497,10 +503,9 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                     nn_pre, skip);
     if (skip) {
-        // untouched (skipped) samples must still hold finite colour / sigma for the compositor (cleared here, after the
-        // nearest-face search has finished with its scratch)
-        if (hipMemsetAsync(w.sigma, 0, sizeof(float) * N, st) != hipSuccess ||
-            hipMemsetAsync(w.colour, 0, sizeof(float) * 3 * N, st) != hipSuccess)
+        // untouched (skipped) samples must hold density 0 for the compositor (cleared here, after the nearest-face search has
+        // finished with its scratch); a colour is read only where the density is positive (k_composite, lazy_colour)
+        if (hipMemsetAsync(w.sigma, 0, sizeof(float) * N, st) != hipSuccess)
             return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
     if (flags & DSN_FIELD_FP32)
@@ -538,14 +543,14 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
                                    w.rec_cap);
             if (k + 1 < K) dsn_launch_advance_T(w.sigma, w.transparent, z, ray_d, R, S, s0, s1, w.T, st);
         }
-        // shading list: weights from the densities alone (the compositor with a zero colour; flagged densities are still NaN and
-        // keep their rays' samples); scratch = the normal buffer, the output maps are rewritten by the real compositing below
+        // shading list: weights from the densities alone (the compositor without a colour and without per-ray outputs; flagged
+        // densities are still NaN and keep their rays' samples); scratch = the normal buffer
         float* wq = w.n_w;
-        dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, nullptr, R, S, out_rgb, out_disp, out_acc, wq, out_depth, st);
+        dsn_launch_composite(nullptr, w.sigma, w.transparent, z, ray_d, nullptr, R, S, nullptr, nullptr, nullptr, wq, nullptr, st);
         int32_t* sel = w.active;            // (both lists are dead by now)
         int32_t* lit = w.slices;
         dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, DSN_STOP_EPS, sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
-                            w.count + DSN_CNT_STOP + 1, st);
+                            w.count + DSN_CNT_STOP + 1, w.colour, st);
         dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, sel,
                                w.count + DSN_CNT_SEL);
         if (w.rec_cap < N)
@@ -591,7 +596,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     else
         dsn_launch_light16((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
-                         out_weights, out_depth, st);
+                         out_weights, out_depth, st, skip);
     if ((flags & DSN_STOP_STATS) && skip)
         dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), DSN_STOP_EPS, w.count + DSN_CNT_STOP + 2, st);
     return dsn_check_launch("dsn_render_rays");

@@ -912,7 +912,7 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
 // products, forward flavour of dense16) and its outputs are stored times max|u|: row-major hdot_l [7][N,256].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, half8 (&yh)[2],
-                                              half8 (&yl)[2], float* st, float stscale) {
+                                              half8 (&yl)[2], float* st, float stscale, float& ovf) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -923,30 +923,42 @@ __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC
         yh[r >> 3][r & 7] = hi;
         yl[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, v);
     }
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(vv[0]), "v"(vv[1]));      // range guard (see k_tangent16)
     if (st) {
         const int r = 2 * kb;
         *reinterpret_cast<float2*>(st + 8 * (r >> 2) + (r & 3)) = make_float2(vv[0] * stscale, vv[1] * stscale);
     }
 }
 __device__ __forceinline__ void layer16_tan(W16& w, int& blk, int lane, const half8 (&xh)[8][2], const half8 (&xl)[8][2],
-                                            half8 (&yh)[8][2], half8 (&yl)[8][2], const uint32_t (&mk)[4], float* st, float stscale) {
+                                            half8 (&yh)[8][2], half8 (&yl)[8][2], const uint32_t (&mk)[4], float* st, float stscale,
+                                            float& ovf) {
     f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice_tan(pM, pC, kb, mw, yh[m - 1], yl[m - 1], st ? st + 32 * (m - 1) : nullptr, stscale); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice_tan(pM, pC, kb, mw, yh[m - 1], yl[m - 1], st ? st + 32 * (m - 1) : nullptr, stscale, ovf); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice_tan(pM, pC, kb, mw, yh[7], yl[7], st ? st + 32 * 7 : nullptr, stscale);
+    for (int kb = 0; kb < 8; ++kb) epi_slice_tan(pM, pC, kb, mw, yh[7], yl[7], st ? st + 32 * 7 : nullptr, stscale, ovf);
+}
+
+// A sample whose tangent / adjoint left the fp16 range (range guard of k_tangent16 / k_adjoint16): its rows of all `layers` output
+// arrays are rewritten as zeros - the sample drops out of this step's second-order / adjoint weight gradients instead of putting
+// inf / NaN into them - and it is counted (the host mirror warns).  `t` = this lane's slot of layer 0, `ls` = layer stride.
+__device__ __forceinline__ void zero_train_rows(float* t, int64_t ls, int layers) {
+    for (int L = 0; L < layers; ++L)
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(t + L * ls + 32 * m + 8 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, const float* __restrict__ u, int64_t N,
-            const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax) {
+            const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count) {
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
@@ -959,11 +971,18 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
     if (!valid) pt = N - 1;
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
     float ua[3] = {u[3 * pt], u[3 * pt + 1], u[3 * pt + 2]};
-    const float sc = fmaxf(fmaxf(fabsf(ua[0]), fabsf(ua[1])), fabsf(ua[2]));
-    const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
-    for (int c = 0; c < 3; ++c) ua[c] *= inv;
+    // Per-sample scale.  The sample runs on u * 2^-6 / max|u|: the 2^-6 leaves the tangent of every hidden unit 64 x 65 000 of
+    // head-room per unit of u before an fp16 operand overflows (the PE tangent alone is up to 512 x).  A max|u| below 1e-30 - a
+    // cotangent that has underflowed to a denormal, as happens on samples whose weight is ~0 - counts as zero: 1 / max|u| would
+    // overflow to inf and fill the weight gradients with NaN (found by training w4; round 2 divided unconditionally).
+    float sc = fmaxf(fmaxf(fabsf(ua[0]), fabsf(ua[1])), fabsf(ua[2]));
+    if (!(sc > 1e-30f) || !(sc < 3.0e38f)) sc = 0.0f;
+    const float inv = sc > 0.0f ? 0.015625f / sc : 0.0f;
+    for (int c = 0; c < 3; ++c) ua[c] = sc > 0.0f ? ua[c] * inv : 0.0f;
+    sc *= 64.0f;                                  // what the stored outputs are multiplied back by
+    float ovf = 0.0f;                             // range guard: running max of |value| over everything this lane splits into fp16
     if (gmax) {      // batch-wide magnitude of the outputs (bit pattern of a non-negative float orders like the float)
-        float wm = valid ? sc : 0.0f;
+        float wm = valid ? sc * 0.015625f : 0.0f;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
         if (lane == 0 && __float_as_uint(wm) > __atomic_load_n(gmax, __ATOMIC_RELAXED)) atomicMax(gmax, __float_as_uint(wm));
@@ -1013,12 +1032,13 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
         dense16<2, false>(w, blk, lane, ph, pl, aM, aC);
         f32x16 v = unscale16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        track16(ovf, v);
         store16(tt ? tt + 0 * ls + 32 * m : nullptr, v, sc);
         split16<false>(v, ah[m], al[m]);
     }
-    TMK_LOAD(1, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 1 * ls : nullptr, sc);
-    TMK_LOAD(2, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 2 * ls : nullptr, sc);
-    TMK_LOAD(3, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 3 * ls : nullptr, sc);
+    TMK_LOAD(1, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 1 * ls : nullptr, sc, ovf);
+    TMK_LOAD(2, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 2 * ls : nullptr, sc, ovf);
+    TMK_LOAD(3, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 3 * ls : nullptr, sc, ovf);
     TMK_LOAD(4, mk)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -1032,20 +1052,25 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
         }
         f32x16 v = unscale16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        track16(ovf, v);
         store16(tt ? tt + 4 * ls + 32 * m : nullptr, v, sc);
         split16<false>(v, ah[m], al[m]);
     }
-    TMK_LOAD(5, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 5 * ls : nullptr, sc);
-    TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 6 * ls : nullptr, sc);
+    TMK_LOAD(5, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 5 * ls : nullptr, sc, ovf);
+    TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 6 * ls : nullptr, sc, ovf);
 #undef TMK_LOAD
+    if (!(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE) && tt) {      // (false for inf and for the NaN an inf times 0 leaves)
+        zero_train_rows(tt, ls, 7);
+        if (half == 0 && range_count) atomicAdd(range_count, 1);
+    }
 }
 
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          float* gmax, hipStream_t st) {
+                          float* gmax, hipStream_t st, int32_t* range_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t,
-                       (uint32_t*)gmax);
+                       (uint32_t*)gmax, range_count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1056,7 +1081,7 @@ void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict__ masks, const float* __restrict__ a_in,
-            float* __restrict__ tr_a, uint32_t* __restrict__ gmax) {
+            float* __restrict__ tr_a, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count) {
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     const int tid = threadIdx.x;
@@ -1087,6 +1112,7 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
             sc = fmaxf(sc, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
         }
     sc = fmaxf(sc, __shfl_xor(sc, 32));
+    if (!(sc > 1e-30f) || !(sc < 3.0e38f)) sc = 0.0f;       // (a denormal seed: 1 / max|seed| would be inf - see k_tangent16)
     const float inv = sc > 0.0f ? 1.0f / sc : 0.0f;
     if (gmax) {
         float wm = valid ? sc : 0.0f;
@@ -1098,7 +1124,7 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[m][r] *= inv;
+        for (int r = 0; r < 16; ++r) v[m][r] = sc > 0.0f ? v[m][r] * inv : 0.0f;
         split16<true>(v[m], ah[m], al[m]);
     }
     W16 w;
@@ -1113,9 +1139,9 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
     float* const ta = valid ? tr_a + pt * 256 + 4 * half : nullptr;
 #define AMK_LOAD(L, mk) { mk[0] = s_mask[L][0][tid]; mk[1] = s_mask[L][1][tid]; mk[2] = s_mask[L][2][tid]; mk[3] = s_mask[L][3][tid]; }
     uint32_t mk[4];
-    float ovf_unused = 0.0f;   // (every sample runs on seed / max|seed|: the range guard of k_field16 is not needed here)
-    AMK_LOAD(5, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf_unused, ta ? ta + 5 * ls : nullptr, sc);
-    AMK_LOAD(4, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 4 * ls : nullptr, sc);
+    float ovf = 0.0f;          // range guard: the seed is normalised, what the six transposed layers make of it is not bounded
+    AMK_LOAD(5, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 5 * ls : nullptr, sc);
+    AMK_LOAD(4, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 4 * ls : nullptr, sc);
     AMK_LOAD(3, mk)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {       // stage2.0^T, h part
@@ -1123,6 +1149,7 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         f32x16 x = fold16(aM, aC);
         mask16(x, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        track16(ovf, x);
         store16(ta ? ta + 3 * ls + 32 * m : nullptr, x, sc);
         split16<true>(x, bh[m], bl[m]);
     }
@@ -1131,18 +1158,22 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
         f32x16 aM = zero16(), aC = zero16();
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
     }
-    AMK_LOAD(2, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 2 * ls : nullptr, sc);
-    AMK_LOAD(1, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf_unused, ta ? ta + 1 * ls : nullptr, sc);
-    AMK_LOAD(0, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf_unused, ta ? ta + 0 * ls : nullptr, sc);
+    AMK_LOAD(2, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 2 * ls : nullptr, sc);
+    AMK_LOAD(1, mk) layer16_bwd<true>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 1 * ls : nullptr, sc);
+    AMK_LOAD(0, mk) layer16_bwd<true>(w, blk, lane, bh, bl, ah, al, mk, ovf, ta ? ta + 0 * ls : nullptr, sc);
 #undef AMK_LOAD
+    if (!(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE) && ta) {
+        zero_train_rows(ta, ls, 6);
+        if (half == 0 && range_count) atomicAdd(range_count, 1);
+    }
 }
 
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
-                          hipStream_t st) {
+                          hipStream_t st, int32_t* range_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_adjoint16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, N, (const uint4*)masks, a_in, tr_a,
-                       (uint32_t*)gmax);
+                       (uint32_t*)gmax, range_count);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,7 +111,8 @@ void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_id
 // because the reference uses the FIRST ray's origin for every ray), then the block writes
 // z_vals / pts with lanes running over samples (coalesced).
 // ---------------------------------------------------------------------------------------------
-#define GG_TILE 2048
+#define GG_TILE 512      // 8 KB of vertices + 4 KB of per-wave survivor lists: with 2048 the kernel held 51 KB of LDS and could not share a
+                         // compute unit with k_field16<forward> (137 KB of 160) when two frames are in flight
 #define GG_THREADS 256
 // order-preserving int key of a float (for atomicMin / atomicMax on intervals found by different vertex slices)
 __device__ __forceinline__ int gg_key(float f) {
@@ -657,13 +658,16 @@ __device__ __forceinline__ float dsn_wave_sum(float v) {
     return v;
 }
 
+// lazy_colour (eval mode with the transparent skip): a colour exists only where the density is positive (elsewhere the weight is
+// exactly 0 and the reference's colour never reaches the pixel), so it is read only there - the colour array needs no clearing.
+// colour == NULL: weights from the densities alone (the shading list of DSN_EARLY_STOP); rgb_map == NULL: no per-ray outputs.
 __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ colour, const float* __restrict__ sigma,
                                                     const uint8_t* __restrict__ transparent,
                                                     const float* __restrict__ z_vals, const float* __restrict__ ray_d,
                                                     const float* __restrict__ noise, int R, int S,
                                                     float* __restrict__ rgb_map, float* __restrict__ disp_map,
                                                     float* __restrict__ acc_map, float* __restrict__ weights,
-                                                    float* __restrict__ depth_map) {
+                                                    float* __restrict__ depth_map, int lazy_colour) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;   // wave-uniform
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
             if (transparent && transparent[g]) s = 0.f;
             if (noise) s = s + noise[g];
             s = s > 0.f ? s : 0.f;
-            cr = colour[3 * g]; cg = colour[3 * g + 1]; cb = colour[3 * g + 2];
+            if (colour && (!lazy_colour || s > 0.f)) { cr = colour[3 * g]; cg = colour[3 * g + 1]; cb = colour[3 * g + 2]; }
         }
         const float alpha = in ? (1.0f - expf(-s * dist)) : 0.f;
         const float fac = in ? ((1.0f - alpha) + 1e-10f) : 1.0f;
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
         sdep += dsn_wave_sum(w * z);
         sacc += dsn_wave_sum(w);
     }
-    if (lane == 0) {
+    if (lane == 0 && rgb_map) {
         rgb_map[3 * r] = sr; rgb_map[3 * r + 1] = sg; rgb_map[3 * r + 2] = sb;
         depth_map[r] = sdep;
         acc_map[r] = sacc;
@@ -721,9 +725,9 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
 
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
-                          float* acc_map, float* weights, float* depth_map, hipStream_t st) {
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour) {
     hipLaunchKernelGGL(k_composite, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
-                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map);
+                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,7 +848,7 @@ __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, int64_t
 __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_count, int64_t rec_cap,
                                                    const float* __restrict__ weight, const float* __restrict__ sigma, float eps,
                                                    int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int32_t* __restrict__ lit,
-                                                   int32_t* __restrict__ lit_count, int32_t* __restrict__ culled) {
+                                                   int32_t* __restrict__ lit_count, int32_t* __restrict__ culled, float* __restrict__ colour) {
     __shared__ int s_cnt[3], s_base[2];
     const int n = *pos_count;
     for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
@@ -863,8 +867,11 @@ __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ po
                 if (keep) {
                     olit[j] = atomicAdd(&s_cnt[1], 1);
                     if (i < rec_cap) osel[j] = atomicAdd(&s_cnt[0], 1);
-                } else
+                } else {
                     atomicAdd(&s_cnt[2], 1);
+                    // (its density is positive, so the compositor reads its colour: the colour of a sample that is not shaded is 0)
+                    colour[3 * (int64_t)idx[j]] = 0.f; colour[3 * (int64_t)idx[j] + 1] = 0.f; colour[3 * (int64_t)idx[j] + 2] = 0.f;
+                }
             }
         }
         __syncthreads();
@@ -949,10 +956,11 @@ void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
 }
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
-                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled, hipStream_t st) {
+                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled,
+                         float* colour, hipStream_t st) {
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
     hipLaunchKernelGGL(k_cull_lit, dim3((unsigned)blocks), dim3(256), 0, st, pos, pos_count, rec_cap, weight, sigma, eps, sel, sel_count, lit,
-                       lit_count, culled);
+                       lit_count, culled, colour);
 }
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
                            float eps, int32_t* out, hipStream_t st) {

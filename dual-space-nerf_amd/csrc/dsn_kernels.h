@@ -38,10 +38,11 @@ void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* gra
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
                        bool exhaustive, hipStream_t st);
 // dsn_nn.hip
-void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st);
+void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
+                         bool fine_only = false);
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
-                          float* acc_map, float* weights, float* depth_map, hipStream_t st);
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false);
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                             void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap);
@@ -96,9 +97,9 @@ void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, cons
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st,
                               int32_t* range_count = nullptr);
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
-                          hipStream_t st);
+                          hipStream_t st, int32_t* range_count = nullptr);
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          float* gmax, hipStream_t st);
+                          float* gmax, hipStream_t st, int32_t* range_count = nullptr);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
@@ -122,6 +123,7 @@ void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const 
                           int s1, float* T, hipStream_t st);
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
-                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled, hipStream_t st);
+                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled,
+                         float* colour, hipStream_t st);
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
                            float eps, int32_t* out, hipStream_t st);

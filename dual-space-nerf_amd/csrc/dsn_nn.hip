@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ c
 
 // exclusive scan of the counts (single block), capacity check
 // exclusive prefix of one value per thread over a 1024-thread block (wave shuffles + one LDS hop); total in *tot
-#define SCAN_PER 11                       // cells per thread and tile: 11 264-cell tiles, LDS stride 11 is conflict-free
+#define SCAN_PER 3                        // cells per thread and tile: 3 072-cell tiles = 12 KB of LDS (with 11 the two scan kernels
+                                          // held 45 KB and could not share a compute unit with a persistent field workgroup: 104-137 KB of 160)
 __device__ __forceinline__ int dsn_block_exscan(int v, int* s_w, int& tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
@@ -260,11 +261,18 @@ static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, flo
 
 static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st) {
+// a level that is not built: dsn_grid_cell() answers -1 for every point (ok = 0), queries go on to the next level / the sweep
+__global__ void k_grid_disable(DsnGrid* __restrict__ g) {
+    g->ok = 0; g->ncell = 0; g->total = 0; g->nx = g->ny = g->nz = 0;
+}
+
+void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
+                         bool fine_only) {
     const int t_fine = dsn_clampi(3 * F, 512, 44000);
     const int t_coarse = dsn_clampi(F / 3, 64, 5000);
     dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), true, st);
-    dsn_build_level(cent, F, nn.coarse, pad_coarse, t_coarse, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), false, st);
+    if (fine_only) hipLaunchKernelGGL(k_grid_disable, dim3(1), dim3(1), 0, st, nn.coarse.g);
+    else dsn_build_level(cent, F, nn.coarse, pad_coarse, t_coarse, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), false, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1269,7 +1269,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
     float* const g_tan = w.small + 300;        // batch-wide magnitudes of the tangent / adjoint arrays (zeroed with w.small)
     float* const g_adj = w.small + 301;
-    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st);
+    int32_t* const range_cnt = (int32_t*)(w.small + 303);      // samples whose tangent / adjoint left the fp16 range (zeroed with w.small)
+    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt);
     wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st);
     for (int l = 1; l < 7; ++l)
         wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
@@ -1288,7 +1289,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;
-    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st);
+    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
         wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]]);

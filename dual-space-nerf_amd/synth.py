@@ -135,8 +135,9 @@ def pose_body(canon: np.ndarray, seed: int = 3, trans=(0.2, -0.1, 1.0)) -> np.nd
 # camera
 # --------------------------------------------------------------------------------------
 def make_rays(H: int, W: int, xyz: np.ndarray, cam_dist: float = 2.6, focal_frac: float = 1.05,
-              pad: float = 0.05, unit_dirs: bool = False, fit_box: bool = False):
-    """Pinhole rays for an H x W image looking at the body's centre from -z at `cam_dist`.
+              pad: float = 0.05, unit_dirs: bool = False, fit_box: bool = False, yaw: float = 0.35, pitch: float = -0.12):
+    """Pinhole rays for an H x W image looking at the body's centre from -z at `cam_dist` (turned by `yaw` about y and
+    `pitch` about x: other values give the other cameras of a multi-view rig, scripts/train_w4.py).
 
     Returns dict(ray_o [R,3], ray_d [R,3], near [R], far [R]) float32, R = H*W.
     ray_d = K^-1 [u,v,1] rotated to world (|d| in 1..~1.1, not normalised) - ZJU convention,
@@ -147,8 +148,7 @@ def make_rays(H: int, W: int, xyz: np.ndarray, cam_dist: float = 2.6, focal_frac
     ctr = 0.5 * (xyz.min(0) + xyz.max(0)).astype(np.float64)
     lo = xyz.min(0).astype(np.float64) - pad
     hi = xyz.max(0).astype(np.float64) + pad
-    # small fixed yaw/pitch so rays are not axis-aligned
-    yaw, pitch = 0.35, -0.12
+    # (defaults: a small fixed yaw/pitch so rays are not axis-aligned)
     Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
     Rx = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])
     Rc2w = Ry @ Rx

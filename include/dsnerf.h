@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 2
+#define DSN_ABI_VERSION 3
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -62,6 +62,14 @@ DSN_EXPORT int dsn_set_body(void* scene, const float* canon_vertex, const int32_
 DSN_EXPORT int dsn_set_frame(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
                   int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2,
                   void* stream);
+/* dsn_set_frame with flags (ABI 3).  DSN_FRAME_FINE_ONLY: of the posed mesh's two nearest-face levels only the fine one is
+ * built (it covers the posed centroids' bounding box + 0.12 m: every sample of a ray clipped to the body's bounds, which is
+ * all Renderer.render / render_view ever produce, utils/rays_utils.py:63-97 + utils/pts_utils.py:18-58); points beyond it
+ * take the exhaustive sweep instead of the coarse lists - the same index, slower for such points, 0.3 ms less per frame. */
+#define DSN_FRAME_FINE_ONLY 1
+DSN_EXPORT int dsn_set_frame_ex(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
+                     int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2, int flags,
+                     void* stream);
 
 /* Pose-only state: what a density-only query needs of a frame (DualSpaceNeRF.forward(density_only=True),
  * model/spacenet.py:223-241, used by Renderer.query_volume can_render.py:280-296 with a batch_info that holds only

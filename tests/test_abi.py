@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.dsn_abi_version() == 2
+    assert lib.dsn_abi_version() == 3
     assert lib.dsn_pose_state_bytes() >= 256 + 4 * (64 + 256)          # header + DsnFrameState
     assert lib.dsn_calibrate_workspace_bytes(C.c_int64(1 << 20)) >= (1 << 20) * 28
     assert lib.dsn_packed_param_bytes() > 3_000_000            # fwd + transposed images of ~0.5 M params
@@ -57,6 +57,7 @@ def test_every_entry_point_rejects_null_arguments(lib):
     calls = {
         "dsn_set_body": lambda: lib.dsn_set_body(z, z, z, 0, 0, z),
         "dsn_set_frame": lambda: lib.dsn_set_frame(z, 1, 1, z, z, z, 0, 0, z, z, z, z),
+        "dsn_set_frame_ex": lambda: lib.dsn_set_frame_ex(z, 1, 1, z, z, z, 0, 0, z, z, z, 0, z),
         "dsn_sample_gg": lambda: lib.dsn_sample_gg(z, 1, 1, z, z, z, z, 0, 0, z, z, z, z, z),
         "dsn_warp": lambda: lib.dsn_warp(z, 1, 1, z, z, i64(0), 1, z, z, z, z, z, z, z, z, 0, z),
         "dsn_field": lambda: lib.dsn_field(z, 1, 1, z, z, i64(0), z, z, z, z, z, 0, z),

@@ -163,3 +163,39 @@ def test_full_batch_gradients_are_additive_and_linear():
         n = max(np.linalg.norm(w), 1e-30)
         assert np.linalg.norm(w - (x + y)) / n < 2e-5, (k, np.linalg.norm(w - (x + y)) / n)
         assert np.linalg.norm(t - 2.0 * w) / n < 2e-5, (k, np.linalg.norm(t - 2.0 * w) / n)
+
+
+def test_underflowing_cotangents_leave_finite_gradients():
+    """Regression (round 3, found by training w4): rays whose cotangent has underflowed to ~1e-38 gave some samples a denormal
+    u = dL/d(grad sigma); k_tangent16 divided by max|u| (1 / 1e-39 = inf) and the second-order weight gradients of the whole
+    batch came out NaN.  Such samples now count as u = 0: the gradients are finite and equal those of the batch with these
+    rays' cotangents set to exactly zero."""
+    from dsnerf_amd import _lib
+    g = dict(load("full_train_grads").items())
+    sd = state("full_train_grads")
+    r = make_renderer(g, "full_train_grads")
+    dev = r.device
+    z = g["render:z_vals"]
+    R, S = z.shape
+    T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    r._set_frame(make_batch(g))
+    rng = np.random.default_rng(7)
+    d_rgb = rng.standard_normal((R, 3)).astype(np.float32)
+    tiny = d_rgb.copy()
+    tiny[::2] *= np.float32(1e-36)                       # every other ray: a cotangent at the edge of float32
+    zero = d_rgb.copy()
+    zero[::2] = 0.0
+    params = {k: torch.from_numpy(v).to(dev) for k, v in sd.items()}
+    ws = _lib.GradWorkspace(dev)
+
+    def run(c):
+        out = _lib.render_rays_grad(r.scene, params, T(g["poses"]), int(g["frame"]), False, T(g["ray_o"]), T(g["ray_d"]), T(z),
+                                    T(g["noise"]), T(c), ws=ws)
+        return [x.double().cpu().numpy() for x in out], _lib.grad_range_overflow(ws, R, S)
+
+    a, ovf_a = run(tiny)
+    b, ovf_b = run(zero)
+    assert ovf_a == 0 and ovf_b == 0
+    for k, x, y in zip(_lib.PARAM_ORDER, a, b):
+        assert np.isfinite(x).all(), k
+        assert np.linalg.norm(x - y) <= 1e-6 * max(np.linalg.norm(y), 1e-30), (k, np.linalg.norm(x - y), np.linalg.norm(y))
