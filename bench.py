@@ -64,9 +64,14 @@ def parse():
                     help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
                          "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
     ap.add_argument("--train-rays", type=int, default=8192)
-    ap.add_argument("--weights", default="default", choices=["default", "w2", "w3"],
+    ap.add_argument("--weights", default="default", choices=["default", "w2", "w3", "w4"],
                     help="parameter set: the hash-generated default, w2 = trained by the real reference (tests/golden/weights_w2.npz, "
-                         "dense near the surface: the density screen calibrates itself off), w3 = large-magnitude hash set")
+                         "dense near the surface: the density screen calibrates itself off), w3 = large-magnitude hash set, w4 = "
+                         "CONVERGED on the synthetic body by this repo's HIP trainer (scripts/train_w4.py, tests/golden/weights_w4.npz)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --strong on ONE GPU: render each of the N ranks' round-robin tile shares of the frame alone, one after "
+                         "the other, and report the N times, max / mean (the load balance of the tile deal) and the strong-scaling "
+                         "efficiency they predict")
     ap.add_argument("--strong", action="store_true",
                     help="strong-scaling mode (BASELINE configs[3]): ONE 1024 x 1024 x 128 frame, its rays dealt to the ranks in "
                          "round-robin 3072-ray tiles (RayParallel.tile_indices), rendered pixels all-gathered inside the timed "
@@ -82,8 +87,8 @@ def parse():
 
 
 def load_weights(synth, name):
-    if name == "w2":
-        z = np.load(os.path.join(ROOT, "tests", "golden", "weights_w2.npz"))
+    if name in ("w2", "w4"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{name}.npz"))
         return {k[2:]: z[k] for k in z.files if k.startswith("w:")}
     if name == "w3":
         return synth.make_state_dict(seed=7, gain=3.5)
@@ -137,7 +142,6 @@ def main():
     xyz = synth.pose_body(canon, seed=3 + rank)          # every rank renders its own frame of the batch
     rays = synth.make_rays(H, W, xyz, fit_box=True)    # every ray crosses the padded body AABB (= mask_at_box rays)
 
-    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
     depth = max(1, args.pipeline)
     scenes = [_lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev) for _ in range(depth)]
     wss = [_lib.RenderWorkspace(dev) for _ in range(depth)]
@@ -157,31 +161,37 @@ def main():
     packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
     for j in range(depth):          # allocate every slot's workspace up front (setup, not a step: W may be smaller than the depth)
         wss[j].get(R, S)
-    # the density screen's margin is measured for these parameters once, like Renderer does after a checkpoint load
-    # (PackedParams.calibrate_screen: set-up, not a step)
-    screen_info = None
-    if not (args.dense or args.fp32 or args.no_screen):
-        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
-        screen_info = packed.calibrate_screen(scene)
-        if not screen_info["usable"] and not args.force_screen:
-            args.no_screen = True
-    # front-to-back slices with ray termination: decided like Renderer does, from one probe frame (set-up, not a step)
-    stop_info = {"enabled": False}
-    if not (args.dense or args.fp32) and args.early_stop != "off":
-        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
-        _lib.render_rays(scene, packed, ws, ray_o, ray_d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False,
-                         screen=not args.no_screen, stop_stats=True)
+
+    def prepare(state_dict):
+        """what Renderer does once per checkpoint (set-up, not a step): pack the parameters, measure the density screen's margin
+        for them (PackedParams.calibrate_screen) and decide front-to-back slicing from the statistics of one probe frame"""
+        pk = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in state_dict.items()})
+        no_screen, screen_info = bool(args.no_screen), None
+        if not (args.dense or args.fp32 or args.no_screen):
+            scene.set_frame(pk, d_xyz, d_poses, 5, False, None, None, None)
+            screen_info = pk.calibrate_screen(scene)
+            if not screen_info["usable"] and not args.force_screen:
+                no_screen = True
+        stop_info = {"enabled": False}
+        if not (args.dense or args.fp32) and args.early_stop != "off":
+            scene.set_frame(pk, d_xyz, d_poses, 5, False, None, None, None)
+            _lib.render_rays(scene, pk, ws, ray_o, ray_d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False,
+                             screen=not no_screen, stop_stats=True)
+            torch.cuda.synchronize()
+            st = _lib.read_stop_stats(ws)
+            frac = st["would_skip"] / max(st["active"], 1)
+            stop_info = {"enabled": args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED,
+                         "probe_frame_would_skip_fraction_of_non_transparent": frac, "eps": _lib.early_stop_eps(S)}
+        if stop_info["enabled"] and screen_info is not None and not args.force_screen:
+            # with termination in use the screen's dropped share counts among the samples still evaluated (PackedParams.screen_pays)
+            pk.early_stop = {"skipped_fraction": stop_info.get("probe_frame_would_skip_fraction_of_non_transparent", 0.0), "usable": True}
+            no_screen = not pk.screen_pays(True)
         torch.cuda.synchronize()
-        st = _lib.read_stop_stats(ws)
-        frac = st["would_skip"] / max(st["active"], 1)
-        stop_info = {"enabled": args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED,
-                     "probe_frame_would_skip_fraction_of_non_transparent": frac, "eps": 2.0 ** -20}
-    early = stop_info["enabled"]
-    if early and screen_info is not None and not args.force_screen:
-        # with termination in use the screen's dropped share counts among the samples still evaluated (PackedParams.screen_pays)
-        packed.early_stop = {"skipped_fraction": stop_info.get("probe_frame_would_skip_fraction_of_non_transparent", 0.0), "usable": True}
-        args.no_screen = not packed.screen_pays(True)
-    torch.cuda.synchronize()
+        return {"packed": pk, "no_screen": no_screen, "early": stop_info["enabled"], "screen_info": screen_info, "stop_info": stop_info}
+
+    cur = prepare(sd)
+    packed, screen_info, stop_info, early = cur["packed"], cur["screen_info"], cur["stop_info"], cur["early"]
+    args.no_screen = cur["no_screen"]
     k_step = 0
 
     def step():
@@ -193,10 +203,10 @@ def main():
         with torch.cuda.stream(streams[j]):
             nears[j].copy_(near0)
             fars[j].copy_(far0)
-            scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)   # what Renderer does per frame
-            outs[j] = _lib.render_rays(scenes[j], packed, wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
+            scenes[j].set_frame(cur["packed"], d_xyz, d_poses, 5, False, None, None, None, fine_only=True)   # what Renderer does per frame
+            outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                        skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
-                                       screen=not args.no_screen, early_stop=early)
+                                       screen=not cur["no_screen"], early_stop=cur["early"])
             if use_dist:
                 packed_px[j][:, 0:3] = outs[j]["color"]
                 packed_px[j][:, 3] = outs[j]["disp_map"]
@@ -271,6 +281,46 @@ def main():
         },
     }
 
+    if rank == 0 and world == 1 and not args.no_extras and not (args.dense or args.fp32):
+        # The frame time is a property of the CHECKPOINT as much as of the kernels: the same frame, same pipeline,
+        # 5 timed frames each, for every parameter set the repo pins with reference-generated goldens.  w4 is the converged one.
+        headline = cur
+        by = {}
+        for name in ("default", "w2", "w3", "w4"):
+            if name in ("w2", "w4") and not os.path.exists(os.path.join(ROOT, "tests", "golden", f"weights_{name}.npz")):
+                continue
+            if name == args.weights:
+                by[name] = {"ms_per_frame": ms_step, "frames": args.steps}
+                c = headline
+            else:
+                c = cur = prepare(load_weights(synth, name))
+                k_step = 0
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                by[name] = {"ms_per_frame": 1e3 * (time.perf_counter() - tb) / 5, "frames": 5}
+            cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
+            st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
+            by[name].update({
+                "rays_per_s": R / (by[name]["ms_per_frame"] * 1e-3),
+                "density_screen": not c["no_screen"],
+                "screen_margin": None if c["screen_info"] is None else c["screen_info"]["margin"],
+                "screen_dropped_fraction_at_calibration": None if c["screen_info"] is None else c["screen_info"]["dropped_fraction"],
+                "early_stop": bool(c["early"]),
+                "early_stop_would_skip_fraction": c["stop_info"].get("probe_frame_would_skip_fraction_of_non_transparent"),
+                "early_stop_skipped_fraction": (st["skipped"] / max(st["active"], 1)) if c["early"] else 0.0,
+                "non_transparent_fraction": int(cw[_lib.CNT_ACTIVE]) / float(R * S),
+                "positive_density_fraction": int(cw[_lib.CNT_POS]) / float(R * S)})
+        cur = headline
+        k_step = 0
+        result["config"]["by_weights"] = by
+        result["config"]["by_weights_note"] = ("same frame and pipeline for every parameter set; default = hash-random init (thin fog), w2 = 400 "
+                                               "reference-trainer steps (solid, unsaturated), w3 = hash init x3.5 (dense guess), w4 = converged "
+                                               "with scripts/train_w4.py: the representative checkpoint")
     if rank == 0 and world == 1 and not args.no_roofline:
         result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -300,6 +350,12 @@ def main():
         ex["host_to_host_ms_after_a_caller_torch_cpu_op"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
                                                                          caller_torch_op=True)
         ex["host_threads"] = torch.get_num_threads()
+        # BASELINE configs[2] in the same line: 8192 x 64 training step (render + MSE + backward + Adam)
+        t_dt, t_loss, t_ovf = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5)
+        result["train"] = {"metric": "training rays/sec (8192 rays x 64 samples: forward + backward + Adam step, BASELINE configs[2])",
+                           "value": args.train_rays * 20 / t_dt, "unit": "rays/s", "train_ms_per_step": 1e3 * t_dt / 20, "steps": 20,
+                           "warmup": 5, "dtype": TRAIN_DTYPE, "final_loss": t_loss, "range_overflow_samples_last_step": t_ovf,
+                           "roofline": train_roofline(1e3 * t_dt / 20, args.train_rays, S)}
         if not args.no_cpu_baseline:
             result["eager_gpu_baseline"] = eager_baseline(args, _lib, synth, dev, chunks=3, train=False)
             result["eager_gpu_baseline"]["x_faster_per_frame"] = result["eager_gpu_baseline"]["eval_ms_per_512x512_frame"] * \
@@ -356,6 +412,8 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
     equal slabs of packed [rays, 6] pixels brings the frame together on every rank, inside the timed region, followed by
     the un-dealing scatter into frame order.  value = rays of the frame / time: strong scaling."""
     import torch.distributed as dist
+    if args.emulate_world > 1 and world == 1:
+        return strong_emulated(args, dsnerf_amd, _lib, synth, dev)
     H = W = args.hw if args.hw != 512 else 1024
     S = args.samples if args.samples != 64 else 128
     R = H * W
@@ -448,11 +506,114 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
         print(json.dumps(res), flush=True)
 
 
-def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
+def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
+    """Load balance of the strong-scaling partition, measured on ONE GPU (no multi-GPU node is available to the
+    builder): the 1024 x 1024 x 128 frame of configs[3] is dealt to N = --emulate-world ranks exactly as strong_bench does
+    (RayParallel.tile_indices, round-robin 3072-ray tiles) and every rank's share is rendered ALONE with the same code, one
+    after the other, on this GPU.  Reported: the N share times, max / mean (the imbalance a real N-GPU run would wait for), the
+    whole frame on one GPU, the un-dealing scatter of N gathered slabs (a local operation, timed here), and the strong-scaling
+    efficiency these predict = T(1 GPU) / (N x (max share + un-deal + all-gather)); the all-gather is NOT measured (one GPU) - it
+    is priced from the xGMI figures of MI355X_MICROARCH.md (each rank receives (N-1)/N of 24 B x R over its N-1 direct links at
+    <= 153 GB/s each, plus a launch latency of 30 us): a stated estimate."""
+    H = W = args.hw if args.hw != 512 else 1024
+    S = args.samples if args.samples != 64 else 128
+    R = H * W
+    Nw = int(args.emulate_world)
+    tile = 3072
+    canon, faces = synth.make_body()
+    sd = load_weights(synth, args.weights)
+    poses = synth.make_poses(seed=5)
+    xyz = synth.pose_body(canon, seed=3)
+    rays = synth.make_rays(H, W, xyz, fit_box=True)
+    rp = dsnerf_amd.RayParallel()
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
+    ws = _lib.RenderWorkspace(dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_xyz, d_poses = T(xyz), T(poses)
+    t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+    info = packed.calibrate_screen(scene)
+
+    def time_share(idx):
+        mine = idx.numpy()
+        o, d, near0, far0 = T(rays["ray_o"][mine]), T(rays["ray_d"][mine]), T(rays["near"][mine]), T(rays["far"][mine])
+        near, far = near0.clone(), far0.clone()
+        Rl = len(mine)
+        px = torch.zeros(Rl, 6, dtype=torch.float32, device=dev)
+        out = None
+        ms = []
+        for i in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            near.copy_(near0)
+            far.copy_(far0)
+            scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
+            out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
+                                   screen=info["usable"])
+            px[:, 0:3] = out["color"]
+            px[:, 3] = out["disp_map"]
+            px[:, 4] = out["acc_map"]
+            px[:, 5] = out["depth_map"]
+            torch.cuda.synchronize()
+            if i >= args.warmup:
+                ms.append(1e3 * (time.perf_counter() - t0))
+        cnt = ws.buf[:256].view(torch.int32).cpu()
+        return float(np.mean(ms)), float(np.min(ms)), Rl, int(cnt[_lib.CNT_ACTIVE]), int(cnt[_lib.CNT_KEEP]), int(cnt[_lib.CNT_POS])
+
+    whole_ms, whole_min, _, a1, k1, p1 = time_share(rp.tile_indices(R, tile, 0, 1))
+    shares = []
+    for r in range(Nw):
+        m, mn, Rl, a, k, p_ = time_share(rp.tile_indices(R, tile, r, Nw))
+        shares.append({"rank": r, "rays": Rl, "ms": m, "ms_min": mn, "non_transparent": a, "accurate_pass": k, "positive_density": p_})
+    # the un-dealing scatter of N equal slabs into frame order (strong_bench's epilogue behind the all-gather)
+    idx_dev = [rp.tile_indices(R, tile, r, Nw).to(dev) for r in range(Nw)]
+    slab = max(i.numel() for i in idx_dev)
+    allp = torch.zeros(Nw * slab, 6, dtype=torch.float32, device=dev)
+    full = torch.empty(R, 6, dtype=torch.float32, device=dev)
+    und = []
+    for i in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(Nw):
+            full[idx_dev[r]] = allp[r * slab: r * slab + idx_dev[r].numel()]
+        torch.cuda.synchronize()
+        if i >= 2:
+            und.append(1e3 * (time.perf_counter() - t0))
+    undeal_ms = float(np.mean(und))
+    t = np.array([x["ms"] for x in shares])
+    ag_ms = 0.03 + 1e3 * (24.0 * R * (Nw - 1) / Nw) / ((Nw - 1) * 153e9) if Nw > 1 else 0.0
+    step_ms = float(t.max()) + undeal_ms + ag_ms
+    res = {"metric": f"strong-scaling load balance, ONE {H}x{W} frame x {S} samples/ray dealt to {Nw} emulated ranks on ONE GPU",
+           "value": R / (step_ms * 1e-3), "unit": "rays/s (PREDICTED for the emulated world: max share + un-deal + priced all-gather)",
+           "n_gpus": 1, "emulated_world": Nw, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
+           "dtype": "split-f16x3 + plain-f16 density screen",
+           "config": {"workload": f"one {H}x{W} frame x {S} samples/ray (BASELINE configs[3]); round-robin {tile}-ray tiles "
+                                  f"(RayParallel.tile_indices); each emulated rank's share rendered alone on one MI355X",
+                      "weights": args.weights, "tile": tile, "shares": shares,
+                      "share_ms_max": float(t.max()), "share_ms_mean": float(t.mean()), "share_ms_min": float(t.min()),
+                      "max_over_mean": float(t.max() / t.mean()),
+                      "whole_frame_one_gpu_ms": whole_ms, "undeal_scatter_ms": undeal_ms,
+                      "all_gather_ms_PRICED_not_measured": ag_ms,
+                      "sum_of_shares_over_whole_frame": float(t.sum() / whole_ms),
+                      "predicted_strong_scaling_efficiency": whole_ms / (Nw * step_ms),
+                      "predicted_speedup": whole_ms / step_ms,
+                      "density_screen_calibration": info}}
+    _flush_c_stdio()
+    print(json.dumps(res), flush=True)
+
+
+TRAIN_DTYPE = ("split-f16x3 (k_field16<train>, k_tangent16, k_adjoint16, k_t_wgrad16c/p: 3 x v_mfma_f32_32x32x16_f16 per product, f32 "
+               "accumulate) + exact-f32 MFMA for the small lighting / colour-head products (k_t_lin, k_t_wgrad)")
+
+
+def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, warmup):
     """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
     backward (dsn_render_rays_grad), Adam step.  With N>1 every rank renders its own 8192-ray batch of the step and
     the 33 gradients are averaged with ONE 2 MB RCCL all-reduce (parallel.RayParallel.average_gradients) before the
-    optimizer step - plain data parallelism (the reference itself trains on one GPU); value = rays/s over all ranks."""
+    optimizer step - plain data parallelism (the reference itself trains on one GPU).  Returns (seconds for `steps` steps - max over
+    ranks -, final loss)."""
     from types import SimpleNamespace
     import torch.distributed as dist
     S, R = args.samples, args.train_rays
@@ -493,11 +654,11 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
@@ -505,21 +666,38 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    final_loss = float(loss)
+    return dt, float(loss), int(r.range_overflow_count())
+
+
+def train_roofline(ms, R, S):
+    """whole-step roofline of the training step: the six trunk-sized contractions per sample (forward, sigma-reverse, tangent,
+    adjoint, and the two weight-gradient products per layer: 6 x 884 608 MAC) over the step time, against the split-fp16 ceiling"""
+    flop = 3.0 * FLOP_FIELD_PER_SAMPLE * R * S          # 3 x (2 x 884 608 MAC) = 5.31 MFLOP per sample
+    ach = flop / (ms * 1e-3) / 1e12
+    peak = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS
+    return {"bound": "mfma", "kernel": "whole training step (k_field16<train> + k_tangent16 + k_adjoint16 + weight-gradient kernels)",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "flop_per_sample": flop / (R * S), "samples_per_step": R * S}
+
+
+def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
+    import torch.distributed as dist
+    S, R = args.samples, args.train_rays
+    dt, final_loss, ovf = train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, args.steps, args.warmup)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         ms = 1e3 * dt / args.steps
-        flop = 6.0 * FLOP_FIELD_PER_SAMPLE / 2.0 * R * S     # fwd, reverse, tangent, adjoint, 2 weight-gradient products
         _flush_c_stdio()
         print(json.dumps({
             "metric": "training rays/sec (64 samples/ray, forward + backward + Adam step)", "value": world * R * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic",
             "config": {"workload": f"training step on {R} rays x {S} samples per GPU (BASELINE configs[2]), dense evaluation "
                                    f"(jitter + noise), synthetic body V=6890/F=13776", "final_loss": final_loss,
-                       "approx_algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}), flush=True)
+                       "range_overflow_samples_last_step": ovf},
+            "roofline": train_roofline(ms, R, S)}), flush=True)
 
 
 def eager_baseline(args, _lib, synth, dev, chunks=5, train=True):
@@ -685,9 +863,17 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
         # scheme is the dense f16 MFMA peak / 3 (= 5.3x the fp32-matrix peak of 157.3)
         peak = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS
         note = "split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32-equivalent accuracy; peak = 2500/3"
+    traffic, traffic_src = measured_traffic(kern, args)
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-           "frac": ach / peak, "traffic": measured_traffic(kern, args), "kernel_ms": ms, "samples_per_launch": n_eval,
+           "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": ms, "samples_per_launch": n_eval,
            "flop_per_sample": flop_per, "scheme": note, "x_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
+    if kern == "k_field16<forward>":
+        rp_ms, rp_src = rocprof_kernel_ms("k_field16ILi1E", args)
+        if rp_ms is not None:
+            # (same sample count: the committed profile is of this command on the same frame)
+            out["rocprof_kernel_ms"] = rp_ms
+            out["rocprof_source"] = rp_src
+            out["frac_at_rocprof_kernel_ms"] = n_eval * flop_per / (rp_ms * 1e-3) / 1e12 / peak
     if screen:
         ach_s = n_all * FLOP_SCREEN_PER_SAMPLE / (ms_screen * 1e-3) / 1e12
         out["screen_kernel"] = {"kernel": "k_screen16", "kernel_ms": ms_screen, "samples_per_launch": n_all,
@@ -701,16 +887,42 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args):
     return out
 
 
+def _profile_file(stem):
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def measured_traffic(kern, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_pmc.json, written by scripts/pmc_summary.py from scripts/gpu_round2.sh: (2*FETCH_SIZE + WRITE_SIZE) KB,
-    the gfx950 correction of MI355X_MICROARCH.md); null when the counters were not collected for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or args.weights != "default" or not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the dominant kernel - NOT measured in this run: read from the committed rocprofv3 PMC passes of this
+    same command (profiles/rNN_pmc.json, written by scripts/pmc_summary.py from scripts/gpu_round*.sh: (2*FETCH_SIZE + WRITE_SIZE) KB,
+    the gfx950 correction of MI355X_MICROARCH.md; counters need their own rocprofv3 passes, which a plain `python bench.py` is not).
+    Returns (bytes | None, source string | None); None when no pass was collected for this configuration."""
+    path = _profile_file("pmc.json")
+    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or args.weights != "default" or path is None:
+        return None, None
     with open(path) as f:
         rec = json.load(f).get(kern)
-    return None if rec is None else rec["hbm_bytes_per_launch"]
+    if rec is None:
+        return None, None
+    return rec["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                         f"`bench.py --steps 5 --warmup 2 --pipeline 1`; not collected in this run)")
+
+
+def rocprof_kernel_ms(mangled_part, args):
+    """average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/rNN_kernel_trace.txt) - beside the live HIP-event time, so that both fractions can be read off one line"""
+    path = _profile_file("kernel_trace.txt")
+    if args.fp32 or args.dense or args.hw != 512 or args.samples != 64 or args.weights != "default" or path is None:
+        return None, None
+    with open(path) as f:
+        for line in f:
+            if mangled_part in line.split(" ")[0]:
+                cols = line.split()
+                return float(cols[3]), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):

@@ -38,7 +38,7 @@ EXPORTS = [
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
-    "dsn_set_screen_margin", "dsn_module_grad",
+    "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -68,12 +68,13 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no fallback path.")
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
+        L.dsn_early_stop_eps.restype = C.c_float
         for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 3:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 3 - rebuild it "
+        if L.dsn_abi_version() != 4:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 4 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -503,6 +504,12 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                  _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
            "dsn_render_rays")
     return out
+
+
+def early_stop_eps(S: int) -> float:
+    """the termination / shading threshold of DSN_EARLY_STOP for rays of S samples: min(2^-20, 1e-4 / (2 (S + 1))) - the frame stays
+    within (S + 1) eps x the largest colour of the one-pass frame (include/dsnerf.h)"""
+    return float(lib().dsn_early_stop_eps(int(S)))
 
 
 def read_stop_stats(ws):

@@ -413,7 +413,13 @@ struct DsnWorkspace {
 #define DSN_CNT_SEL 13
 #define DSN_CNT_LIT 14
 #define DSN_CNT_STOP 56       // [56] samples left out by ray termination, [57] samples not shaded (weight < eps), [58] DSN_STOP_STATS
-#define DSN_STOP_EPS 9.5367431640625e-07f   // 2^-20
+// DSN_EARLY_STOP threshold: the frame moves by at most (S + 1) eps x max|colour| (S unshaded samples of weight < eps each + a
+// terminated tail of total weight < eps), so eps shrinks with S: half of the 1e-4 parity bar for colours <= 1
+static inline float dsn_stop_eps(int S) {
+    const float cap = 9.5367431640625e-07f;      // 2^-20
+    const float e = 1e-4f / (2.0f * (float)(S + 1));
+    return e < cap ? e : cap;
+}
 static inline int dsn_slice_len(int S) {
     const char* e = getenv("DSN_STOP_SLICE");      // experiments: samples per slice
     int L = e ? atoi(e) : 8;
@@ -460,6 +466,8 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
+
+float dsn_early_stop_eps(int S) { return dsn_stop_eps(S > 0 ? S : 1); }
 
 size_t dsn_render_workspace_bytes(int R, int S) {
     if (R <= 0 || S <= 0) return 0;
@@ -526,7 +534,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             const int32_t* sc = w.count + DSN_CNT_SLICE + k;
             if (k > 0) {
                 if (hipMemsetAsync(w.count + DSN_CNT_ALIVE, 0, 4, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
-                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, DSN_STOP_EPS, w.alive, w.count + DSN_CNT_ALIVE, w.count + DSN_CNT_STOP, st);
+                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, dsn_stop_eps(S), w.alive, w.count + DSN_CNT_ALIVE, w.count + DSN_CNT_STOP, st);
                 sl = w.alive;
                 sc = w.count + DSN_CNT_ALIVE;
             }
@@ -549,7 +557,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         dsn_launch_composite(nullptr, w.sigma, w.transparent, z, ray_d, nullptr, R, S, nullptr, nullptr, nullptr, wq, nullptr, st);
         int32_t* sel = w.active;            // (both lists are dead by now)
         int32_t* lit = w.slices;
-        dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, DSN_STOP_EPS, sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
+        dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, dsn_stop_eps(S), sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
                             w.count + DSN_CNT_STOP + 1, w.colour, st);
         dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, sel,
                                w.count + DSN_CNT_SEL);
@@ -598,7 +606,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st, skip);
     if ((flags & DSN_STOP_STATS) && skip)
-        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), DSN_STOP_EPS, w.count + DSN_CNT_STOP + 2, st);
+        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), dsn_stop_eps(S), w.count + DSN_CNT_STOP + 2, st);
     return dsn_check_launch("dsn_render_rays");
 }
 

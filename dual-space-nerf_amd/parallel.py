@@ -43,11 +43,13 @@ class RayParallel:
     # With the transparent skip the cost of a ray depends on where it crosses the body, so contiguous blocks of one
     # frame are uneven (the rows through the torso cost several times the rows above the head).  Dealing small tiles
     # round-robin gives every rank the same mix; the exchange is still ONE all-gather of equal-sized slabs.
-    def tile_indices(self, R: int, tile: int = 3072, rank: int = None) -> torch.Tensor:
-        """ray indices (ascending) of the tiles owned by `rank` (default: this rank)."""
+    def tile_indices(self, R: int, tile: int = 3072, rank: int = None, world: int = None) -> torch.Tensor:
+        """ray indices (ascending) of the tiles owned by `rank` (default: this rank) in a group of `world` ranks (default: this
+        group's size; another value lets one process enumerate the shares of a larger job: bench.py --strong --emulate-world)."""
         rank = self.rank if rank is None else rank
+        world = self.world if world is None else int(world)
         ntiles = (R + tile - 1) // tile
-        mine = torch.arange(rank, ntiles, self.world)
+        mine = torch.arange(rank, ntiles, world)
         idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
         return idx[idx < R]
 
@@ -92,21 +94,25 @@ class RayParallel:
         rank = self.rank if rank is None else rank
         return list(range(rank, n_frames, self.world))
 
-    def render_frames(self, render_frame_fn, n_frames: int, pixels: int, channels: int = 6):
+    def render_frames(self, render_frame_fn, n_frames: int, pixels: int, channels: int = 6, device=None):
         """Every rank renders its frames of a sequence (render_frame_fn(f) -> [pixels, channels] device tensor, e.g. the packed
         rgb / disp / acc / depth image of Renderer.render_view(device_output=True)); after each round of `world` frames ONE
         all_gather_into_tensor brings that round's images to every rank - issued asynchronously, so the exchange of round k
-        overlaps the rendering of round k + 1.  Returns the list of n_frames images in sequence order on every rank."""
+        overlaps the rendering of round k + 1.  Returns the list of n_frames images in sequence order on every rank.
+        Fewer frames than ranks is fine: a rank without a frame in a round joins that round's collective with zeros (its
+        buffer lives on `device`, default: the current CUDA device, or the CPU when there is none) - every rank takes the same
+        path through the collectives whatever n_frames is, so no rank can raise while the others wait."""
+        if n_frames <= 0:
+            return []
         rounds = (n_frames + self.world - 1) // self.world
         outs, works = [], []
-        dev = None
+        dev = torch.device(device) if device is not None else None
         for r in range(rounds):
             f = r * self.world + self.rank
             img = render_frame_fn(f) if f < n_frames else None
             if dev is None:
-                if img is None:
-                    raise ValueError("render_frames: more ranks than frames")
-                dev = img.device
+                dev = img.device if img is not None else (
+                    torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
             if img is None:
                 img = torch.zeros(pixels, channels, dtype=torch.float32, device=dev)
             img = img.reshape(pixels, channels).contiguous()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 3
+#define DSN_ABI_VERSION 4
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -271,14 +271,18 @@ DSN_EXPORT int dsn_module_grad(const void* scene, int V, int F, const void* pack
 #define DSN_SCREEN_AUDIT 32
 /* Front-to-back evaluation with ray termination (eval mode: needs DSN_SKIP_TRANSPARENT, split-fp16 field).  raw2outputs
  * (utils/nerf_net_utils.py:24-39) weighs sample i with alpha_i * T_i, T_i = prod_{j<i}(1 - alpha_j + 1e-10) non-increasing
- * along the ray: once T < eps = 2^-20 every later sample weighs less than eps and all of them together add less than eps to
+ * along the ray: once T < eps (<= 2^-20) every later sample weighs less than eps and all of them together add less than eps to
  * acc_map (eps * colour to the pixel, eps * far to depth_map).  The frame is evaluated in slices of 8 samples along the rays
  * (S / 32 beyond 256 samples); after each slice T of every ray is advanced with the densities just computed, the next slice
  * leaves out the finished rays (their remaining samples keep density 0), and d sigma/dx, normals and lighting are computed only
- * for samples whose own weight is >= eps.  Outputs differ from the dense evaluation by less than 64 eps = 6.1e-5 x the largest
- * colour component (1e-6 typical); when no ray saturates, weights / acc / depth keep their bits and only the colour moves (< eps per unshaded sample).  int32 words 56 / 57 of
- * `workspace`: samples left out by termination / samples not shaded. */
+ * for samples whose own weight is >= eps.  Worst case against the dense evaluation: the S samples not shaded add up to S eps and
+ * the terminated tail to eps, i.e. (S + 1) eps x the largest colour component, so eps follows S (dsn_early_stop_eps):
+ * eps(S) = min(2^-20, 1e-4 / (2 (S + 1))) keeps the worst case at half of the 1e-4 bar for colours <= 1 at any S (1e-6 typical);
+ * when no ray saturates, weights / acc / depth keep their bits and only the colour moves (< eps per unshaded sample).
+ * int32 words 56 / 57 of `workspace`: samples left out by termination / samples not shaded. */
 #define DSN_EARLY_STOP 64
+/* the termination / shading threshold DSN_EARLY_STOP and DSN_STOP_STATS use for rays of S samples (host function, no device work) */
+DSN_EXPORT float dsn_early_stop_eps(int S);
 /* statistics for the caller's decision whether DSN_EARLY_STOP pays (a frame rendered WITHOUT it): word 58 of `workspace` =
  * non-transparent samples that lie in a slice whose ray had T < eps when the slice began (what DSN_EARLY_STOP would leave out;
  * compare with word 0, the non-transparent samples).  Slicing costs a few launches per slice, ~0.5 ms on a 512 x 512 x 64 frame. */

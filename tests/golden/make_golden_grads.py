@@ -104,18 +104,20 @@ def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, see
 def main():
     import torch
     torch.set_num_threads(8)
-    if "--other-weights" in sys.argv:            # the trained parameter set (make_weights_w2.py)
-        z = np.load(os.path.join(HERE, "weights_w2.npz"))
+    if "--other-weights" in sys.argv:            # the trained parameter sets: w2 (make_weights_w2.py, default) or `--other-weights w4`
+        rest = [a for a in sys.argv[sys.argv.index("--other-weights") + 1:] if not a.startswith("-")]
+        tag = rest[0] if rest else "w2"
+        z = np.load(os.path.join(HERE, f"weights_{tag}.npz"))
         state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
         poses = synth.make_poses()
         canon_s, faces_s = synth.make_small_body()
         xyz_s = synth.pose_body(canon_s)
         rays_s = synth.make_rays(8, 8, xyz_s, cam_dist=2.2, focal_frac=2.0)
-        case("small_train_grads_w2", canon_s, faces_s, xyz_s, poses, rays_s, np.arange(64), 16, state, raw_noise_std=1.0)
+        case("small_train_grads_" + tag, canon_s, faces_s, xyz_s, poses, rays_s, np.arange(64), 16, state, raw_noise_std=1.0)
         canon, faces = synth.make_body()
         xyz = synth.pose_body(canon)
         rays = synth.make_rays(32, 32, xyz, fit_box=True)
-        case("full_train_grads_w2", canon, faces, xyz, poses, rays, np.arange(0, 1024, 8), 64, state, raw_noise_std=1.0)
+        case("full_train_grads_" + tag, canon, faces, xyz, poses, rays, np.arange(0, 1024, 8), 64, state, raw_noise_std=1.0)
         return
     state = synth.make_state_dict()
     poses = synth.make_poses()

@@ -9,7 +9,10 @@ CASES = ["small_eval", "small_train", "small_novel", "small_rot", "full_eval"]
 # the same stage / end-to-end cases on two more parameter sets (tests/golden/make_golden.py --other-weights):
 #   _w2: TRAINED by the real reference (tests/golden/make_weights_w2.py; weights_w2.npz) - larger, non-uniform layer scales
 #   _w3: hash-generated with init gain 3.5 - |sigma| ~ 1e3, |d sigma/dx| ~ 2e5, activations ~ 1e2
-W_CASES = ["small_eval_w2", "small_train_w2", "full_eval_w2", "small_eval_w3", "small_train_w3", "full_eval_w3"]
+#   _w4: CONVERGED on the full-size synthetic body by this repo's HIP trainer on the MI355X (scripts/train_w4.py, 24 000 steps,
+#        held-out PSNR 26-27 dB; weights_w4.npz) - a bimodal field (sigma in [-316, 1013]: << 0 outside, >> 0 inside), acc 0 / 1
+W_CASES = ["small_eval_w2", "small_train_w2", "full_eval_w2", "small_eval_w3", "small_train_w3", "full_eval_w3",
+           "small_eval_w4", "small_train_w4", "full_eval_w4"]
 ALL_CASES = CASES + W_CASES
 
 
@@ -23,10 +26,10 @@ _STATE = {}
 def state(name=None):
     """the 33 parameters a golden case was generated with (by case name; default set when the name carries no tag)"""
     import dsnerf_amd.synth as synth
-    tag = "w2" if name and "_w2" in name else ("w3" if name and "_w3" in name else "")
+    tag = next((t for t in ("w2", "w3", "w4") if name and "_" + t in name), "")
     if tag not in _STATE:
-        if tag == "w2":
-            z = np.load(os.path.join(GOLDEN, "weights_w2.npz"))
+        if tag in ("w2", "w4"):
+            z = np.load(os.path.join(GOLDEN, f"weights_{tag}.npz"))
             _STATE[tag] = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
         elif tag == "w3":
             _STATE[tag] = synth.make_state_dict(seed=7, gain=3.5)

@@ -75,7 +75,7 @@ def test_render_matches_reference_and_oracle(name):
     assert np.array_equal(np.isnan(d), np.isnan(dg))
 
 
-@pytest.mark.parametrize("name", ["small_eval", "full_eval", "full_eval_w2", "full_eval_w3"])
+@pytest.mark.parametrize("name", ["small_eval", "full_eval", "full_eval_w2", "full_eval_w3", "full_eval_w4"])
 def test_skip_transparent_is_exact(name):
     g = load(name)
     r = make_renderer(g, name)

@@ -141,7 +141,7 @@ def test_camera_rays_h36m_restatement():
 
 
 @pytest.mark.parametrize("name", ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2",
-                                  "full_train_grads_w2"])
+                                  "full_train_grads_w2", "small_train_grads_w4", "full_train_grads_w4"])
 def test_train_oracle_reproduces_reference_autograd(name):
     """oracle/train_oracle.py (differentiable restatement, torch CPU) against the loss and the parameter gradients the
     reference's own loss.backward() produced (tests/golden/make_golden_grads.py)."""

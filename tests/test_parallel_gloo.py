@@ -152,7 +152,7 @@ def _frames_worker(rank, world, port, n_frames, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [5, 4, 2])
+@pytest.mark.parametrize("n_frames", [5, 4, 2, 1])      # (1: fewer frames than ranks - rank 1 joins with zeros, nobody raises)
 def test_frame_parallel_and_tile_undeal_world2(n_frames):
     """BASELINE configs[4] (a sequence dealt frame by frame over the ranks, one asynchronous all-gather per round) and the
     exchange of configs[3] (round-robin tiles of ONE frame: gather of equal slabs + un-dealing into ray order)"""
