@@ -58,8 +58,13 @@ def parse():
                     help="front-to-back slices with ray termination (DSN_EARLY_STOP): auto = like Renderer, from the statistics of one "
                          "probe frame at set-up (used when it would leave out >= 4 %% of the non-transparent samples)")
     ap.add_argument("--pipeline", type=int, default=2,
-                    help="frames in flight (each on its own HIP stream with its own scene / workspace): the per-frame setup, "
-                         "sampling and warp kernels of frame k+1 run beside the field kernels of frame k; 1 = strictly serial")
+                    help="frames in flight (own scene / workspace each); 1 = strictly serial.  How they overlap: --overlap")
+    ap.add_argument("--overlap", default="frame", choices=["phase", "frame"],
+                    help="frame (default): one HIP stream per frame in flight; phase: one stream for the field kernels and one for "
+                         "everything else (_lib.PhasePipeline: geometry of frame k+1 and shading of frame k-1 BESIDE the field kernels of "
+                         "frame k).  Measured equal within 1.5 %% (profiles/r03c_*): the GPU is busy 99.7 %% of the frame either way - the "
+                         "small kernels are work the chip has to do, not latency to hide; beside a persistent field workgroup they run "
+                         "5-10x longer and slow it by 8 %%")
     ap.add_argument("--train", action="store_true",
                     help="secondary mode (not the headline metric): BASELINE configs[2] training step, 8192 rays x 64 "
                          "samples, render + MSE loss + backward + Adam step through the Renderer mirror")
@@ -194,27 +199,47 @@ def main():
     args.no_screen = cur["no_screen"]
     k_step = 0
 
+    pipe = _lib.PhasePipeline(dev) if (args.overlap == "phase" and depth > 1) else None
+
+    def frame_call(j, phases=0):
+        outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
+                                   skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
+                                   screen=not cur["no_screen"], early_stop=cur["early"], phases=phases)
+
+    def exchange(j):
+        if use_dist:
+            packed_px[j][:, 0:3] = outs[j]["color"]
+            packed_px[j][:, 3] = outs[j]["disp_map"]
+            packed_px[j][:, 4] = outs[j]["acc_map"]
+            packed_px[j][:, 5] = outs[j]["depth_map"]
+            dist.all_gather_into_tensor(gathered[j], packed_px[j])
+
     def step():
-        # one whole frame on slot j's stream; consecutive frames use different slots, so the small geometry kernels of
-        # the next frame fill the gaps beside the LDS-bound field kernels of this one
+        # one whole frame in slot j.  overlap = frame: on slot j's stream (consecutive frames on different streams).  overlap =
+        # phase: set-up + geometry on the side stream, field kernels on the field stream, shading (+ the exchange) on the side
+        # stream one step later - the small kernels run BESIDE the persistent field workgroups instead of between them
         nonlocal k_step
         j = k_step % depth
         k_step += 1
-        with torch.cuda.stream(streams[j]):
+
+        def geometry():
             nears[j].copy_(near0)
             fars[j].copy_(far0)
             scenes[j].set_frame(cur["packed"], d_xyz, d_poses, 5, False, None, None, None, fine_only=True)   # what Renderer does per frame
-            outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
-                                       skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
-                                       screen=not cur["no_screen"], early_stop=cur["early"])
-            if use_dist:
-                packed_px[j][:, 0:3] = outs[j]["color"]
-                packed_px[j][:, 3] = outs[j]["disp_map"]
-                packed_px[j][:, 4] = outs[j]["acc_map"]
-                packed_px[j][:, 5] = outs[j]["depth_map"]
-                dist.all_gather_into_tensor(gathered[j], packed_px[j])
+            if pipe is not None:
+                frame_call(j, _lib.PHASE_GEOMETRY)
+
+        if pipe is not None:
+            pipe.submit(geometry, lambda: frame_call(j, _lib.PHASE_FIELD), lambda: (frame_call(j, _lib.PHASE_SHADE), exchange(j)))
+            return
+        with torch.cuda.stream(streams[j]):
+            geometry()
+            frame_call(j)
+            exchange(j)
 
     def barrier():
+        if pipe is not None:
+            pipe.flush()                 # (the shading of the last frame: every step's frame is complete inside the timed region)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -234,6 +259,8 @@ def main():
     t1 = time.perf_counter()
     for _ in range(3):
         step()
+        if pipe is not None:
+            pipe.flush()
         torch.cuda.synchronize()
     ms_serial = 1e3 * (time.perf_counter() - t1) / 3
     if use_dist:
@@ -273,7 +300,7 @@ def main():
             "accurate_pass_sample_fraction": None if n_kept is None else n_kept / float(R * S),
             "early_stop": stop_info,
             "ms_per_frame": ms_step,
-            "frames_in_flight": depth, "ms_per_frame_alone": ms_serial,
+            "frames_in_flight": depth, "overlap": ("none" if depth == 1 else args.overlap), "ms_per_frame_alone": ms_serial,
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
@@ -297,11 +324,11 @@ def main():
                 k_step = 0
                 for _ in range(2):
                     step()
-                torch.cuda.synchronize()
+                barrier()
                 tb = time.perf_counter()
                 for _ in range(5):
                     step()
-                torch.cuda.synchronize()
+                barrier()
                 by[name] = {"ms_per_frame": 1e3 * (time.perf_counter() - tb) / 5, "frames": 5}
             cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
             st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
@@ -350,6 +377,7 @@ def main():
         ex["host_to_host_ms_after_a_caller_torch_cpu_op"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
                                                                          caller_torch_op=True)
         ex["host_threads"] = torch.get_num_threads()
+        ex["host_cpu_quota_cores"] = _lib.cpu_quota_cores()
         # BASELINE configs[2] in the same line: 8192 x 64 training step (render + MSE + backward + Adam)
         t_dt, t_loss, t_ovf = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5)
         result["train"] = {"metric": "training rays/sec (8192 rays x 64 samples: forward + backward + Adam step, BASELINE configs[2])",
@@ -373,9 +401,11 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
     """The reference's render_view contract (can_render.py:248-278): a batch of HOST tensors in (what its DataLoader hands
     over), four HOST images out, one frame at a time through the Renderer mirror.  PCIe-inclusive: never `value`.
     The fresh per-frame near / far tensors (render_view updates them in place) are made with numpy, like the product of a DataLoader
-    worker process; caller_torch_op=True makes them with torch .clone() on the main thread instead - a 1 MB torch CPU op right before
-    the frame wakes torch's intra-op OpenMP pool, whose spinning threads then starve the thread that feeds the GPU
-    (scripts/h2h_caller_probe.py: 18.3 ms vs 25-33 ms per frame on the same renderer)."""
+    worker process; caller_torch_op=True runs the reference caller's own torch CPU ops on the main thread between the frames instead
+    (test.py:61-76: clamp, psnr, permute / flip on the previous frame's 512 x 512 host images, + 1 MB .clone()s).  In round 2 that
+    doubled the frame time (36 vs 19 ms): torch's intra-op pool, sized from the 128-256 hardware threads, burnt the cgroup's 16-core
+    CPU quota in busy-waits and the kernel froze the process for the rest of the 100 ms period (profiles/r03a_h2h_guard.json); Renderer
+    now fits the pool to the quota (_lib.fit_host_pool) and retires surplus threads while a frame is in flight (_HostPoolGuard)."""
     from types import SimpleNamespace
     cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
                           MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0, raw_noise_std=1.0,
@@ -390,9 +420,18 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
              "xyz": C(xyz)[None], "poses": C(poses)[None], "Th": torch.zeros(1, 1, 3), "frame": torch.tensor([5]),
              "img": torch.zeros(1, H, W, 3, dtype=torch.float64), "mask_at_box": torch.ones(1, H * W, dtype=torch.bool)}
     ms = []
-    for i in range(12):      # (the first frames of a new Renderer carry its one-off work: screen calibration, early-stop probe, staging buffers)
+    out = None
+    gt = torch.rand(H, W, 3, dtype=torch.float64)
+    for i in range(16):      # (the first frames of a new Renderer carry its one-off work: screen calibration, early-stop probe, staging buffers)
         b = dict(batch)
         if caller_torch_op:
+            # what test.py:61-76 does on the main thread between two render_view calls, on the previous frame's host images:
+            # torch.clamp, two psnr's (utils/metrics.py: mean of a squared difference, log10), the lpips-style permute / flip
+            if out is not None:
+                c = torch.clamp(out["coarse_color"], min=0.0, max=1.0)
+                v = (c - gt) ** 2
+                _ = float(-10 * torch.log10(torch.mean(v))) + float(-10 * torch.log10(torch.mean(v[batch["mask_at_box"][0].reshape(H, W)])))
+                _ = (2 * c - 1).permute(2, 0, 1)[None].float().flip(1).sum()
             b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
         else:
             b["near"], b["far"] = torch.from_numpy(batch["near"].numpy().copy()), torch.from_numpy(batch["far"].numpy().copy())
@@ -464,6 +503,8 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
             full[dev_idx[0]] = px[:Rl]
 
     def barrier():
+        if pipe is not None:
+            pipe.flush()                 # (the shading of the last frame: every step's frame is complete inside the timed region)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -932,7 +973,11 @@ def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):
     R = rays["ray_o"].shape[0]
     P = O.Params(sd)
     tv = torch.linspace(0.0, 1.0, steps=S).numpy()
-    cores = os.cpu_count() or 1
+    from dsnerf_amd import _lib
+    quota = _lib.cpu_quota_cores()
+    # threads = the cores this process is really granted: the boxes show 256 hardware threads under a cgroup quota of 16 cores, and
+    # 256 OpenMP threads on 16 cores' worth of bandwidth only add throttling and barrier waits
+    cores = O.set_threads(max(1, min(os.cpu_count() or 1, int(quota))) if quota else 0)
 
     def run(n):
         sel = np.linspace(0, R - 1, n).astype(np.int64)
@@ -944,9 +989,9 @@ def cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args):
     t_cal = run(max(cores, 64))                      # calibration (also warms the OpenMP pool)
     n = int(np.clip(args.cpu_rays if args.cpu_rays > 0 else 15.0 * max(cores, 64) / t_cal, 128, 65536))
     dt = run(n)
-    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} rays evenly spread over the same frame x {S} samples (dense evaluation, OpenMP over all "
-                      f"host cores), {dt:.1f} s"}
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "cpu_quota_cores": quota, "kind": "port",
+            "sample": f"{n} rays evenly spread over the same frame x {S} samples (dense evaluation, OpenMP with {cores} threads"
+                      + (f" under a cgroup CPU quota of {quota:g} cores" if quota else "") + f"), {dt:.1f} s"}
 
 
 def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
@@ -975,7 +1020,9 @@ def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
 
     hw = os.cpu_count() or 1
     best = None
-    for threads in sorted({min(hw, 32), min(hw, 128)}):
+    from dsnerf_amd import _lib
+    quota = _lib.cpu_quota_cores()
+    for threads in sorted({min(hw, 32), min(hw, 128)} | ({max(1, min(hw, int(quota)))} if quota else set())):
         torch.set_num_threads(threads)
         run()                                     # warm the pools
         dt = run()

@@ -48,6 +48,7 @@ SAMPLE_UNIFORM = 8
 NO_SCREEN = 16
 SCREEN_AUDIT = 32
 EARLY_STOP, STOP_STATS = 64, 128
+PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
 CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
 EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
 SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.05      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
@@ -83,6 +84,43 @@ def lib():
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed: {lib().dsn_last_error().decode()}")
+
+
+def cpu_quota_cores():
+    """CPU bandwidth this process may use, in cores, from the cgroup (v2 cpu.max / v1 cpu.cfs_quota_us); None = unlimited / unknown.
+    os.cpu_count() and the affinity mask do not see it: the GPU boxes show 256 hardware threads under a quota of 16 cores."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else q / float(per)
+    except Exception:
+        return None
+
+
+def fit_host_pool():
+    """Cap torch's intra-op pool at the cgroup's CPU quota (minus two cores for the thread that feeds the GPU and the HIP
+    runtime's helper threads).  torch sizes its OpenMP pool from the hardware thread count (128-256 on the GPU boxes) whatever the
+    quota (16 cores there): every torch CPU op of the CALLER (test.py:61-76 runs torch.clamp / psnr / .cpu() between frames) then
+    wakes a team that burns the whole 100 ms quota period in a few milliseconds of busy-waiting at the pool's dock, the kernel
+    freezes the container for the rest of the period, and a 19 ms frame takes 60-90 ms (scripts/h2h_guard_probe.py,
+    profiles/r03a_h2h_guard.json: nr_throttled counts them; mean 36 ms in BENCH_r02).  No quota, pool already small, or
+    DSN_HOST_POOL=keep: nothing happens.  Returns (threads before, threads now, quota)."""
+    before = torch.get_num_threads()
+    quota = cpu_quota_cores()
+    if quota is None or os.environ.get("DSN_HOST_POOL", "") == "keep":
+        return before, before, quota
+    want = max(1, int(quota) - 2)
+    if before > want:
+        torch.set_num_threads(want)
+    return before, torch.get_num_threads(), quota
 
 
 def require_gpu():
@@ -455,8 +493,10 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False):
+                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors.
+    phases: 0 = the whole frame; PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE = only those parts, on the current stream (the caller
+    orders the three calls of a frame with its own events and passes the same `out` / workspace to all of them: PhasePipeline).
     early_stop: DSN_EARLY_STOP (eval mode: front-to-back slices, rays end once their transmittance is below 2^-20).
     stop_stats: DSN_STOP_STATS (count what early stop would leave out; read ws word CNT_STOP + 2)."""
     R = ray_o.shape[0]
@@ -486,6 +526,7 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= EARLY_STOP
     if stop_stats:
         flags |= STOP_STATS
+    flags |= int(phases) & (PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE)
     buf = ws.get(R, S)
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT
@@ -504,6 +545,61 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                  _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
            "dsn_render_rays")
     return out
+
+
+class PhasePipeline:
+    """Frames in flight BY PHASE (round 3): two HIP streams, one for the matrix-bound field kernels (density screen, field forward /
+    reverse: 13 of a 512 x 512 x 64 frame's 17 ms, one persistent workgroup per compute unit) and one for everything else (per-frame
+    list build, sampler, nearest-face search, warp of frame k + 1; normals, lighting, compositing of frame k - 1), which is sized to
+    fit into the LDS and registers the field workgroups leave on every compute unit and runs BESIDE them.  With one stream per FRAME
+    (round 2) the two frames' phases lock into step - both do geometry, then their field kernels take turns - and 2.3 ms of geometry
+    per frame run with no field kernel beside them (profiles/r03b_overlap_two_frame_streams.txt).
+    MEASURED (profiles/r03c_overlap_phase.txt, r03c_ab_*.json): no gain on the default frame (16.50 vs 16.26-16.45 ms), 2 % on the
+    converged set (10.66 vs 10.90).  The GPU is busy 99.7 % of the frame in both schemes; beside a persistent field workgroup the small
+    kernels run 5-10x longer (k_light16 0.40 -> 3.4 ms) and slow the field kernels by 8 %: the geometry is work the chip has to do,
+    not latency to hide.  Kept as an option (bench.py --overlap phase) and as the test of the phase flags.
+
+    submit(geometry_fn, field_fn, shade_fn): geometry_fn() is enqueued on the side stream at once, field_fn() on the field stream
+    behind it, shade_fn() on the side stream behind field_fn - but one submit later, so that the side stream never waits for a
+    field phase with the next frame's geometry queued behind the wait.  flush() enqueues the pending shading; join() makes the
+    caller's current stream wait for everything.  The functions enqueue on torch's current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.field = torch.cuda.Stream(device=self.device)
+        self.pending = None
+
+    def submit(self, geometry_fn, field_fn, shade_fn):
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)                      # inputs produced on the caller's stream
+        with torch.cuda.stream(self.side):
+            geometry_fn()
+            e_g = torch.cuda.Event()
+            e_g.record()
+        with torch.cuda.stream(self.field):
+            self.field.wait_event(e_g)
+            field_fn()
+            e_f = torch.cuda.Event()
+            e_f.record()
+        prev, self.pending = self.pending, (shade_fn, e_f)
+        if prev is not None:
+            self._shade(prev)
+
+    def _shade(self, p):
+        shade_fn, e_f = p
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(e_f)
+            shade_fn()
+
+    def flush(self):
+        if self.pending is not None:
+            self._shade(self.pending)
+            self.pending = None
+
+    def join(self):
+        self.flush()
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
 def early_stop_eps(S: int) -> float:

@@ -176,8 +176,10 @@ class Renderer:
         self.early_stop = "auto"
         self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
         # render_view / render_views: torch's intra-op pool is capped at this many threads while a frame is staged, enqueued and
-        # awaited (_HostPoolGuard; None = leave the pool alone)
+        # awaited (_HostPoolGuard; None = leave the pool alone); and for good at the cgroup's CPU quota (_lib.fit_host_pool: a pool
+        # larger than the quota gets the whole process frozen by the kernel's bandwidth control whenever the caller runs a torch op)
         self.host_pool_limit = 8
+        self.host_pool = _lib.fit_host_pool()
 
     # ---- mode switches (reference :26-38) ----
     def train(self):
@@ -457,7 +459,9 @@ class Renderer:
         batch["face_idx"] = self.face_idx
         return {"coarse": out}
 
-    def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None):
+    def _eval_plan(self, noise, screen=None):
+        """per-frame decisions of an eval-mode frame (needs the scene's frame state for a first calibration): keyword arguments
+        of _lib.render_rays"""
         skip = self.skip_transparent and not self.net.training
         if skip and noise is None and self.early_stop == "auto":
             self._read_stop_probe()      # (first: whether the screen pays depends on it)
@@ -474,10 +478,14 @@ class Renderer:
                     stop = packed.early_stop["usable"]
             else:
                 stop = bool(self.early_stop)
-        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise,
-                               skip_transparent=skip, uniform=(self.sample_points_mode == "uniform"), screen=screen,
-                               audit=self.screen_audit, early_stop=stop, stop_stats=stats)
-        if stats:
+        return {"skip_transparent": skip, "uniform": (self.sample_points_mode == "uniform"), "screen": screen,
+                "audit": self.screen_audit, "early_stop": stop, "stop_stats": stats}
+
+    def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None, plan=None, phases=0, out=None):
+        plan = self._eval_plan(noise, screen) if plan is None else plan
+        packed = self.net.packed(self.device)
+        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out, **plan)
+        if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
             snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
             ev = torch.cuda.Event()
             ev.record()
@@ -638,8 +646,8 @@ class Renderer:
                 self._screen_usable()
             import itertools
             batches = itertools.chain([first], batches)
-        results = []
         keys = ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")
+        results = []
         for k, batch in enumerate(batches):
             slot = slots[k % n]
             slot.stream.wait_stream(cur)

@@ -489,13 +489,20 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     DsnWorkspace w = dsn_carve(workspace, R, S);
     const int64_t N = (int64_t)R * S;
     float* z = out_z ? out_z : w.z;
-    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+    // Phases (DSN_PHASE_*): none of the three bits = the whole frame on `stream`.  With bits set only those parts are enqueued, so
+    // that a caller with several frames in flight can put the geometry / shading kernels of one frame on a stream of their own
+    // BESIDE the matrix-bound field kernels of another (events between the calls are the caller's; the state that travels
+    // between the phases lives in `workspace`).  Same arguments in all three calls.
+    const int ph = flags & (DSN_PHASE_GEOMETRY | DSN_PHASE_FIELD | DSN_PHASE_SHADE);
+    const bool do_geom = !ph || (ph & DSN_PHASE_GEOMETRY), do_field = !ph || (ph & DSN_PHASE_FIELD), do_shade = !ph || (ph & DSN_PHASE_SHADE);
     int32_t* list = skip ? w.active : nullptr;
     int32_t* cnt = skip ? w.count : nullptr;
+    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
+    if (do_geom) {
+    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     if (skip) {
         if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
-    const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     const int32_t* nn_pre = nullptr;
     const char* cm_env = getenv("DSN_CELLMAJOR_MIN");      // test / tuning override
     const long long cellmajor_min = cm_env ? atoll(cm_env) : (long long)DSN_CELLMAJOR_MIN;
@@ -503,7 +510,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         // cell-major search: samples counting-sorted by fine cell, lists through the scalar cache (dsn_nn.hip).
         // Scratch: buffers that are not written before the field's reverse pass / the normal and lighting kernels -
         // cell ids and the result in the gradient buffer (2 N ints of 3 N), the sorted (point, id) records in n_w | colour
-        // (16 N bytes of 24 N; colour is cleared below, after the search).
+        // (16 N bytes of 24 N; a colour is read only where the density is positive: no clearing).
         int32_t* g3 = (int32_t*)w.grad;
         dsn_launch_nn_cellmajor(s.nn_world, nullptr, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, g3 + N, w.nn_small, st);
         nn_pre = g3 + N;
@@ -516,6 +523,8 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         if (hipMemsetAsync(w.sigma, 0, sizeof(float) * N, st) != hipSuccess)
             return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
+    }       // geometry phase
+    if (do_field) {
     if (flags & DSN_FIELD_FP32)
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     else if (skip && (flags & DSN_EARLY_STOP)) {
@@ -598,6 +607,13 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
         dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     }
+    }       // field phase
+    // the list the shading kernels walk (what the field phase leaves; recomputed here so that a DSN_PHASE_SHADE call finds it)
+    if (!(flags & DSN_FIELD_FP32) && skip) {
+        if (flags & DSN_EARLY_STOP) { list = w.slices; cnt = w.count + DSN_CNT_LIT; }
+        else { list = w.pos; cnt = w.count + DSN_CNT_POS; }
+    }
+    if (do_shade) {
     dsn_launch_normal(s, w.x_c, w.grad, N, list, cnt, nullptr, w.n_w, exh, st);
     if (flags & DSN_FIELD_FP32)
         dsn_launch_light((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
@@ -607,6 +623,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
                          out_weights, out_depth, st, skip);
     if ((flags & DSN_STOP_STATS) && skip)
         dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), dsn_stop_eps(S), w.count + DSN_CNT_STOP + 2, st);
+    }       // shading phase
     return dsn_check_launch("dsn_render_rays");
 }
 

@@ -287,6 +287,18 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
  * non-transparent samples that lie in a slice whose ray had T < eps when the slice began (what DSN_EARLY_STOP would leave out;
  * compare with word 0, the non-transparent samples).  Slicing costs a few launches per slice, ~0.5 ms on a 512 x 512 x 64 frame. */
 #define DSN_STOP_STATS 128
+/* Phases of the fused path.  None of the three bits: the whole frame (all of the above) on `stream`.  With bits set
+ * dsn_render_rays enqueues only those parts - DSN_PHASE_GEOMETRY: sampler, cell-major nearest-face search, warp, clears
+ * (utils/pts_utils.py:18-58, can_render.py:333-379); DSN_PHASE_FIELD: density screen, canonical field forward / reverse, range
+ * fallback, front-to-back slices (model/spacenet.py:93-148,301-311); DSN_PHASE_SHADE: normals, lighting MLP, compositing
+ * (model/spacenet.py:278-298,174-188, utils/nerf_net_utils.py:5-56).  A caller with several frames in flight puts geometry and
+ * shading of one frame on a stream of their own beside the matrix-bound field kernels of another (the field kernels occupy every
+ * compute unit with one persistent workgroup; the geometry kernels are sized to fit into the LDS and registers they leave), with its
+ * own events between the three calls; everything that travels between the phases lives in `workspace`.  Same arguments in all
+ * three calls; dsn_set_frame belongs in front of the geometry phase, on its stream. */
+#define DSN_PHASE_GEOMETRY 256
+#define DSN_PHASE_FIELD 512
+#define DSN_PHASE_SHADE 1024
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,

@@ -20,6 +20,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -55,6 +58,18 @@ static inline void cross3(const float* a, const float* b, float* o) {
  * (ATen RangeFactories, scalar path); used by utils/pts_utils.py:4.  The vectorised ATen path differs
  * from this in the last bit depending on the host's SIMD width, so callers that need bit parity with a
  * particular torch build pass torch.linspace's own output as t_vals (orc_sample_gg). */
+/* thread count of the OpenMP loops below (bench.py's cpu_baseline: the host cores the cgroup really grants, not the hardware
+ * thread count); returns the count in effect */
+ORC_API int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 ORC_API void orc_linspace01(int S, float* t) {
     if (S == 1) { t[0] = 0.f; return; }
     float step = 1.0f / (float)(S - 1);

@@ -46,6 +46,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's loops (0 = leave); returns the count in effect"""
+    return int(lib().orc_set_threads(C.c_int(int(n))))
+
+
 def _f(a):
     return None if a is None else np.ascontiguousarray(a, np.float32)
 

@@ -16,7 +16,7 @@ import torch
 
 import oracle as O
 import train_oracle as TO
-from helpers import GOLDEN, code_for, load, maxdiff, state
+from helpers import GOLDEN, code_for, load, maxdiff, ref_tol, state
 from test_gpu_render import make_batch, make_cfg, make_renderer
 
 pytestmark = pytest.mark.gpu
@@ -193,6 +193,25 @@ def test_screen_calibration_bounds_the_frame(wname):
     r._set_frame(batch)
     packed = r.net.packed(r.device)
     info = packed.calibrate_screen(r.scene)
+    if wname == "_w4":
+        # The CONVERGED set defeats the plain-fp16 trunk: sigma in [-316, 1013] comes out of large cancelling terms and the fp16
+        # evaluation is off by 4-5 % of their magnitude (cap 0.5 %) - the calibration says so, the margin is +inf, Renderer leaves the
+        # screen out (every non-transparent sample takes the accurate pass), and forcing it on still drops nothing.
+        assert not info["safe"] and not info["usable"] and info["margin"] == float("inf") and info["deviation"] > 0.005, info
+        assert not r._screen_usable()
+        S = 64
+        o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+        outs = []
+        for screen in (True, False):
+            n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+            ws = _lib.RenderWorkspace(r.device)
+            outs.append(_lib.render_rays(r.scene, packed, ws, o, d, n2, f2, S, r._t_vals(S), screen=screen))
+            if screen:
+                cnt = ws.buf[:256].view(torch.int32).cpu()
+                assert int(cnt[_lib.CNT_KEEP]) == int(cnt[_lib.CNT_ACTIVE])          # margin +inf: nothing is declared empty
+        for k in ("color", "acc_map", "depth_map", "weights"):
+            assert torch.equal(outs[0][k], outs[1][k]), k
+        return
     assert info["safe"] and 0.002 <= info["margin"] <= 0.05 and info["overflow_fraction"] < 0.5, info
     # the screen pays only where it drops a good share of the samples: the default set yes, the trained set (dense near the
     # surface: every calibration point has sigma > 0) no - Renderer leaves it off there
@@ -366,7 +385,7 @@ def test_spacenet_forward_honours_pose_feats_and_idx(name):
     idx = torch.full((N // S, S), int(g["frame"]))
     rgbs, den, zero = nerf(x, None, idx, False, pf)
     assert zero == 0 and rgbs.shape == (N, 3) and den.shape == (N, 1)
-    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < 1e-4 and maxdiff(rgbs.cpu().numpy(), g["essence"]) < 1e-4
+    assert maxdiff(den.cpu().numpy()[:, 0], g["sigma"]) < ref_tol(g, "sigma", 1e-4) and maxdiff(rgbs.cpu().numpy(), g["essence"]) < 1e-4
     rgbs3, den3, _ = nerf(x.reshape(N // S, S, 3), None, idx, False, pf)                # bins mode (:109-112)
     assert torch.equal(den3, den) and torch.equal(rgbs3, rgbs)
     assert torch.equal(nerf(x, None, idx, True, pf), den)
@@ -380,7 +399,7 @@ def test_spacenet_forward_honours_pose_feats_and_idx(name):
     P = O.Params(sd)
     code = sd["nerf.embedding.weight"][17] * (0 if name == "small_novel" else 1)
     osig, _, _ = O.field(g["x_c"][N // 2:], P, code, g["pose_feat"][0] * 0.5, want_grad=False)
-    assert maxdiff(den2[N // 2:, 0].cpu().numpy(), osig) < 1e-4
+    assert maxdiff(den2[N // 2:, 0].cpu().numpy(), osig) < max(1e-4, 4e-6 * float(np.abs(osig).max()))      # (helpers.ref_tol's rule)
     with pytest.raises(RuntimeError, match="pose_feats"):
         nerf(x, None, idx, False, None)
 
@@ -442,7 +461,8 @@ def test_module_forward_is_differentiable(name):
     assert none is None and col.requires_grad and den.requires_grad
     dc = np.abs(col.detach().cpu().numpy() - out["colour"].detach().numpy()).max(-1)     # through normalize(d sigma/dx): per point
     assert np.median(dc) < 2e-6 and np.mean(dc > 1e-4) < 5e-3, (np.median(dc), np.mean(dc > 1e-4))
-    assert maxdiff(den.detach().cpu().numpy()[:, 0], out["sigma"].detach().numpy()) < 1e-4
+    osg = out["sigma"].detach().numpy()
+    assert maxdiff(den.detach().cpu().numpy()[:, 0], osg) < max(1e-4, 4e-6 * float(np.abs(osg).max()))      # (helpers.ref_tol's rule: w4 |sigma| ~ 1e3)
     r.net.zero_grad()
     ((T(gc) * col).sum() + (T(gs) * den).sum()).backward()
     for k, p in r.net.named_parameters():

@@ -1,0 +1,178 @@
+"""Round-3 GPU tests: the host path under the reference caller's own torch CPU ops, the converged parameter set (w4) on the
+bench frame, the strong-scaling tile deal.  All through the C ABI (ctypes), as everywhere."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import state
+from test_gpu_round2 import full_frame, renderer_with
+
+pytestmark = pytest.mark.gpu
+
+
+def _test_py_caller_ops(out, gt, mask):
+    """test.py:61-76 on the previous frame's host images: clamp, psnr with / without mask_at_box (utils/metrics.py), the
+    lpips-style permute / flip - all torch CPU ops on the main thread"""
+    c = torch.clamp(out["coarse_color"], min=0.0, max=1.0)
+    v = (c - gt) ** 2
+    a = -10 * torch.log10(torch.mean(v[mask]))
+    b = -10 * torch.log10(torch.mean(v))
+    pred = (2 * c - 1).permute(2, 0, 1)[None].float().flip(1)
+    return float(a) + float(b) + float(pred.sum())
+
+
+def test_render_view_between_the_callers_torch_cpu_ops():
+    """test.py runs torch CPU ops on 512 x 512 host images between render_view calls.  Whatever the caller does
+    between the frames, (1) the frames are bit-identical, (2) the caller's thread setting survives a frame (the guard restores
+    it; the one-off fit to the cgroup quota happens at construction), (3) render_view costs about what it costs alone: the
+    median is compared (a throttled frame takes 60-90 ms and used to hit one frame in three, profiles/r03a_h2h_guard.json)."""
+    from dsnerf_amd import _lib
+    H = 512
+    canon, faces, batch = full_frame(hw=H)
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    quota = _lib.cpu_quota_cores()
+    before, now, q = r.host_pool
+    assert q == quota and (quota is None or now <= max(1, int(quota) - 2) or now == before <= max(1, int(quota) - 2))
+    threads = torch.get_num_threads()
+    gt = torch.rand(H, H, 3, dtype=torch.float64)
+    mask = batch["mask_at_box"][0].reshape(H, H)
+
+    def fresh():
+        b = dict(batch)
+        b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        return b
+
+    for _ in range(4):                        # one-off work of a new Renderer: calibration, early-stop probe, staging buffers
+        ref = r.render_view(fresh())
+    plain, busy = [], []
+    for i in range(10):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = r.render_view(fresh())
+        plain.append(time.perf_counter() - t)
+    out = ref
+    for i in range(10):
+        _test_py_caller_ops(out, gt, mask)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = r.render_view(fresh())
+        busy.append(time.perf_counter() - t)
+        assert torch.get_num_threads() == threads
+        for k in ref:
+            assert torch.equal(torch.nan_to_num(out[k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0)), k
+    assert np.median(busy) <= 1.25 * np.median(plain) + 1e-3, (np.median(plain), np.median(busy), sorted(busy))
+
+
+def test_converged_checkpoint_on_the_bench_frame():
+    """w4 (trained to convergence by the HIP trainer, pinned by reference-generated goldens) on a 256 x 256 frame of the bench
+    camera: the field is bimodal (most rays are either empty or opaque), termination pays, and the sliced frame stays within its
+    bound of the one-pass frame; screen on / off is bit-identical"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=256)
+    r = renderer_with(state("x_w4"), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    info = r.net.packed(r.device).calibrate_screen(r.scene)
+    assert not info["safe"] and not r._screen_usable(), info          # the trained field defeats plain fp16: the screen stays out (margin +inf)
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+
+    def run(**kw):
+        n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        ws = _lib.RenderWorkspace(r.device)
+        out = _lib.render_rays(r.scene, r.net.packed(r.device), ws, o, d, n, f, S, r._t_vals(S), **kw)
+        torch.cuda.synchronize()
+        return out, _lib.read_stop_stats(ws)
+
+    ref, st0 = run(screen=False, stop_stats=True)
+    scr, _ = run(screen=True)                                         # forced on with its +inf margin: drops nothing
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(ref[k], scr[k]), k
+    acc = ref["acc_map"]
+    assert float(((acc < 0.02) | (acc > 0.98)).float().mean()) > 0.9          # bimodal: a trained solid, not a fog
+    assert float((acc > 0.98).float().mean()) > 0.15
+    assert st0["would_skip"] > 0.3 * st0["active"], st0
+    got, st1 = run(screen=False, early_stop=True)
+    assert st1["skipped"] > 0.3 * st1["active"]
+    eps = _lib.early_stop_eps(S)
+    cmax = max(1.0, float(ref["color"].abs().max()))
+    assert float((ref["color"] - got["color"]).abs().max()) <= (S + 1) * eps * cmax + 2e-6 * cmax
+    assert float((ref["acc_map"] - got["acc_map"]).abs().max()) <= 2 * eps
+    assert float((ref["weights"] - got["weights"]).abs().max()) <= eps
+
+
+def test_tile_deal_reassembles_the_frame_bit_for_bit():
+    """bench.py --strong [--emulate-world N]: the N round-robin tile shares of ONE frame, rendered one after the other with the
+    whole-frame kernels and un-dealt into frame order, equal the frame rendered in one piece - every ray's pixel is independent of
+    which other rays share its launch (the geometry-guided sampler takes the batch's first ray origin: one camera, one origin)"""
+    import dsnerf_amd
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=192)
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    r._screen_usable()
+    S = 64
+    R = 192 * 192
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    n0, f0 = r._dev(batch["near"][0]), r._dev(batch["far"][0])
+    pk = r.net.packed(r.device)
+
+    def render(idx):
+        ws = _lib.RenderWorkspace(r.device)
+        out = _lib.render_rays(r.scene, pk, ws, o[idx].contiguous(), d[idx].contiguous(), n0[idx].clone(), f0[idx].clone(), S,
+                               r._t_vals(S), want_weights=False)
+        return torch.cat([out["color"], out["disp_map"][:, None], out["acc_map"][:, None], out["depth_map"][:, None]], 1)
+
+    whole = render(torch.arange(R, device=r.device))
+    rp = dsnerf_amd.RayParallel()
+    Nw, tile = 8, 1024
+    slab = max(rp.tile_indices(R, tile, k, Nw).numel() for k in range(Nw))
+    allp = torch.zeros(Nw * slab, 6, device=r.device)
+    seen = torch.zeros(R, dtype=torch.int32)
+    for k in range(Nw):
+        idx = rp.tile_indices(R, tile, k, Nw)
+        seen[idx] += 1
+        allp[k * slab: k * slab + idx.numel()] = render(idx.to(r.device))
+    assert bool((seen == 1).all())                                     # a partition: every ray on exactly one rank
+    full = torch.empty(R, 6, device=r.device)
+    for k in range(Nw):                                                # RayParallel.undeal_tiles for an emulated world
+        idx = rp.tile_indices(R, tile, k, Nw).to(r.device)
+        full[idx] = allp[k * slab: k * slab + idx.numel()]
+    assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(whole, nan=-1.0))
+
+
+@pytest.mark.parametrize("mode", ["plain", "no_screen", "early_stop", "fp32", "dense"])
+def test_phase_calls_equal_the_whole_frame(mode):
+    """dsn_render_rays with DSN_PHASE_GEOMETRY, then _FIELD, then _SHADE (three calls, here on one stream) == one call without phase
+    bits, bit for bit, in every mode of the fused path - what lets a caller put the phases on different streams"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=128)
+    r = renderer_with(state("x_w3") if mode == "early_stop" else state(), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    r._screen_usable()
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    kw = {"plain": {}, "no_screen": {"screen": False}, "early_stop": {"early_stop": True}, "fp32": {"fp32": True},
+          "dense": {"skip_transparent": False}}[mode]
+    pk = r.net.packed(r.device)
+
+    def run(split):
+        n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+        ws = _lib.RenderWorkspace(r.device)
+        if not split:
+            return _lib.render_rays(r.scene, pk, ws, o, d, n, f, S, r._t_vals(S), **kw), n
+        out = None
+        for ph in (_lib.PHASE_GEOMETRY, _lib.PHASE_FIELD, _lib.PHASE_SHADE):
+            out = _lib.render_rays(r.scene, pk, ws, o, d, n, f, S, r._t_vals(S), phases=ph, out=out, **kw)
+        return out, n
+
+    (a, na), (b, nb) = run(False), run(True)
+    assert torch.equal(na, nb)
+    for k in a:
+        assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
+    assert float(a["acc_map"].max()) > 0.05
