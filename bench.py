@@ -379,10 +379,17 @@ def main():
         ex["host_threads"] = torch.get_num_threads()
         ex["host_cpu_quota_cores"] = _lib.cpu_quota_cores()
         # BASELINE configs[2] in the same line: 8192 x 64 training step (render + MSE + backward + Adam)
-        t_dt, t_loss, t_ovf = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5)
+        t_dt, t_loss, t_ovf, t_rows = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5)
+        if os.path.exists(os.path.join(ROOT, "tests", "golden", "weights_w4.npz")):
+            # the same step from the CONVERGED parameters (late in training the field is bimodal: most rows have alpha = 0 exactly and
+            # drop out of the backward; from the hash-random start nearly every evaluated row carries a gradient)
+            w_dt, w_loss, w_ovf, w_rows = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5, weights="w4")
+            result["train_w4"] = {"train_ms_per_step": 1e3 * w_dt / 20, "value": args.train_rays * 20 / w_dt, "unit": "rays/s",
+                                  "rows_last_step": w_rows, "final_loss": w_loss, "range_overflow_samples_last_step": w_ovf,
+                                  "roofline": train_roofline(1e3 * w_dt / 20, args.train_rays, S)}
         result["train"] = {"metric": "training rays/sec (8192 rays x 64 samples: forward + backward + Adam step, BASELINE configs[2])",
                            "value": args.train_rays * 20 / t_dt, "unit": "rays/s", "train_ms_per_step": 1e3 * t_dt / 20, "steps": 20,
-                           "warmup": 5, "dtype": TRAIN_DTYPE, "final_loss": t_loss, "range_overflow_samples_last_step": t_ovf,
+                           "warmup": 5, "dtype": TRAIN_DTYPE, "final_loss": t_loss, "range_overflow_samples_last_step": t_ovf, "rows_last_step": t_rows,
                            "roofline": train_roofline(1e3 * t_dt / 20, args.train_rays, S)}
         if not args.no_cpu_baseline:
             result["eager_gpu_baseline"] = eager_baseline(args, _lib, synth, dev, chunks=3, train=False)
@@ -649,7 +656,7 @@ TRAIN_DTYPE = ("split-f16x3 (k_field16<train>, k_tangent16, k_adjoint16, k_t_wgr
                "accumulate) + exact-f32 MFMA for the small lighting / colour-head products (k_t_lin, k_t_wgrad)")
 
 
-def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, warmup):
+def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, warmup, weights=None):
     """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
     backward (dsn_render_rays_grad), Adam step.  With N>1 every rank renders its own 8192-ray batch of the step and
     the 33 gradients are averaged with ONE 2 MB RCCL all-reduce (parallel.RayParallel.average_gradients) before the
@@ -659,7 +666,7 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
     import torch.distributed as dist
     S, R = args.samples, args.train_rays
     canon, faces = synth.make_body()
-    sd = synth.make_state_dict()
+    sd = load_weights(synth, weights or args.weights)
     xyz = synth.pose_body(canon, seed=3 + rank)
     rays = synth.make_rays(args.hw, args.hw, xyz, fit_box=True)
     sel = np.linspace(0, args.hw * args.hw - 1, R).astype(np.int64)
@@ -707,7 +714,9 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    return dt, float(loss), int(r.range_overflow_count())
+    from dsnerf_amd import _lib
+    rows = _lib.grad_row_counts(r._grad_ws, R, S)
+    return dt, float(loss), int(r.range_overflow_count()), {"samples": R * S, "forward_rows": rows[0], "backward_rows": rows[1]}
 
 
 def train_roofline(ms, R, S):
@@ -724,7 +733,7 @@ def train_roofline(ms, R, S):
 def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
     import torch.distributed as dist
     S, R = args.samples, args.train_rays
-    dt, final_loss, ovf = train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, args.steps, args.warmup)
+    dt, final_loss, ovf, rows = train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, args.steps, args.warmup)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -737,7 +746,9 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic",
             "config": {"workload": f"training step on {R} rays x {S} samples per GPU (BASELINE configs[2]), dense evaluation "
                                    f"(jitter + noise), synthetic body V=6890/F=13776", "final_loss": final_loss,
-                       "range_overflow_samples_last_step": ovf},
+                       "range_overflow_samples_last_step": ovf, "rows_last_step": rows,
+                       "rows_note": "the forward skips transparent samples with noise <= 0 (alpha = 0 exactly), the backward every row "
+                                    "whose cotangents are all zero; the roofline counts the DENSE algorithmic work of the batch"},
             "roofline": train_roofline(ms, R, S)}), flush=True)
 
 

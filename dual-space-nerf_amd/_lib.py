@@ -644,6 +644,16 @@ def grad_range_word(ws: "GradWorkspace", R, S):
     return ws.buf[off:off + 4].view(torch.int32)
 
 
+def grad_row_counts(ws: "GradWorkspace", R, S):
+    """(synchronises) (rows the last training forward evaluated, rows its backward propagated) of R x S samples: the forward skips
+    transparent samples whose noise is <= 0 (alpha = 0 exactly), the backward every row whose cotangents are all zero (dsn_train.hip,
+    Rows) - two int32 words in the 256 bytes in front of the workspace's last 4 KB"""
+    need = lib().dsn_grad_workspace_bytes(int(R), int(S))
+    off = need - 4096 - 256
+    c = ws.buf[off:off + 8].view(torch.int32).cpu()
+    return int(c[0]), int(c[1])
+
+
 def grad_range_overflow(ws: "GradWorkspace", R, S) -> int:
     """(synchronises) the counter's value after the last dsn_render_rays_grad on this workspace"""
     return int(grad_range_word(ws, R, S).item())

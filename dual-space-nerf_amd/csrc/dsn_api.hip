@@ -646,16 +646,23 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
+    // Rows the step evaluates: a transparent sample has its density forced to 0 (can_render.py:115-120), so with noise <= 0 its
+    // alpha is exactly 0 (utils/nerf_net_utils.py:30-36: relu(0 + noise) = 0): neither its colour nor its density reaches an
+    // output or receives a gradient.  Everything else - transparent samples with positive noise included, their colour is
+    // weighted - goes through the networks.  (~30 % of a batch is skipped with raw_noise_std > 0, every transparent sample without.)
+    dsn_train_forward_rows(c.transparent, noise, N, c.live, c.bcnt, c.list1, c.rowcnt, st);
     // (train mode has no exact-fp32 twin of the stored activations: samples outside the fp16 range are counted in count[48],
     //  which the host mirror checks - Renderer.range_overflow_count())
     if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays_train: memset failed");
+    // (skipped rows keep whatever their density slot held: the compositor masks transparent samples itself)
     dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st,
-                             w.count + DSN_CNT_RANGE);
-    dsn_launch_normal(s, c.x_c, c.grad, N, nullptr, nullptr, c.idx_c, c.n_w, exh, st);
-    dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, nullptr, nullptr, w.colour, st,
+                             w.count + DSN_CNT_RANGE, c.list1, c.rowcnt);
+    dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st);
+    dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, c.list1, c.rowcnt, w.colour, st,
                        c.hl1, c.hl2, c.pre);
+    // (a colour is read only where relu(density + noise) > 0: skipped rows never are)
     dsn_launch_composite(w.colour, c.sigma, c.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc, out_weights,
-                         out_depth, st);
+                         out_depth, st, true);
     return dsn_check_launch("dsn_render_rays_train");
 }
 

@@ -874,12 +874,13 @@ void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st,
-                              int32_t* range_count) {
+                              int32_t* range_count, const int32_t* row_list, const int32_t* row_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     // range_count (optional): incremented once per sample whose activations / adjoints left the fp16 range
+    // row_list / row_count (optional): only the listed samples are evaluated (their rows are written, the others left alone)
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
+                       row_list, row_count, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
                        range_count, tr_h, tr_a, tr_rr, (int64_t)0, N, (const int32_t*)nullptr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
@@ -958,7 +959,10 @@ __device__ __forceinline__ void zero_train_rows(float* t, int64_t ls, int layers
 
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, const float* __restrict__ u, int64_t N,
-            const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count) {
+            const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count,
+            const int32_t* __restrict__ row_list, const int32_t* __restrict__ row_count) {
+    // row_list / row_count (optional): the pass runs on the listed samples only (rows whose cotangents are all zero add nothing to
+    // any gradient: dsn_train.hip, Rows); arrays stay indexed by sample, N is still the layer stride
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
@@ -966,9 +970,12 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
+    const int64_t NL = row_count ? (int64_t)(*row_count) : N;
+    if ((int64_t)blockIdx.x * 128 >= NL) return;      // block-uniform
     int64_t pt = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
-    const bool valid = pt < N;
-    if (!valid) pt = N - 1;
+    const bool valid = pt < NL;
+    if (!valid) pt = NL - 1;
+    if (row_list) pt = (int64_t)row_list[pt];
     const float xa[3] = {x_c[3 * pt], x_c[3 * pt + 1], x_c[3 * pt + 2]};
     float ua[3] = {u[3 * pt], u[3 * pt + 1], u[3 * pt + 2]};
     // Per-sample scale.  The sample runs on u * 2^-6 / max|u|: the 2^-6 leaves the tangent of every hidden unit 64 x 65 000 of
@@ -1066,11 +1073,11 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
 }
 
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          float* gmax, hipStream_t st, int32_t* range_count) {
+                          float* gmax, hipStream_t st, int32_t* range_count, const int32_t* row_list, const int32_t* row_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t,
-                       (uint32_t*)gmax, range_count);
+                       (uint32_t*)gmax, range_count, row_list, row_count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1081,16 +1088,20 @@ void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict__ masks, const float* __restrict__ a_in,
-            float* __restrict__ tr_a, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count) {
+            float* __restrict__ tr_a, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count,
+            const int32_t* __restrict__ row_list, const int32_t* __restrict__ row_count) {
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
+    const int64_t NL = row_count ? (int64_t)(*row_count) : N;
+    if ((int64_t)blockIdx.x * 128 >= NL) return;      // block-uniform
     int64_t pt = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
-    const bool valid = pt < N;
-    if (!valid) pt = N - 1;
+    const bool valid = pt < NL;
+    if (!valid) pt = NL - 1;
+    if (row_list) pt = (int64_t)row_list[pt];
     {
         const uint4* mrec = masks + ((size_t)pt * 2 + half) * 7;
 #pragma unroll
@@ -1169,11 +1180,11 @@ k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict
 }
 
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
-                          hipStream_t st, int32_t* range_count) {
+                          hipStream_t st, int32_t* range_count, const int32_t* row_list, const int32_t* row_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_adjoint16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, N, (const uint4*)masks, a_in, tr_a,
-                       (uint32_t*)gmax, range_count);
+                       (uint32_t*)gmax, range_count, row_list, row_count);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -91,15 +91,21 @@ size_t dsn_train_workspace_size(int64_t N);
 struct DsnTrainCache {
     uint8_t* transparent; int32_t* idx_c; float *x_c, *sigma, *essence, *grad, *n_w, *h0, *a0, *rr; void* masks;
     float *hl1, *hl2, *pre;        // lighting MLP: hidden layers after ReLU [N,128] and the output pre-activation [N]
+    uint8_t* live; int32_t *list1, *bcnt, *rowcnt;      // rows the forward evaluates: flags, ascending list, build scratch, [0] = their number
 };
+// rows the training forward has to evaluate: all but transparent samples whose noise is <= 0 (alpha = 0 exactly) -> list, *count
+void dsn_train_forward_rows(const uint8_t* transparent, const float* noise, int64_t N, uint8_t* flag, int32_t* bcnt, int32_t* list,
+                            int32_t* count, hipStream_t st);
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N);
 void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, float* sigma,
                               float* essence, float* grad, float* tr_h, float* tr_a, float* tr_rr, void* masks, hipStream_t st,
-                              int32_t* range_count = nullptr);
+                              int32_t* range_count = nullptr, const int32_t* row_list = nullptr, const int32_t* row_count = nullptr);
 void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, const float* a_in, float* tr_a, float* gmax,
-                          hipStream_t st, int32_t* range_count = nullptr);
+                          hipStream_t st, int32_t* range_count = nullptr, const int32_t* row_list = nullptr,
+                          const int32_t* row_count = nullptr);
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          float* gmax, hipStream_t st, int32_t* range_count = nullptr);
+                          float* gmax, hipStream_t st, int32_t* range_count = nullptr, const int32_t* row_list = nullptr,
+                          const int32_t* row_count = nullptr);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,

@@ -52,12 +52,93 @@ const int kTrunkLd[7] = {87, 256, 256, 256, 319, 256, 256};
 #define T_THREADS 256
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + T_THREADS - 1) / T_THREADS)); }
 
+// Row subsets (round 3).  A sample whose cotangents are all zero contributes exactly nothing to any parameter gradient (every pass
+// below is linear in them), and a sample whose alpha is exactly 0 - transparent with noise <= 0, or relu(sigma + noise) = 0 - has
+// zero cotangents (utils/nerf_net_utils.py:24-39: w = alpha T; d alpha / d sigma carries relu'), so the passes run on the LISTED rows
+// only: `list` = ascending sample indices (NULL: all rows), `cnt` = their number on the device (NULL: N).  Arrays stay indexed by
+// sample; rows that are not listed are never read or written.  Launches are sized for N, kernels stop at the device count.
+struct Rows { const int32_t* list; const int32_t* cnt; };
+__device__ __forceinline__ int64_t rows_n(const Rows& r, int64_t N) { return r.cnt ? (int64_t)(*r.cnt) : N; }
+__device__ __forceinline__ int64_t rows_at(const Rows& r, int64_t k) { return r.list ? (int64_t)r.list[k] : k; }
+// rows a workgroup of a row-chunked kernel takes: an even share of the listed rows, in multiples of `mult`, at least `least`
+__device__ __forceinline__ int64_t rows_share(int64_t NL, int mult, int least) {
+    int64_t rows = (NL + gridDim.x - 1) / gridDim.x;
+    if (rows < least) rows = least;
+    return (rows + mult - 1) / mult * mult;
+}
+
+// ascending list of the rows with flag != 0: per-block counts, single-block scan, fill (deterministic; N / 256 <= 4096 blocks)
+__global__ void __launch_bounds__(T_THREADS) k_t_rows_count(const uint8_t* __restrict__ flag, int64_t N, int32_t* __restrict__ bcnt) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const bool on = n < N && flag[n] != 0;
+    __shared__ int s_c[T_THREADS / 64];
+    const unsigned long long m = __ballot(on);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) bcnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+__global__ void __launch_bounds__(1024) k_t_rows_scan(int32_t* __restrict__ bcnt, int nb, int32_t* __restrict__ total) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? bcnt[i] : 0;
+        int inc = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int wp = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const int x = s_w[k]; if (k < wave) wp += x; tot += x; }
+        const int carry = s_carry;
+        if (i < nb) bcnt[i] = carry + wp + inc - v;      // exclusive prefix
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ void __launch_bounds__(T_THREADS) k_t_rows_fill(const uint8_t* __restrict__ flag, int64_t N, const int32_t* __restrict__ boff,
+                                                            int32_t* __restrict__ list) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    const bool on = n < N && flag[n] != 0;
+    __shared__ int s_c[T_THREADS / 64];
+    const unsigned long long m = __ballot(on);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_c[wave] = __popcll(m);
+    __syncthreads();
+    if (on) {
+        int off = boff[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) off += s_c[k];
+        list[off] = (int32_t)n;
+    }
+}
+// module mode (explicit cotangents): rows with a non-zero cotangent
+__global__ void __launch_bounds__(T_THREADS) k_t_flag_cotangent(const float* __restrict__ d_col, const float* __restrict__ d_sig, int64_t N,
+                                                                 uint8_t* __restrict__ flag) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    flag[n] = (d_sig[n] != 0.0f || d_col[3 * n] != 0.0f || d_col[3 * n + 1] != 0.0f || d_col[3 * n + 2] != 0.0f) ? 1 : 0;
+}
+// live rows of the FORWARD: everything except transparent samples whose noise is <= 0 (alpha = 0 exactly: neither their colour nor
+// their density reaches an output or receives a gradient, can_render.py:115-120 + utils/nerf_net_utils.py:30-36)
+__global__ void __launch_bounds__(T_THREADS) k_t_flag_forward(const uint8_t* __restrict__ transparent, const float* __restrict__ noise,
+                                                               int64_t N, uint8_t* __restrict__ flag) {
+    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (n >= N) return;
+    flag[n] = (transparent[n] == 0 || (noise && noise[n] > 0.0f)) ? 1 : 0;
+}
+
 // model/dimension_kernel.py:34-35,56-75: [x, sin(2^j x), cos(2^j x)]_{j<10}; column 63 is a zero pad
-__global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_c, int64_t N, float* __restrict__ pe) {
-    const int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (t >= N * PE_LD) return;
-    const int64_t n = t >> 6;
-    const int c = (int)(t & 63);
+__global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_c, int64_t N, float* __restrict__ pe, Rows rw) {
+    const int64_t tl = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (tl >= rows_n(rw, N) * PE_LD) return;
+    const int64_t n = rows_at(rw, tl >> 6);
+    const int c = (int)(tl & 63);
+    const int64_t t = n * PE_LD + c;
     float v = 0.0f;
     if (c < 3) v = x_c[3 * n + c];
     else if (c < PE_K) {
@@ -72,13 +153,14 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_
 // (gmax: batch-wide max |tpe| as float bits, for the split-fp16 weight-gradient product; zeroed by the caller.  Grid-stride
 // loop: one look-before-atomicMax per BLOCK - half a million waves reading the same word serialise on its L2 channel)
 __global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restrict__ x_c, const float* __restrict__ u,
-                                                             int64_t N, float* __restrict__ tpe, unsigned* __restrict__ gmax) {
+                                                             int64_t N, float* __restrict__ tpe, unsigned* __restrict__ gmax, Rows rw) {
     __shared__ float s_m[T_THREADS / 64];
     float m = 0.0f;
-    const int64_t total = N * PE_LD, stride = (int64_t)gridDim.x * T_THREADS;
-    for (int64_t t = (int64_t)blockIdx.x * T_THREADS + threadIdx.x; t < total; t += stride) {
-        const int64_t n = t >> 6;
-        const int c = (int)(t & 63);
+    const int64_t total = rows_n(rw, N) * PE_LD, stride = (int64_t)gridDim.x * T_THREADS;
+    for (int64_t tl = (int64_t)blockIdx.x * T_THREADS + threadIdx.x; tl < total; tl += stride) {
+        const int64_t n = rows_at(rw, tl >> 6);
+        const int c = (int)(tl & 63);
+        const int64_t t = n * PE_LD + c;
         float v = 0.0f;
         if (c < 3) v = u[3 * n + c];
         else if (c < PE_K) {
@@ -122,11 +204,12 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe_reverse(const float* __restr
 // out[n,c] = (h[n,c] > 0) ? base[n,c] (optional) + scale[n] (optional, else 1) * w[c] : 0
 __global__ void __launch_bounds__(T_THREADS) k_t_seed(const float* __restrict__ h, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* base, int C,
-                                                       int64_t total, float* out) {   // base may alias out
-    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
-    if (t >= total) return;
-    const int64_t n = t / C;
-    const int c = (int)(t % C);
+                                                       int64_t total, float* out, Rows rw) {   // base may alias out
+    const int64_t tl = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
+    if (tl >= rows_n(rw, total / C) * C) return;
+    const int64_t n = rows_at(rw, tl / C);
+    const int c = (int)(tl % C);
+    const int64_t t = n * C + c;
     const float sc = scale ? scale[n] : 1.0f;
     const float4 ww = make_float4(w[c], w[c + 1], w[c + 2], w[c + 3]);
     float4 v = make_float4(sc * ww.x, sc * ww.y, sc * ww.z, sc * ww.w);
@@ -148,10 +231,11 @@ __device__ __forceinline__ float t_wave_sum(float v) {
 // out[n, k] = bias[k] + h[n,:] . w[k,:]   (K <= 3 output rows; one wave per sample)
 __global__ void __launch_bounds__(T_THREADS) k_t_rowdot(const float* __restrict__ h, int C, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int K, int64_t N,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, Rows rw) {
     const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    const int64_t kr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (kr >= rows_n(rw, N)) return;
+    const int64_t n = rows_at(rw, kr);
     for (int k = 0; k < K; ++k) {
         float acc = 0.0f;
         for (int c = lane; c < C; c += 64) acc = fmaf(h[n * C + c], w[k * C + c], acc);
@@ -179,22 +263,23 @@ __global__ void __launch_bounds__(T_THREADS) k_t_mask_colsum256(float* __restric
 
 // column sums of a [N,C] matrix (C <= 256), accumulated into out[C]
 __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict__ a, int C, int64_t N, int rows_per_block,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, Rows rw) {
     __shared__ float s[T_THREADS];
     const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    const int64_t NL = rows_n(rw, N);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
-    if (end > N) end = N;
+    if (end > NL) end = NL;
     float acc = 0.0f;
     if (r0 < rs) {
         int64_t n = base + r0;
         for (; n + 7 * (int64_t)rs < end; n += 8 * (int64_t)rs) {      // eight independent loads in flight per thread
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a[(n + k * (int64_t)rs) * C + c];
+            for (int k = 0; k < 8; ++k) v[k] = a[rows_at(rw, n + k * (int64_t)rs) * C + c];
             acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; n < end; n += rs) acc += a[n * C + c];
+        for (; n < end; n += rs) acc += a[rows_at(rw, n) * C + c];
     }
     s[threadIdx.x] = acc;
     __syncthreads();
@@ -208,12 +293,13 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
 // db[o] += sum_n dY[n,o] - a weighted column sum at the HBM rate (rocBLAS runs these K = 524 288, M <= 3 shapes at 0.23 ms)
 template <int OUT>
 __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict__ X, int C, const float* __restrict__ dY, int64_t N,
-                                                          int rows_per_block, float* __restrict__ dW, float* __restrict__ db) {
+                                                          int rows_per_block, float* __restrict__ dW, float* __restrict__ db, Rows rw) {
     __shared__ float s[OUT][T_THREADS];
     const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    const int64_t NL = rows_n(rw, N);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
-    if (end > N) end = N;
+    if (end > NL) end = NL;
     float acc[OUT], bs[OUT];
 #pragma unroll
     for (int o = 0; o < OUT; ++o) { acc[o] = 0.0f; bs[o] = 0.0f; }
@@ -222,7 +308,7 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
         float x[4], y[4][OUT];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t row = n + k * (int64_t)rs;
+            const int64_t row = rows_at(rw, n + k * (int64_t)rs);
             x[k] = X[row * C + c];
 #pragma unroll
             for (int o = 0; o < OUT; ++o) y[k][o] = dY[row * OUT + o];
@@ -233,9 +319,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
             for (int o = 0; o < OUT; ++o) { acc[o] = fmaf(x[k], y[k][o], acc[o]); bs[o] += y[k][o]; }
     }
     for (; n < end; n += rs) {
-        const float x = X[n * C + c];
+        const int64_t row = rows_at(rw, n);
+        const float x = X[row * C + c];
 #pragma unroll
-        for (int o = 0; o < OUT; ++o) { const float y = dY[n * OUT + o]; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
+        for (int o = 0; o < OUT; ++o) { const float y = dY[row * OUT + o]; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
     }
 #pragma unroll
     for (int o = 0; o < OUT; ++o) s[o][threadIdx.x] = acc[o];
@@ -258,16 +345,18 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
 // (model/spacenet.py:174-188); thread = feature, two samples per block iteration, rows written coalesced
 __global__ void __launch_bounds__(T_THREADS) k_t_light_first(const float* __restrict__ xl, const float* __restrict__ W0,
                                                               const float* __restrict__ b0, int64_t N, int rows_per_block,
-                                                              float* __restrict__ hl1) {
+                                                              float* __restrict__ hl1, Rows rw) {
     const int f = threadIdx.x & 127, r0 = threadIdx.x >> 7;
     float w[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) w[j] = W0[f * 9 + j];
     const float b = b0[f];
+    const int64_t NL = rows_n(rw, N);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
-    if (end > N) end = N;
-    for (int64_t n = base + r0; n < end; n += 2) {
+    if (end > NL) end = NL;
+    for (int64_t kr = base + r0; kr < end; kr += 2) {
+        const int64_t n = rows_at(rw, kr);
         const float* x = xl + n * 9;          // wave-uniform address: nine scalar / broadcast loads
         float acc = 0.0f;
 #pragma unroll
@@ -279,13 +368,15 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_first(const float* __rest
 // data gradient of the first lighting layer: d_xl[n,j] = sum_k d_hl1[n,k] W0[k,j], 128 -> 9.  A 64-sample tile goes through
 // LDS (coalesced rows in, padded rows out) so that thread (sample, quarter of k) reads its own row slice conflict-free.
 __global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __restrict__ d_hl1, const float* __restrict__ W0,
-                                                                  int64_t N, float* __restrict__ d_xl) {
+                                                                  int64_t N, float* __restrict__ d_xl, Rows rw) {
     __shared__ float tile[64][129];
     __shared__ float part[4][64][9];
+    const int64_t NL = rows_n(rw, N);
     const int64_t n0 = (int64_t)blockIdx.x * 64;
+    if (n0 >= NL) return;          // block-uniform
     for (int e = threadIdx.x; e < 64 * 128; e += T_THREADS) {
         const int r = e >> 7, k = e & 127;
-        tile[r][k] = (n0 + r < N) ? d_hl1[(n0 + r) * 128 + k] : 0.0f;
+        tile[r][k] = (n0 + r < NL) ? d_hl1[rows_at(rw, n0 + r) * 128 + k] : 0.0f;
     }
     __syncthreads();
     const int sm = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,7 +393,7 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 9; e += T_THREADS) {
         const int r = e / 9, j = e - 9 * r;
-        if (n0 + r < N) d_xl[(n0 + r) * 9 + j] = (part[0][r][j] + part[1][r][j]) + (part[2][r][j] + part[3][r][j]);
+        if (n0 + r < NL) d_xl[rows_at(rw, n0 + r) * 9 + j] = (part[0][r][j] + part[1][r][j]) + (part[2][r][j] + part[3][r][j]);
     }
 }
 
@@ -310,9 +401,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __
 __global__ void __launch_bounds__(T_THREADS) k_t_light_in(const float* __restrict__ n_w, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, const float* __restrict__ z_vals,
                                                            const DsnFrameState* __restrict__ fs, int64_t N, int S,
-                                                           float* __restrict__ xl) {
-    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (n >= N) return;
+                                                           float* __restrict__ xl, Rows rw) {
+    const int64_t kr = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (kr >= rows_n(rw, N)) return;
+    const int64_t n = rows_at(rw, kr);
     const int64_t ray = n / S;
     const float d[3] = {ray_d[3 * ray], ray_d[3 * ray + 1], ray_d[3 * ray + 2]};
     const float z = z_vals[n];
@@ -333,9 +425,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_in(const float* __restric
 
 // colour = (ELU(pre) + 1) * essence  (model/spacenet.py:186-188, :265)
 __global__ void __launch_bounds__(T_THREADS) k_t_colour(const float* __restrict__ pre, const float* __restrict__ ess, int64_t N,
-                                                         float* __restrict__ wl, float* __restrict__ col) {
-    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (n >= N) return;
+                                                         float* __restrict__ wl, float* __restrict__ col, Rows rw) {
+    const int64_t kr = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (kr >= rows_n(rw, N)) return;
+    const int64_t n = rows_at(rw, kr);
     const float p = pre[n];
     const float w = (p > 0.0f ? p : expm1f(p)) + 1.0f;
     wl[n] = w;
@@ -349,7 +442,7 @@ __global__ void __launch_bounds__(T_THREADS) k_t_composite_adjoint(
     const float* __restrict__ z_vals, const float* __restrict__ ray_d, const float* __restrict__ noise, int R, int S,
     const float* __restrict__ d_rgb, const float* __restrict__ d_disp, const float* __restrict__ d_acc,
     const float* __restrict__ d_depth, const float* __restrict__ d_weights, float* __restrict__ scratch_t,
-    float* __restrict__ d_colour, float* __restrict__ d_sigma) {
+    float* __restrict__ d_colour, float* __restrict__ d_sigma, uint8_t* __restrict__ live) {
     const int r = blockIdx.x * T_THREADS + threadIdx.x;
     if (r >= R) return;
     const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
@@ -388,22 +481,30 @@ __global__ void __launch_bounds__(T_THREADS) k_t_composite_adjoint(
         const float alpha = 1.0f - e;
         const float Ti = scratch_t[b + i];
         const float w = alpha * Ti;
-        const float* c = colour + 3 * (b + i);
-        float gw = (gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2]) + gd * z_vals[b + i] + ga;
+        // (a colour exists only where the forward evaluated the sample - rows with alpha = 0 may never have been written; its
+        //  product with w = 0 would be 0 for any finite colour)
+        float cg = 0.0f;
+        if (s > 0.0f) { const float* c = colour + 3 * (b + i); cg = gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2]; }
+        float gw = cg + gd * z_vals[b + i] + ga;
         if (d_weights) gw += d_weights[b + i];
         const float dalpha = gw * Ti - suffix / ((1.0f - alpha) + 1e-10f);
         suffix += gw * w;
-        d_sigma[b + i] = (!tr && raw > 0.0f) ? dalpha * dist * e : 0.0f;
-        for (int k = 0; k < 3; ++k) d_colour[3 * (b + i) + k] = w * gr[k];
+        const float ds = (!tr && raw > 0.0f) ? dalpha * dist * e : 0.0f;
+        const float dc[3] = {w * gr[0], w * gr[1], w * gr[2]};
+        d_sigma[b + i] = ds;
+        for (int k = 0; k < 3; ++k) d_colour[3 * (b + i) + k] = dc[k];
+        // rows whose cotangents are all zero add exactly nothing to any parameter gradient: the passes below skip them
+        if (live) live[b + i] = (ds != 0.0f || dc[0] != 0.0f || dc[1] != 0.0f || dc[2] != 0.0f) ? 1 : 0;
     }
 }
 
 // colour = wl * essence, wl = ELU(pre) + 1:  d_essence, d_pre
 __global__ void __launch_bounds__(T_THREADS) k_t_colour_adjoint(const float* __restrict__ d_colour, const float* __restrict__ ess,
                                                                  const float* __restrict__ wl, const float* __restrict__ pre,
-                                                                 int64_t N, float* __restrict__ d_ess, float* __restrict__ d_pre) {
-    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (n >= N) return;
+                                                                 int64_t N, float* __restrict__ d_ess, float* __restrict__ d_pre, Rows rw) {
+    const int64_t kr = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (kr >= rows_n(rw, N)) return;
+    const int64_t n = rows_at(rw, kr);
     float dw = 0.0f;
     for (int c = 0; c < 3; ++c) {
         const float dc = d_colour[3 * n + c];
@@ -416,11 +517,12 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colour_adjoint(const float* __r
 // d_rr[n,c] = (rr > 0) ? sum_k d_ess[n,k] W[k,c] : 0      (rgb_net.3 transposed, model/spacenet.py:72-79)
 __global__ void __launch_bounds__(T_THREADS) k_t_rgb_hidden_adjoint(const float* __restrict__ d_ess, const float* __restrict__ w3,
                                                                      const float* __restrict__ rr, int64_t total,
-                                                                     float* __restrict__ d_rr) {
-    const int64_t t = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
-    if (t >= total) return;
-    const int64_t n = t >> 7;
-    const int c = (int)(t & 127);
+                                                                     float* __restrict__ d_rr, Rows rw) {
+    const int64_t tl = 4 * ((int64_t)blockIdx.x * T_THREADS + threadIdx.x);
+    if (tl >= rows_n(rw, total >> 7) * 128) return;
+    const int64_t n = rows_at(rw, tl >> 7);
+    const int c = (int)(tl & 127);
+    const int64_t t = n * 128 + c;
     const float e0 = d_ess[3 * n], e1 = d_ess[3 * n + 1], e2 = d_ess[3 * n + 2];
     const float4 a0 = make_float4(w3[c], w3[c + 1], w3[c + 2], w3[c + 3]);
     const float4 a1 = make_float4(w3[128 + c], w3[129 + c], w3[130 + c], w3[131 + c]);
@@ -439,9 +541,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_normal_adjoint(const DsnFaceRec
                                                                  const DsnFaceRec* __restrict__ face_canon,
                                                                  const float* __restrict__ x_c, const float* __restrict__ g,
                                                                  const int32_t* __restrict__ idx_c, const float* __restrict__ d_xl,
-                                                                 int64_t N, float* __restrict__ u) {
-    const int64_t n = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
-    if (n >= N) return;
+                                                                 int64_t N, float* __restrict__ u, Rows rw) {
+    const int64_t kr = (int64_t)blockIdx.x * T_THREADS + threadIdx.x;
+    if (kr >= rows_n(rw, N)) return;
+    const int64_t n = rows_at(rw, kr);
     const DsnFaceRec fc = dsn_load_face(face_canon, idx_c[n]);
     const DsnFaceRec fw = dsn_load_face(face_world, idx_c[n]);
     float p[3], pe[3], s[3], e[3], df[3], uu, vv, hh;
@@ -565,14 +668,17 @@ typedef float t_f32x16 __attribute__((ext_vector_type(16)));
 template <int OT, int IT, int WO, int WI>
 __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                                                   int64_t N, int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
-                                                  float* __restrict__ dbias) {
+                                                  float* __restrict__ dbias, Rows rw) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wo = wave / WI, wi = wave % WI;
     const int col = lane & 31, half = lane >> 5;
+    const int64_t NL = rows_n(rw, N);
+    if (rw.cnt) rows_per_wg = (int)rows_share(NL, 2, 64);      // (the launch was sized for N rows: share what is listed)
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
-    if (n1 > N) n1 = N;
+    if (n1 > NL) n1 = NL;
+    if (n0 >= n1) return;
     const bool want_bias = dbias != nullptr && wi == 0;      // column sums of dY (the bias gradient) ride on the loads
     float bsum[OT];
 #pragma unroll
@@ -593,8 +699,9 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
     auto load = [&](int64_t n, float (*fa)[OT], float (*fb)[IT]) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
-            const int64_t row = n + 2 * s + half;
-            const bool ok = row < n1;
+            const int64_t lrow = n + 2 * s + half;
+            const bool ok = lrow < n1;
+            const int64_t row = ok ? rows_at(rw, lrow) : 0;
 #pragma unroll
             for (int a = 0; a < OT; ++a) fa[s][a] = ok ? pa[row * ldy + a * 32] : 0.0f;
 #pragma unroll
@@ -649,18 +756,18 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
 // dW [out,in] += dY[N,out]^T X[N,in]; out in {128,256}, padded in (multiple of 32) in {32,64,128,256}, in_valid <= in
 // (columns >= in_valid are neither read nor written)
 bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ldx, const float* dY, int ldy, float* dW, int ldw,
-                hipStream_t st, float* dbias = nullptr) {
+                hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}) {
     int groups = (out == 256 && in == 256) ? 256 : 768;   // the smaller tiles leave room for 3 workgroups per CU
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 1) & ~1;
     groups = (int)((N + rows - 1) / rows);
     const dim3 g((unsigned)groups), b(256);
-    if (out == 256 && in == 256) hipLaunchKernelGGL((k_t_wgrad<4, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
-    else if (out == 256 && in == 64) hipLaunchKernelGGL((k_t_wgrad<2, 2, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
-    else if (out == 128 && in == 256) hipLaunchKernelGGL((k_t_wgrad<2, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
-    else if (out == 128 && in == 128) hipLaunchKernelGGL((k_t_wgrad<2, 2, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
-    else if (out == 128 && in == 32) hipLaunchKernelGGL((k_t_wgrad<1, 1, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias);
+    if (out == 256 && in == 256) hipLaunchKernelGGL((k_t_wgrad<4, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias, rw);
+    else if (out == 256 && in == 64) hipLaunchKernelGGL((k_t_wgrad<2, 2, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias, rw);
+    else if (out == 128 && in == 256) hipLaunchKernelGGL((k_t_wgrad<2, 4, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias, rw);
+    else if (out == 128 && in == 128) hipLaunchKernelGGL((k_t_wgrad<2, 2, 2, 2>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias, rw);
+    else if (out == 128 && in == 32) hipLaunchKernelGGL((k_t_wgrad<1, 1, 4, 1>), g, b, 0, st, dY, ldy, X, ldx, N, rows, dW, ldw, in_valid, dbias, rw);
     else return false;
     return true;
 }
@@ -675,6 +782,8 @@ bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ld
 // the epilogue.  fp32 accumulation throughout.
 // ------------------------------------------------------------------------------------------------------------
 typedef _Float16 t_half8 __attribute__((ext_vector_type(8)));
+typedef int t_i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) t_i32x4* t_cptr4;
 __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest power of two >= s (1 for s <= 0 or non-finite)
     if (!(s > 0.0f) || !(s < 3.0e38f)) return 1.0f;
     int e;
@@ -694,7 +803,7 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
 __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
-                                                     float* __restrict__ dbias) {
+                                                     float* __restrict__ dbias, Rows rw) {
     constexpr int OT = 4, IT = 4, WI = 2;
     __shared__ __attribute__((aligned(16))) float ring[W16S_STAGES][2][16][256];
     __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][256];
@@ -702,9 +811,12 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave / WI, wi = wave % WI;
     const int col = lane & 31, half = lane >> 5;
+    const int64_t NL = rows_n(rw, N);
+    if (rw.cnt) rows_per_wg = (int)rows_share(NL, 16, 64);     // (the launch was sized for N rows: share what is listed)
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
-    if (n1 > N) n1 = N;
+    if (n1 > NL) n1 = NL;
+    if (n0 >= n1) return;                                // workgroup-uniform
     const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
     const bool tail = n0 + 16 * (int64_t)full < n1;
     float bsum = 0.0f;                                   // column sum of dY feature tid (bias gradient)
@@ -718,13 +830,51 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ring[0][0][0][0];
+    // listed rows: this wave's four row numbers of the NEXT step to be staged, fetched with ONE scalar load a step ahead (a plain
+    // global pointer gives vector loads + s_waitcnt vmcnt(0), which drains the DMA queue at every step)
+    t_i32x4 ids = {0, 0, 0, 0};
+    auto fetch_ids = [&](int t) {
+        if (!rw.list) return;
+        // (constant address space: the list is not written during this kernel, and only for loads from there does hipcc pick
+        //  s_load_dwordx4 and track the wait itself; 16-byte aligned: n0 and the list base are)
+        ids = *reinterpret_cast<t_cptr4>((uintptr_t)(rw.list + (n0 + 16 * (int64_t)t + 4 * wave)));
+    };
     auto stage = [&](int t) {
         const int slot = t % W16S_STAGES;
         const int64_t row = n0 + 16 * (int64_t)t + 4 * wave;
-        const char* ga = reinterpret_cast<const char*>(dY + row * 256) + lane * 16;
-        const char* gb = reinterpret_cast<const char*>(X + row * 256) + lane * 16;
         const unsigned da = ring_off + (unsigned)(((slot * 2 + 0) * 16 + 4 * wave) * 1024);
         const unsigned db = ring_off + (unsigned)(((slot * 2 + 1) * 16 + 4 * wave) * 1024);
+        if (rw.list) {
+            // listed rows: the wave's four rows of this step lie anywhere - one address per row; the LDS side advances by 1 KB per
+            // instruction.  The row numbers were fetched one step earlier (ids: scalar loads whose latency would otherwise sit in
+            // front of every step's DMA); a run of four consecutive rows takes the one-address form
+            if (ids[3] - ids[0] == 3) {
+                const char* ga = reinterpret_cast<const char*>(dY + (int64_t)ids[0] * 256) + lane * 16;
+                const char* gb = reinterpret_cast<const char*>(X + (int64_t)ids[0] * 256) + lane * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                             : : "v"(ga), "s"(da) : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                             : : "v"(gb), "s"(db) : "memory", "m0");
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* ga = reinterpret_cast<const char*>(dY + (int64_t)ids[j] * 256) + lane * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* gb = reinterpret_cast<const char*>(X + (int64_t)ids[j] * 256) + lane * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db + 1024u * j) : "memory", "m0");
+            }
+            return;
+        }
+        const char* ga = reinterpret_cast<const char*>(dY + row * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(X + row * 256) + lane * 16;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
@@ -778,7 +928,8 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
             }
     };
     const int pre = full < W16S_STAGES - 1 ? full : W16S_STAGES - 1;
-    for (int t = 0; t < pre; ++t) stage(t);
+    for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
+    if (pre < full) fetch_ids(pre);
     for (int t = 0; t < full; ++t) {
         const int issued = (t + W16S_STAGES - 1 < full) ? t + W16S_STAGES - 1 : full;
         const int ahead = issued - (t + 1);
@@ -787,7 +938,10 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // A: step t has landed for everyone; everyone has fetched the operands of step t - 1 (opbuf and ring slot t - 1 are free)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + W16S_STAGES - 1 < full) stage(t + W16S_STAGES - 1);
+        if (t + W16S_STAGES - 1 < full) {
+            stage(t + W16S_STAGES - 1);
+            if (t + W16S_STAGES < full) fetch_ids(t + W16S_STAGES);      // (waited for at the next lgkmcnt(0): hidden behind this step)
+        }
         const int slot = t % W16S_STAGES;
         float v[2][16];
 #pragma unroll
@@ -802,8 +956,9 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
         float v[2][16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int64_t row = n0 + 16 * (int64_t)full + j;
-            const bool ok = row < n1;
+            const int64_t lrow = n0 + 16 * (int64_t)full + j;
+            const bool ok = lrow < n1;
+            const int64_t row = ok ? rows_at(rw, lrow) : 0;
             v[0][j] = ok ? dY[row * 256 + tid] : 0.0f;
             v[1][j] = ok ? X[row * 256 + tid] : 0.0f;
         }
@@ -834,7 +989,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
 __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
-                                                        float* __restrict__ dbias) {
+                                                        float* __restrict__ dbias, Rows rw) {
     __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
     __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
     __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
@@ -842,9 +997,12 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
+    const int64_t NL = rows_n(rw, N);
+    if (rw.cnt) rows_per_wg = (int)rows_share(NL, 16, 64);
     const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t n1 = n0 + rows_per_wg;
-    if (n1 > N) n1 = N;
+    if (n1 > NL) n1 = NL;
+    if (n0 >= n1) return;                                // workgroup-uniform
     const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
     const bool tail = n0 + 16 * (int64_t)full < n1;
     float bsum = 0.0f;
@@ -859,14 +1017,34 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     const unsigned offY = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringY[0][0][0];
     const unsigned offX = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringX[0][0][0];
+    t_i32x4 ids = {0, 0, 0, 0};        // listed rows: this wave's four row numbers of the NEXT step (one scalar load, see k_t_wgrad16c)
+    auto fetch_ids = [&](int t) {
+        if (!rw.list) return;
+        ids = *reinterpret_cast<t_cptr4>((uintptr_t)(rw.list + (n0 + 16 * (int64_t)t + 4 * wave)));
+    };
     // DMA of step t: rows 4 wave .. + 3 of dY (1 KB each) and KB `wave` of the 4 KB the 16 rows of X occupy
     auto stage = [&](int t) {
         const int slot = t % W16P_STAGES;
         const int64_t row = n0 + 16 * (int64_t)t;
-        const char* ga = reinterpret_cast<const char*>(dY + (row + 4 * wave) * 256) + lane * 16;
-        const char* gb = reinterpret_cast<const char*>(X + row * 64) + wave * 1024 + lane * 16;
         const unsigned da = offY + (unsigned)((slot * 16 + 4 * wave) * 1024);
         const unsigned db = offX + (unsigned)(slot * 4096 + wave * 1024);
+        if (rw.list) {
+            // listed rows: one address per 1 KB row of dY; the wave's KB of X is four 256-byte rows, lane -> (row lane / 16, 16 B piece).
+            // Row numbers fetched one step earlier (scalar loads; a vector load's wait would drain the DMA queue)
+            const int rr[4] = {ids[0], ids[1], ids[2], ids[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* ga = reinterpret_cast<const char*>(dY + (int64_t)rr[j] * 256) + lane * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
+            }
+            const int q = lane >> 4;
+            const int64_t rx = q == 0 ? rr[0] : (q == 1 ? rr[1] : (q == 2 ? rr[2] : rr[3]));
+            const char* gb = reinterpret_cast<const char*>(X + rx * 64) + (lane & 15) * 16;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db) : "memory", "m0");
+            return;
+        }
+        const char* ga = reinterpret_cast<const char*>(dY + (row + 4 * wave) * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(X + row * 64) + wave * 1024 + lane * 16;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
@@ -922,13 +1100,17 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
             }
     };
     const int pre = full < W16P_STAGES - 1 ? full : W16P_STAGES - 1;
-    for (int t = 0; t < pre; ++t) stage(t);
+    for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
+    if (pre < full) fetch_ids(pre);
     for (int t = 0; t < full; ++t) {
         const int issued = (t + W16P_STAGES - 1 < full) ? t + W16P_STAGES - 1 : full;
         if (issued - (t + 1) >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // one later step (5 pieces) may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + W16P_STAGES - 1 < full) stage(t + W16P_STAGES - 1);
+        if (t + W16P_STAGES - 1 < full) {
+            stage(t + W16P_STAGES - 1);
+            if (t + W16P_STAGES < full) fetch_ids(t + W16P_STAGES);
+        }
         const int slot = t % W16P_STAGES;
         float vy[16], vx[8];
 #pragma unroll
@@ -943,13 +1125,13 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
         float vy[16], vx[8];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int64_t row = n0 + 16 * (int64_t)full + j;
-            vy[j] = row < n1 ? dY[row * 256 + tid] : 0.0f;
+            const int64_t lrow = n0 + 16 * (int64_t)full + j;
+            vy[j] = lrow < n1 ? dY[rows_at(rw, lrow) * 256 + tid] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t row = n0 + 16 * (int64_t)full + 8 * ((tid >> 6) & 1) + j;
-            vx[j] = row < n1 ? X[row * 64 + (tid & 63)] : 0.0f;
+            const int64_t lrow = n0 + 16 * (int64_t)full + 8 * ((tid >> 6) & 1) + j;
+            vx[j] = lrow < n1 ? X[rows_at(rw, lrow) * 64 + (tid & 63)] : 0.0f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         publish(vy, vx);
@@ -973,25 +1155,25 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
 }
 
 void wgrad_mfma16p(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, int in_valid,
-                   hipStream_t st, float* dbias = nullptr) {
+                   hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}) {
     int groups = 512;                 // two workgroups per CU
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias);
+    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias, rw);
 }
 
 // dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
 // dbias (optional) [256] += column sums of dY
 void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
-                  float* dbias = nullptr) {
+                  float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}) {
     int groups = 256;                 // one workgroup per CU, one round (with 512 the launch ran 0.33 instead of 0.28 ms)
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias);
+    hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
 }
 
 
@@ -1013,7 +1195,7 @@ enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_SEED = 3 };
 template <int K, int M, bool TRANS, int EPI>
 __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
                                                   int64_t N, const float* __restrict__ bias_or_wv, const float* __restrict__ msrc,
-                                                  const float* __restrict__ sc) {
+                                                  const float* __restrict__ sc, Rows rw) {
     constexpr int NT = M / 32, NQ = NT / 4;
     // B in LDS as [k][quad of column tiles][column in tile][tile in quad]: the 4 column tiles a lane feeds with one k come
     // back with ONE ds_read_b128 (lanes 16 bytes apart: conflict-free)
@@ -1028,12 +1210,14 @@ __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, c
         for (int i = tid; i < M; i += 256) sV[i] = bias_or_wv[i];
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    const int64_t ntile = (N + 31) / 32;
+    const int64_t NL = rows_n(rw, N);
+    const int64_t ntile = (NL + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
         // D[feature][point] = sum_k B[k][feature] X[point][k]: lane = point `col`, registers = features
-        const int64_t prow = tile * 32 + col;
-        const bool valid = prow < N;
-        const int64_t crow = valid ? prow : N - 1;
+        const int64_t lrow = tile * 32 + col;
+        const bool valid = lrow < NL;
+        const int64_t crow = rows_at(rw, valid ? lrow : NL - 1);
+        const int64_t prow = crow;
         const float* xr = X + crow * K + 4 * half;
         // what the epilogue needs from memory is requested NOW and used after the products: its latency hides behind them
         float4 mk[EPI == EPI_MASK || EPI == EPI_SEED ? NT : 1][4];
@@ -1101,11 +1285,12 @@ __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, c
     }
 }
 template <int K, int M, bool TRANS, int EPI>
-void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_or_wv, const float* msrc, const float* sc, hipStream_t st) {
+void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_or_wv, const float* msrc, const float* sc, hipStream_t st,
+         Rows rw = Rows{nullptr, nullptr}) {
     const int64_t ntile = (N + 31) / 32;
     int groups = (int)((ntile + 3) / 4);
     if (groups > 256) groups = 256;               // one workgroup per CU: B is staged once per workgroup
-    hipLaunchKernelGGL((k_t_lin<K, M, TRANS, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, W, Y, N, bias_or_wv, msrc, sc);
+    hipLaunchKernelGGL((k_t_lin<K, M, TRANS, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, W, Y, N, bias_or_wv, msrc, sc, rw);
 }
 
 struct TrainWs {
@@ -1114,6 +1299,10 @@ struct TrainWs {
     float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
     void* masks;
     float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
+    uint8_t* live;                 // [N] row flags (scratch of the list builds)
+    int32_t *list1, *list2;        // [N] rows the forward evaluates / rows with non-zero cotangents (ascending sample indices)
+    int32_t *bcnt;                 // [N / 256 + 1] per-block counts / offsets of a list build
+    int32_t *rowcnt;               // [0] = entries of list1, [1] = entries of list2 (NOT in `small`: that is cleared per backward)
     size_t bytes;
 };
 
@@ -1153,20 +1342,25 @@ TrainWs carve(void* base, int64_t N) {
     w.d_rr = (float*)take(512 * n);
     w.u = (float*)take(12 * n);
     w.scratch_t = (float*)take(4 * n);
-    w.small = (float*)take(4 * 1024);
+    w.live = (uint8_t*)take(n);
+    w.list1 = (int32_t*)take(4 * n);
+    w.list2 = (int32_t*)take(4 * n);
+    w.bcnt = (int32_t*)take(4 * (n / T_THREADS + 2));
+    w.rowcnt = (int32_t*)take(256);           // (the 256 bytes in front of `small`: the host mirror reads the two counts there)
+    w.small = (float*)take(4 * 1024);         // (last: the host mirror finds its counters at the end of the workspace)
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
 
-void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st) {
+void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st, Rows rw = Rows{nullptr, nullptr}) {
     const int rows = 256;
-    hipLaunchKernelGGL(k_t_colsum, dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, a, C, N, rows, out);
+    hipLaunchKernelGGL(k_t_colsum, dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, a, C, N, rows, out, rw);
 }
 
 template <int OUT>
-void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st) {
+void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st, Rows rw = Rows{nullptr, nullptr}) {
     const int rows = 256;
-    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db);
+    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw);
 }
 
 }  // namespace
@@ -1175,8 +1369,26 @@ size_t dsn_train_workspace_size(int64_t N) { return carve(nullptr, N).bytes; }
 
 DsnTrainCache dsn_train_cache(void* workspace, int64_t N) {
     const TrainWs w = carve(workspace, N);
-    DsnTrainCache c = {w.transparent, w.idx_c, w.x_c, w.sig, w.ess, w.g, w.n_w, w.h[0], w.ap[0], w.rr, w.masks, w.hl1, w.hl2, w.pre};
+    DsnTrainCache c = {w.transparent, w.idx_c, w.x_c, w.sig, w.ess, w.g, w.n_w, w.h[0], w.ap[0], w.rr, w.masks, w.hl1, w.hl2, w.pre,
+                       w.live, w.list1, w.bcnt, w.rowcnt};
     return c;
+}
+
+// list <- ascending indices of the rows with flag != 0, *count <- their number (three small launches, deterministic)
+// DSN_TRAIN_ALL_ROWS=1 (tests / A-B runs): every row is listed - the dense evaluation of round 2
+static bool dsn_train_all_rows() { const char* e = getenv("DSN_TRAIN_ALL_ROWS"); return e && e[0] == '1'; }
+void dsn_train_build_rows(uint8_t* flag, int64_t N, int32_t* bcnt, int32_t* list, int32_t* count, hipStream_t st) {
+    if (dsn_train_all_rows()) (void)hipMemsetAsync(flag, 1, (size_t)N, st);
+    const int nb = (int)((N + T_THREADS - 1) / T_THREADS);
+    hipLaunchKernelGGL(k_t_rows_count, dim3((unsigned)nb), dim3(T_THREADS), 0, st, (const uint8_t*)flag, N, bcnt);
+    hipLaunchKernelGGL(k_t_rows_scan, dim3(1), dim3(1024), 0, st, bcnt, nb, count);
+    hipLaunchKernelGGL(k_t_rows_fill, dim3((unsigned)nb), dim3(T_THREADS), 0, st, (const uint8_t*)flag, N, (const int32_t*)bcnt, list);
+}
+// rows the training forward has to evaluate (see k_t_flag_forward) -> list, *count
+void dsn_train_forward_rows(const uint8_t* transparent, const float* noise, int64_t N, uint8_t* flag, int32_t* bcnt, int32_t* list,
+                            int32_t* count, hipStream_t st) {
+    hipLaunchKernelGGL(k_t_flag_forward, grid_for(N), dim3(T_THREADS), 0, st, transparent, noise, N, flag);
+    dsn_train_build_rows(flag, N, bcnt, list, count, st);
 }
 
 #define T_CHECK(x) do { if (!(x)) return #x; } while (0)
@@ -1213,90 +1425,101 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
 
     // ---- forward: warp, encoding, trunk, heads ------------------------------------------------------------
     // (skipped when dsn_render_rays_train has just left all of it in this workspace)
+    // R1: the rows the forward evaluates (all but transparent samples with noise <= 0: alpha = 0 exactly); R2 (below): the rows
+    // with non-zero cotangents - the only ones that reach a gradient.  Arrays stay indexed by sample.
+    Rows R1 = {nullptr, nullptr};
     if (module) {
         if (hipMemcpyAsync(w.x_c, ext_x_c, sizeof(float) * 3 * (size_t)N64, hipMemcpyDeviceToDevice, st) != hipSuccess) return "x_c copy";
-    } else if (!cached)
-        dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
-                        nullptr, false, st);
-    hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe);
+    } else {
+        if (!cached) {
+            dsn_launch_warp(s, nullptr, ray_o, ray_d, z_vals, N64, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, nullptr,
+                            nullptr, false, st);
+            dsn_train_forward_rows(w.transparent, noise, N64, w.live, w.bcnt, w.list1, w.rowcnt, st);
+        }
+        R1 = Rows{w.list1, w.rowcnt};
+    }
     // trunk + heads forward and the sigma reverse pass in ONE fused split-fp16 launch (k_field16<train>): besides sigma,
     // essence and g = d sigma/dx it leaves every layer's activations h_l, the masked sigma-adjoints a_l and the rgb hidden
     // layer in the row-major arrays the weight-gradient products below read
-    const int64_t tot = N64 * 256;
     const dim3 wave_grid((unsigned)((N64 + 3) / 4));
-    if (!cached) dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, w.masks, st);
+    if (!cached) dsn_launch_field16_train(packed, s.frame, w.x_c, N64, w.sig, w.ess, w.g, w.h[0], w.ap[0], w.rr, w.masks, st, nullptr,
+                                          R1.list, R1.cnt);
 
     // ---- normals, lighting, colour ---------------------------------------------------------------------------
-    if (!cached) dsn_launch_normal(s, w.x_c, w.g, N64, nullptr, nullptr, w.idx_c, w.n_w, false, st);
-    hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl);
+    if (!cached) dsn_launch_normal(s, w.x_c, w.g, N64, R1.list, R1.cnt, w.idx_c, w.n_w, false, st);
+    hipLaunchKernelGGL(k_t_light_in, grid_for(N64), dim3(T_THREADS), 0, st, w.n_w, ray_o, ray_d, z_vals, s.frame, N64, S, w.xl, R1);
     if (!cached) {      // (the training forward's k_light16 has left hl1, hl2 and pre in this workspace otherwise)
         hipLaunchKernelGGL(k_t_light_first, dim3((unsigned)((N64 + 255) / 256)), dim3(T_THREADS), 0, st, w.xl, prm[P_L0_W], prm[P_L0_B],
-                           N64, 256, w.hl1);
-        lin<128, 128, true, EPI_BIAS_RELU>(w.hl1, prm[P_L2_W], w.hl2, N64, prm[P_L2_B], nullptr, nullptr, st);   // hl2 = relu(hl1 W2^T + b2)
-        hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre);
+                           N64, 256, w.hl1, R1);
+        lin<128, 128, true, EPI_BIAS_RELU>(w.hl1, prm[P_L2_W], w.hl2, N64, prm[P_L2_B], nullptr, nullptr, st, R1);   // hl2 = relu(hl1 W2^T + b2)
+        hipLaunchKernelGGL(k_t_rowdot, wave_grid, dim3(T_THREADS), 0, st, w.hl2, 128, prm[P_L4_W], prm[P_L4_B], 1, N64, w.pre, R1);
     }
-    hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col);
+    hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col, R1);
 
     // ---- adjoint of compositing and of the colour product ------------------------------------------------------
     if (!module)
         hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
-                           noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig);
+                           noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig, w.live);
     const float* const d_col = module ? ext_d_col : w.d_col;
     const float* const d_sig = module ? ext_d_sig : w.d_sig;
+    if (module) hipLaunchKernelGGL(k_t_flag_cotangent, grid_for(N64), dim3(T_THREADS), 0, st, d_col, d_sig, N64, w.live);
+    dsn_train_build_rows(w.live, N64, w.bcnt, w.list2, w.rowcnt + 1, st);
+    const Rows R2 = {w.list2, w.rowcnt + 1};
+    hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe, R2);
     hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
-                       w.d_pre);
+                       w.d_pre, R2);
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
-    wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st);
+    wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2);
     hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
-                       w.d_hl2);
-    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B]));
-    lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
-    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B]));
+                       w.d_hl2, R2);
+    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
+    lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
+    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2));
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
-                       w.d_xl);
+                       w.d_xl, R2);
 
     // ---- u = dL/dg through the normal map, then the tangent pass (second-order term) ---------------------------
     hipLaunchKernelGGL(k_t_normal_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, s.face_world, s.face_canon, w.x_c, w.g, w.idx_c,
-                       w.d_xl, N64, w.u);
+                       w.d_xl, N64, w.u, R2);
     float* const g_tpe = w.small + 302;        // batch-wide max |tpe| (float bits; zeroed with w.small)
     {
         const int64_t nb = (N64 * PE_LD + T_THREADS - 1) / T_THREADS;
         hipLaunchKernelGGL(k_t_pe_tangent, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe,
-                           (unsigned*)g_tpe);
+                           (unsigned*)g_tpe, R2);
     }
     // all seven tangent layers in one fused split-fp16 launch (k_tangent16, relu patterns from the training forward's records),
     // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
     float* const g_tan = w.small + 300;        // batch-wide magnitudes of the tangent / adjoint arrays (zeroed with w.small)
     float* const g_adj = w.small + 301;
     int32_t* const range_cnt = (int32_t*)(w.small + 303);      // samples whose tangent / adjoint left the fp16 range (zeroed with w.small)
-    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st);
+    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt, R2.list, R2.cnt);
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st, nullptr, R2);
     for (int l = 1; l < 7; ++l)
-        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st);
-    colsum(w.tn[6], 256, N64, grd[P_DEN_W], st);   // d (w_d . hdot_6) / d w_d
+        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, nullptr, R2);
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2);
+    colsum(w.tn[6], 256, N64, grd[P_DEN_W], st, R2);   // d (w_d . hdot_6) / d w_d
     float* cur = w.t0;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
-    wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st);
+    wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2);
     hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
-                       w.d_rr);
-    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B]));
-    wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st);
+                       w.d_rr, R2);
+    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
+    wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st, R2);
     // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in
-    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st);
+    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = w.tn;
-    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt);
+    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt, R2.list, R2.cnt);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
-        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]]);
-        if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st);
+        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2);
+        if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2);
     }
     // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
-    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small);
+    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2);
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
     if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
     hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,

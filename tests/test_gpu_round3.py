@@ -176,3 +176,41 @@ def test_phase_calls_equal_the_whole_frame(mode):
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
     assert float(a["acc_map"].max()) > 0.05
+
+
+@pytest.mark.parametrize("name", ["full_train_grads", "full_train_grads_w4"])
+def test_training_row_skip_is_exact(name, monkeypatch):
+    """Round 3: the training step evaluates only rows that can reach an output (all but transparent samples with noise <= 0) and
+    back-propagates only rows with a non-zero cotangent.  Against the dense evaluation of round 2 (DSN_TRAIN_ALL_ROWS=1): same
+    outputs bit for bit, same gradients up to the summation order of the weight-gradient products (the skipped rows are exact
+    zeros in every sum), and a fair share of the rows really is skipped"""
+    import test_gpu_render as TR
+    from helpers import load
+    from dsnerf_amd import _lib
+    g = load(name)
+
+    def run():
+        r = TR.make_renderer(g, name)
+        r.cfg.MODEL.raw_noise_std = float(g["raw_noise_std"])
+        r.train()
+        torch.manual_seed(int(g["seed"]))
+        out = r.render(TR.make_batch(g))["coarse"]
+        loss = ((out["color"] - torch.from_numpy(g["target_rgb"]).cuda()) ** 2).mean() + 0.1 * out["acc_map"].mean() \
+            + 1e-3 * (out["weights"] * out["weights"]).sum() + 1e-2 * out["depth_map"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        R, S = out["z_vals"].shape
+        rows = _lib.grad_row_counts(r._grad_ws, R, S)
+        return ({k: v.detach().clone() for k, v in out.items()}, {k: p.grad.detach().clone() for k, p in r.net.named_parameters()}, rows,
+                R * S)
+
+    out_s, grad_s, rows_s, N = run()
+    monkeypatch.setenv("DSN_TRAIN_ALL_ROWS", "1")
+    out_d, grad_d, rows_d, _ = run()
+    monkeypatch.delenv("DSN_TRAIN_ALL_ROWS")
+    assert rows_d == (N, N) and rows_s[1] <= rows_s[0] < N and rows_s[1] < 0.8 * N, (rows_s, rows_d, N)
+    for k in out_s:
+        assert torch.equal(torch.nan_to_num(out_s[k], nan=-1.0), torch.nan_to_num(out_d[k], nan=-1.0)), k
+    for k in grad_s:
+        a, b = grad_s[k].double(), grad_d[k].double()
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
