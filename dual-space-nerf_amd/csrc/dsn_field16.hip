@@ -52,7 +52,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define F16_PIPE_LATE 1       // stage2.0 / stage2.4 (forward) with software-pipelined epilogues like the plain 256 -> 256 layers
 #endif
 #ifndef F16_ABL
-#define F16_ABL 0             // timing ablations (WRONG results): 1 no ring barrier, 2 no vmcnt wait, 4 no LDS-DMA, 8 no pipelined epilogue (MFMAs die too), 16 empty epilogue slices (MFMAs kept)
+#define F16_ABL 0             // timing ablations (WRONG results): 1 no ring barrier, 2 no vmcnt wait, 4 no LDS-DMA, 8 no pipelined epilogue (MFMAs die too), 16 empty epilogue slices (MFMAs kept), 32 epilogue without the second accumulator's add / fold
 #endif
 #ifndef F16_NEXT_POINT
 #define F16_NEXT_POINT 1      // k_field16: the next tile's list entry and coordinates are fetched under the current tile
@@ -353,7 +353,14 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * kb + e;
+#if F16_ABL & 32
+        // timing emulation (WRONG results) of "one accumulator per output block, two blocks' chains interleaved": the epilogue loses its
+        // accumulator add (forward) / fold (reverse); the second accumulator stays live so that no MFMA dies
+        asm volatile("" : : "v"(pC[r]));
+        float v = FWD ? pM[r] * F16_FWD_INV : pM[r];
+#else
         float v = FWD ? (pM[r] + pC[r]) * F16_FWD_INV : fmaf(pC[r], DSN_LO_INV, pM[r]);
+#endif
         if (FWD) {
             bits = dsn_push_sign(bits, v);      // `bits` collects the 16 signs of this output block
             v = fmaxf(v, 0.0f);

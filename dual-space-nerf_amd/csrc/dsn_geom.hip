@@ -382,10 +382,14 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
                                                         float* __restrict__ x_c, float* __restrict__ ray_d_can,
                                                         int32_t* __restrict__ active_list,
                                                         int32_t* __restrict__ active_count,
-                                                        const int32_t* __restrict__ nn_pre, int lazy_canon) {
+                                                        const int32_t* __restrict__ nn_pre, int lazy_canon,
+                                                        const int32_t* __restrict__ only_cell_of, const int32_t* __restrict__ only_count) {
     __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     const int64_t i = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
-    const bool valid = i < N;
+    // only_cell_of / only_count (fused path, behind dsn_launch_nn_cellmajor_warp): this launch takes the samples the cell-major pass
+    // left alone - those outside the fine grid (cell_of < 0), *only_count of them; normally none: the launch is 65 k workgroups that look
+    if (only_count && *only_count == 0) return;      // block-uniform
+    const bool valid = i < N && (!only_cell_of || only_cell_of[i] < 0);
     float p[3] = {0.f, 0.f, 0.f};
     int64_t ray = 0;
     if (valid) {
@@ -460,17 +464,19 @@ __global__ void __launch_bounds__(WARP_THREADS) k_warp(DsnNNArgs nn, const float
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st, const int32_t* nn_pre, bool lazy_canon) {
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre, bool lazy_canon, const int32_t* only_cell_of,
+                     const int32_t* only_count) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
     DsnNNArgs nn = dsn_nn_args(s.nn_world);
     if (exhaustive)
         hipLaunchKernelGGL(k_warp<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count, nullptr, (int)(lazy_canon && !ray_d_can));
+                           ray_d_can, active_list, active_count, nullptr, (int)(lazy_canon && !ray_d_can), (const int32_t*)nullptr,
+                           (const int32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_warp<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_world, s.face_world,
                            s.face_canon, s.F, pts, ray_o, ray_d, z_vals, N, S, face_idx, uv, h, transparent, x_c,
-                           ray_d_can, active_list, active_count, nn_pre, (int)(lazy_canon && !ray_d_can));
+                           ray_d_can, active_list, active_count, nn_pre, (int)(lazy_canon && !ray_d_can), only_cell_of, only_count);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,11 +27,18 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
-                     bool exhaustive, hipStream_t st, const int32_t* nn_pre = nullptr, bool lazy_canon = false);
+                     bool exhaustive, hipStream_t st, const int32_t* nn_pre = nullptr, bool lazy_canon = false,
+                     const int32_t* only_cell_of = nullptr, const int32_t* only_count = nullptr);
 // dsn_nn.hip: cell-major exact search of the fine lists (nn [N]: index, or -1 where the fine grid does not cover)
 size_t dsn_nn_sort_scratch_size(int64_t N);
 void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
                              int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
+// the same search with the rest of the warp stage fused behind it (transparent, x_c, active list written by the search kernel);
+// *outside <- device counter of the samples left alone (cell_of < 0): dsn_launch_warp(..., only_cell_of, only_count) takes those
+void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
+                                  int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
+                                  uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
+                                  int32_t** outside, hipStream_t st);
 void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, const float* smpl_w, const float* A, int bw_type,
                          int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
                                                               const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                               const float* __restrict__ z_vals, int64_t N, int S,
                                                               int32_t* __restrict__ cell_of, int32_t* __restrict__ nn,
-                                                              int32_t* __restrict__ counts) {
+                                                              int32_t* __restrict__ counts, int32_t* __restrict__ outside) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1;
@@ -330,10 +330,16 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
         nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
         c = dsn_grid_cell(*gf, p[0], p[1], p[2]);
         cell_of[i] = c;
-        if (c < 0) nn[i] = -1;
+        if (c < 0 && nn) nn[i] = -1;
     }
     const NnsRun r = nns_run(c, lane);
     if (r.head && c >= 0) atomicAdd(counts + c, r.len);
+    // samples outside the fine grid (none for rays clipped to the body's bounds): counted, the fused search + warp leaves them to
+    // a second pass (k_warp on the samples with cell_of < 0)
+    if (outside) {
+        const unsigned long long om = __ballot(i < N && c < 0);
+        if (om && lane == 0) atomicAdd(outside, __popcll(om));
+    }
 }
 
 // exclusive scans over the cells: sample offsets and wave offsets (ceil(count / 64) waves per cell); counts are
@@ -401,11 +407,22 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter(const int32_t* __re
     }
 }
 
+// WARP = true (round 3): the rest of the warp stage (can_render.py:333-379: projection onto the nearest posed face, transparency,
+// canonical re-embedding, active list) runs right here, on the point and the face index the search has in registers - no nn[] round
+// trip, no second pass over the 16.8 M samples, and the face records of a wave's samples (one cell: a handful of faces) come from L1.
+// Same helpers and expressions as k_warp: bit-identical transparent / x_c.  The active list comes out cell-major instead of
+// ray-major (its order never reaches a value; the sigma > 0 list inherits it, which puts the lanes of k_normal's waves into the
+// same canonical cells).
+struct NnsWarp {
+    const DsnFaceRec* face_world; const DsnFaceRec* face_canon; uint8_t* transparent; float* x_c; int32_t* active_list;
+    int32_t* active_count; int lazy_canon;
+};
+template <bool WARP>
 __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __restrict__ off_f, const float4* __restrict__ list_f,
                                                             const int32_t* __restrict__ wave_cell, const int32_t* __restrict__ wave_offs,
                                                             const int32_t* __restrict__ totals, const int32_t* __restrict__ offs,
                                                             const int32_t* __restrict__ counts, const float4* __restrict__ sorted,
-                                                            int32_t* __restrict__ nn) {
+                                                            int32_t* __restrict__ nn, NnsWarp wp) {
     const int lane = threadIdx.x & 63;
     // XCD-aware block -> wave map.  Consecutive waves work on the same cell and read the same candidate list; workgroup b
     // runs on XCD b % 8 (MI355X_MICROARCH.md), each with its own L2, so the plain map b -> waves 4b .. 4b+3 sends every
@@ -416,15 +433,17 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
     const unsigned bq = blockIdx.x >> 3, bx = blockIdx.x & 7u;
     const unsigned vb = ((bq >> 4) * 8u + bx) * 16u + (bq & 15u);
     const int w = __builtin_amdgcn_readfirstlane(vb * (NNS_THREADS / 64) + (threadIdx.x >> 6));
-    if (w >= totals[0]) return;
-    const int c = __builtin_amdgcn_readfirstlane(wave_cell[w]);
+    const int nwaves = totals[0];
+    if (WARP ? (int)(vb * (NNS_THREADS / 64)) >= nwaves : w >= nwaves) return;      // (WARP: block-uniform - the append below has barriers)
+    const bool wave_on = w < nwaves;
+    const int c = __builtin_amdgcn_readfirstlane(wave_cell[wave_on ? w : 0]);
     const int slot = (w - __builtin_amdgcn_readfirstlane(wave_offs[c])) * 64 + lane;
-    const bool valid = slot < __builtin_amdgcn_readfirstlane(counts[c]);
+    const bool valid = wave_on && slot < __builtin_amdgcn_readfirstlane(counts[c]);
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) q = sorted[__builtin_amdgcn_readfirstlane(offs[c]) + slot];
     const float p[3] = {q.x, q.y, q.z};
     const int o = __builtin_amdgcn_readfirstlane(off_f[c]);
-    const int n = __builtin_amdgcn_readfirstlane(off_f[c + 1]) - o;
+    const int n = wave_on ? __builtin_amdgcn_readfirstlane(off_f[c + 1]) - o : 0;
     const float4* __restrict__ e = list_f + o;
     float best = INFINITY;
     int bi = 0;
@@ -444,7 +463,71 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
         const float d = dsn_d2(p[0], p[1], p[2], a);
         if (d < best) { best = d; bi = __float_as_int(a.w); }
     }
-    if (valid) nn[__float_as_int(q.w)] = bi;
+    if (!WARP) {
+        if (valid) nn[__float_as_int(q.w)] = bi;
+        return;
+    }
+    bool active = false;
+    const int64_t i = (int64_t)__float_as_int(q.w);
+    if (valid) {
+        const DsnFaceRec fw = dsn_load_face(wp.face_world, bi);
+        float u, v, h, xc[3] = {0.f, 0.f, 0.f};
+        dsn_project(p, fw, u, v, h);
+        const bool tr = (u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f);
+        if (!(tr && wp.lazy_canon)) {
+            const DsnFaceRec fc = dsn_load_face(wp.face_canon, bi);
+            dsn_map2face(u, v, h, fc, xc);
+        }
+        wp.transparent[i] = tr ? 1 : 0;
+        wp.x_c[3 * i] = xc[0]; wp.x_c[3 * i + 1] = xc[1]; wp.x_c[3 * i + 2] = xc[2];
+        active = !tr;
+    }
+    if (wp.active_list) {      // workgroup-aggregated append, as in k_warp: one atomic per 256 samples
+        __shared__ int s_cnt[NNS_THREADS / 64];
+        __shared__ int s_base;
+        const unsigned long long m = __ballot(active);
+        const int wave = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < NNS_THREADS / 64; ++k) tot += s_cnt[k];
+            s_base = tot ? atomicAdd(wp.active_count, tot) : 0;
+        }
+        __syncthreads();
+        if (active) {
+            int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < wave; ++k) off += s_cnt[k];
+            wp.active_list[off] = (int32_t)i;
+        }
+    }
+}
+
+// the fused form: nearest face + the rest of the warp stage for every sample inside the fine grid; *outside (device int) counts the
+// samples it leaves alone (cell_of < 0).  cell_of: N ints; sorted: N float4 of scratch
+void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
+                                  int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
+                                  uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
+                                  int32_t** outside, hipStream_t st) {
+    char* q = (char*)small;
+    int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* offs = (int32_t*)q;       q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* wave_offs = (int32_t*)q;  q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* totals = (int32_t*)q;     q += 256;
+    int32_t* wave_cell = (int32_t*)q;
+    (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
+    (void)hipMemsetAsync(totals, 0, 256, st);
+    *outside = totals + 2;
+    const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
+    hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, cell_of, (int32_t*)nullptr,
+                       counts, totals + 2);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
+    hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
+    const int64_t max_waves = N / 64 + DSN_NN_FINE_MAXCELL + 1;
+    const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
+    hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, (int32_t*)nullptr, wp);
 }
 
 size_t dsn_nn_sort_scratch_size(int64_t N) {
@@ -464,11 +547,11 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
     int32_t* wave_cell = (int32_t*)q;
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
-    hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, pts, ray_o, ray_d, z_vals, N, S, cell_of, nn, counts);
+    hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, pts, ray_o, ray_d, z_vals, N, S, cell_of, nn, counts, (int32_t*)nullptr);
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / 64 + DSN_NN_FINE_MAXCELL + 1;
-    hipLaunchKernelGGL(k_nns_search, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
-                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn);
+    hipLaunchKernelGGL(k_nns_search<false>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn, NnsWarp{});
 }

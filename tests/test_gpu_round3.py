@@ -214,3 +214,36 @@ def test_training_row_skip_is_exact(name, monkeypatch):
     for k in grad_s:
         a, b = grad_s[k].double(), grad_d[k].double()
         assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("wname,far_rays", [("", False), ("x_w4", False), ("", True)])
+def test_fused_search_and_warp_equals_the_two_kernel_form(wname, far_rays, monkeypatch):
+    """Round 3: in the fused path the cell-major nearest-face kernel also does the rest of the warp stage (projection, transparency,
+    canonical point, active list).  Against round 2's form (DSN_NN_UNFUSED: search -> nn[] -> k_warp) the frame is bit-identical -
+    also when some rays run far outside the fine grid (their samples take the second, k_warp pass)"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)
+    r = renderer_with(state(wname) if wname else state(), canon, faces)
+    r.eval()
+    r._set_frame(batch)
+    r._screen_usable()
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    n0, f0 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+    if far_rays:                                   # every 7th ray is sampled uniformly up to 2 m behind the body (uniform mode keeps near / far)
+        f0[::7] += 2.0
+    pk = r.net.packed(r.device)
+
+    def run():
+        ws = _lib.RenderWorkspace(r.device)
+        out = _lib.render_rays(r.scene, pk, ws, o, d, n0.clone(), f0.clone(), S, r._t_vals(S), uniform=far_rays)
+        torch.cuda.synchronize()
+        return out, int(ws.buf[:256].view(torch.int32)[_lib.CNT_ACTIVE])
+
+    a, na = run()
+    monkeypatch.setenv("DSN_NN_UNFUSED", "1")
+    b, nb = run()
+    monkeypatch.delenv("DSN_NN_UNFUSED")
+    assert na == nb > 0
+    for k in a:
+        assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
