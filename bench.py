@@ -173,8 +173,12 @@ def main():
         pk = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in state_dict.items()})
         no_screen, screen_info = bool(args.no_screen), None
         if not (args.dense or args.fp32 or args.no_screen):
+            # (like Renderer on the first eval frame of a checkpoint: the geometry phase of the frame, then the margin measured on the
+            #  canonical points of ITS non-transparent samples)
             scene.set_frame(pk, d_xyz, d_poses, 5, False, None, None, None)
-            screen_info = pk.calibrate_screen(scene)
+            _lib.render_rays(scene, pk, ws, ray_o, ray_d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False,
+                             phases=_lib.PHASE_GEOMETRY)
+            screen_info = pk.calibrate_screen(scene, frame=(ws, R, S))
             if not screen_info["usable"] and not args.force_screen:
                 no_screen = True
         stop_info = {"enabled": False}
@@ -201,10 +205,16 @@ def main():
 
     pipe = _lib.PhasePipeline(dev) if (args.overlap == "phase" and depth > 1) else None
 
+    audit_every = dsnerf_amd.can_render.SCREEN_AUDIT_EVERY      # what Renderer does by default (screen_audit = "auto")
+    audit_of = {}
+
     def frame_call(j, phases=0):
+        # (one frame in `audit_every` carries the density screen's audit, like Renderer's default: 1/128 of the samples the screen
+        #  drops take the accurate pass anyway; the frame is bit-identical, the cost is in the measured time)
         outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                    skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
-                                   screen=not cur["no_screen"], early_stop=cur["early"], phases=phases)
+                                   screen=not cur["no_screen"], early_stop=cur["early"], phases=phases,
+                                   audit=audit_of.get(j, False))
 
     def exchange(j):
         if use_dist:
@@ -220,6 +230,7 @@ def main():
         # stream one step later - the small kernels run BESIDE the persistent field workgroups instead of between them
         nonlocal k_step
         j = k_step % depth
+        audit_of[j] = (k_step % audit_every == 0) and not cur["no_screen"] and not (args.dense or args.fp32)
         k_step += 1
 
         def geometry():
@@ -296,7 +307,7 @@ def main():
             "evaluated_sample_fraction": n_active / float(R * S),
             "shaded_sample_fraction": n_pos / float(R * S),
             "density_screen": not (args.dense or args.fp32 or args.no_screen),
-            "density_screen_calibration": screen_info, "weights": args.weights,
+            "density_screen_calibration": screen_info, "density_screen_audit_every_n_frames": audit_every, "weights": args.weights,
             "accurate_pass_sample_fraction": None if n_kept is None else n_kept / float(R * S),
             "early_stop": stop_info,
             "ms_per_frame": ms_step,

@@ -38,7 +38,7 @@ EXPORTS = [
     "dsn_render_workspace_bytes", "dsn_render_rays", "dsn_grad_workspace_bytes", "dsn_render_rays_grad",
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
-    "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps",
+    "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -51,7 +51,8 @@ EARLY_STOP, STOP_STATS = 64, 128
 PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
 CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
 EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
-SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.05      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
+SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.15      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
+SCREEN_HEADROOM = 10.0        # = F16_SCREEN_HEADROOM: every calibration point is this factor in deviation away from a wrong drop
 SCREEN_MIN_DROPPED = 0.35     # PackedParams.calibrate_screen: below this share of dropped calibration points the screen stays off
 RAYS_ZJU, RAYS_H36M = 0, 1
 FRAME_FINE_ONLY = 1           # dsn_set_frame_ex: only the fine nearest-face level of the posed mesh (points beyond it: exhaustive sweep)
@@ -188,43 +189,56 @@ class PackedParams:
         f = min(max(float(self.early_stop.get("skipped_fraction", 0.0)), 0.0), 0.99)
         return sc["dropped_fraction"] / (1.0 - f) >= SCREEN_MIN_DROPPED
 
-    def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20, other_frames=(0, 125, 250, 375, 499)):
+    def calibrate_screen(self, scene: "Scene", n_points: int = 1 << 20, other_frames=(0, 125, 250, 375, 499), frame=None):
         """Measure the density screen's margin for THESE parameters (dsn_calibrate_screen; synchronises: meant to run once per
         checkpoint, Renderer does it lazily before the first eval-mode frame after the parameters changed): on the scene's
         current frame state with n_points points, and - the first layer's bias depends on the frame's embedding row - with the
-        same pose under a spread of other frame codes (`other_frames`, n_points / 4 points each).  The margin is 10x the
-        largest deviation seen anywhere.  Returns / stores dict(deviation, margin, overflow_fraction, points,
+        same pose under a spread of other frame codes (`other_frames`, n_points / 4 points each).  The margin leaves every point
+        seen a factor 10 of headroom in deviation against a wrong drop (include/dsnerf.h: margin = 10 max(dev - rel / 10), at least
+        0.002, +inf above 0.15).  Returns / stores dict(deviation, margin_statistic, margin, overflow_fraction, points,
         dropped_fraction, safe, usable); safe = False: the screen would need a margin above the cap; usable = safe and it
-        drops enough samples to pay for itself."""
+        drops enough samples to pay for itself.
+        frame = (RenderWorkspace, R, S) of a frame whose geometry phase has run (render_rays(..., phases=PHASE_GEOMETRY)): the
+        calibration points are then the canonical points of that frame's non-transparent samples (+ a 2 cm halo) instead of a cube
+        around the canonical centroids - what Renderer and bench.py do: the margin and the share the screen drops are measured on what
+        is rendered (dsn_calibrate_screen_frame)."""
         ws = torch.empty(lib().dsn_calibrate_workspace_bytes(C.c_int64(n_points)), dtype=torch.uint8, device=self.device)
         out = torch.zeros(8, dtype=torch.float32, device=self.device)
 
         def run(n):
-            _check(lib().dsn_calibrate_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), C.c_int64(n), _ptr(ws), _ptr(out),
-                                              _stream()), "dsn_calibrate_screen")
-            return [float(v) for v in out.cpu()[:5]]
+            if frame is not None:       # (render workspace, R, S) of a frame whose geometry phase has run: calibrate on ITS points
+                rws, R_, S_ = frame
+                _check(lib().dsn_calibrate_screen_frame(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), _ptr(rws.buf), int(R_), int(S_),
+                                                        C.c_int64(n), _ptr(ws), _ptr(out), _stream()), "dsn_calibrate_screen_frame")
+            else:
+                _check(lib().dsn_calibrate_screen(_ptr(scene.buf), scene.V, scene.F, _ptr(self.buf), C.c_int64(n), _ptr(ws), _ptr(out),
+                                                  _stream()), "dsn_calibrate_screen")
+            return [float(v) for v in out.cpu()[:6]]
 
-        d, m, ovf, n, dropped = run(n_points)
         state = getattr(scene, "_pose_args", None)          # (poses, frame_idx, zero_code, light_shift, rot, rot_center) of set_frame
-        total = n
+        d = t = ovf = 0.0
+        total = 0
         if state is not None and not state[2] and other_frames:
             poses, frame_idx, zero_code, ls, r, rc = state
             for f in other_frames:
                 if f == frame_idx:
                     continue
                 _set_pose(scene.buf, self, poses, None, f, zero_code, ls, r, rc, self.device)
-                d2, _, ovf2, n2, _ = run(max(n_points // 4, 1024))
-                d, ovf, total = max(d, d2), max(ovf, ovf2), total + n2
+                d2, _, ovf2, n2, _, t2 = run(max(n_points // 4, 1024))
+                d, t, ovf, total = max(d, d2), max(t, t2), max(ovf, ovf2), total + n2
             _set_pose(scene.buf, self, poses, None, frame_idx, zero_code, ls, r, rc, self.device)      # back to the frame's own state
-            m = max(10.0 * d, SCREEN_MARGIN_FLOOR)
-            m = m if m <= SCREEN_MARGIN_CAP else float("inf")
-            _check(lib().dsn_set_screen_margin(_ptr(self.buf), C.c_float(m), _stream()), "dsn_set_screen_margin")
+        # the frame's own state last, with the other states' statistic carried in (out[7]): the margin it leaves in the packed image and
+        # the share of points it counts as dropped are those of the joint set
+        out[7:8].fill_(t)
+        d1, m, ovf1, n1, dropped, t = run(n_points)
+        d, ovf, total = max(d, d1), max(ovf, ovf1), total + n1
         safe = bool(m < float("inf"))
         # The screen costs ~0.3 of an accurate forward pass per sample (k_screen16 0.71 us vs k_field16<forward> 2.36 us per
         # thousand samples): it pays only if it drops more than that share.  A network that is dense everywhere near the
         # surface (every calibration point sigma > 0) is better off without it.
-        self.screen = {"deviation": d, "margin": m, "overflow_fraction": ovf, "points": int(total), "dropped_fraction": dropped,
-                       "safe": safe, "usable": safe and dropped >= SCREEN_MIN_DROPPED}
+        self.screen = {"deviation": d, "margin_statistic": t, "margin": m, "overflow_fraction": ovf, "points": int(total),
+                       "dropped_fraction": dropped, "safe": safe, "usable": safe and dropped >= SCREEN_MIN_DROPPED,
+                       "points_from": "frame" if frame is not None else "centroid cube"}
         return self.screen
 
     def set_screen_margin(self, margin: float):

@@ -47,6 +47,7 @@ def load_bodydata(model_type="smpl", gender="neutral", model_path=""):
 
 
 _OUT_KEYS = ("color", "disp_map", "acc_map", "depth_map", "weights", "z_vals")
+SCREEN_AUDIT_EVERY = 8        # Renderer.screen_audit = "auto": one eval frame in this many carries the density screen's audit
 
 
 class _HostPoolGuard:
@@ -168,7 +169,13 @@ class Renderer:
         self._slots = []
         self.skip_transparent = True      # eval mode: networks only on non-transparent samples (exact)
         self.density_screen = True        # eval mode: plain-fp16 screen in front of the accurate pass (exact by its margin)
-        self.screen_audit = False         # eval mode: re-check 1/128 of the screened-out samples every frame
+        # eval mode: re-check 1/128 of the screened-out samples.  True: every frame (read with last_screen_audit()); "auto" (default):
+        # the first frame after a calibration and every SCREEN_AUDIT_EVERY-th one after it, read back WITHOUT a wait at the start
+        # of a later frame - a violation (a dropped sample whose accurate density is positive) switches the screen off with a
+        # warning.  The margin is calibrated on one pose: this is what watches every other pose in production.
+        self.screen_audit = "auto"
+        self._audit_probe = None          # (count words, event) of an audited frame still to be looked at
+        self._audit_frames = 0
         self.screen_info = None           # what the last calibration of the screen found (PackedParams.calibrate_screen)
         # eval mode: front-to-back slices with ray termination (DSN_EARLY_STOP; pixel error < 64 * 2^-20 x colour).  "auto": the first
         # eval frame of a parameter version also counts what termination would leave out (DSN_STOP_STATS); from the next frame
@@ -274,18 +281,22 @@ class Renderer:
             self._mark_frame_src(batch["xyz"])
         return (xyz, poses, frame, zero_code, ls, rot, rc)
 
-    def _screen_usable(self):
+    def _screen_usable(self, frame=None):
         """eval mode: is the density screen on for this frame?  Calibrates its margin for the current parameters first
-        (once per parameter version: synchronises then).  Needs the scene's frame state to be set."""
+        (once per parameter version: synchronises then).  Needs the scene's frame state to be set.  frame = (scene, workspace, R, S)
+        of a frame whose geometry phase has run: the calibration then uses that frame's own canonical points (what _render_eval
+        does on the first eval frame of a parameter version); without it, a cube around the canonical centroids."""
         if not (self.density_screen and self.skip_transparent):
             return False
         packed = self.net.packed(self.device)
         if packed.screen is None:
-            info = packed.calibrate_screen(self.scene)
+            info = packed.calibrate_screen(self.scene) if frame is None else packed.calibrate_screen(frame[0], frame=frame[1:])
             self.screen_info = dict(info)
             if not info["safe"]:
-                warnings.warn("dsnerf_amd: the plain-fp16 density screen deviates by %.3g of the term magnitude for these parameters "
-                              "(cap 0.005): it stays off, every non-transparent sample takes the accurate pass" % info["deviation"])
+                warnings.warn("dsnerf_amd: the plain-fp16 density screen would need a margin of %.3g of the term magnitude for these "
+                              "parameters (cap %.3g; largest deviation %.3g): it stays off, every non-transparent sample takes the "
+                              "accurate pass" % (_lib.SCREEN_HEADROOM * info["margin_statistic"], _lib.SCREEN_MARGIN_CAP,
+                                                 info["deviation"]))
         return packed.screen_pays(self._early_stop_in_use(packed))
 
     def _early_stop_in_use(self, packed):
@@ -478,19 +489,70 @@ class Renderer:
                     stop = packed.early_stop["usable"]
             else:
                 stop = bool(self.early_stop)
+        audit = False
+        if screen:
+            self._read_audit_probe()
+            screen = screen and self.density_screen        # (a violation found just now has switched it off)
+            if self.screen_audit == "auto":
+                audit = self._audit_probe is None and self._audit_frames % SCREEN_AUDIT_EVERY == 0
+                self._audit_frames += 1
+            else:
+                audit = bool(self.screen_audit)
         return {"skip_transparent": skip, "uniform": (self.sample_points_mode == "uniform"), "screen": screen,
-                "audit": self.screen_audit, "early_stop": stop, "stop_stats": stats}
+                "audit": audit, "early_stop": stop, "stop_stats": stats}
 
     def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None, plan=None, phases=0, out=None):
-        plan = self._eval_plan(noise, screen) if plan is None else plan
         packed = self.net.packed(self.device)
+        if (plan is None and screen is None and phases == 0 and noise is None and packed.screen is None and self.density_screen
+                and self.skip_transparent and not self.net.training):
+            # First eval frame of a parameter version: its geometry phase first (sampler, warp: the canonical points of its
+            # non-transparent samples), the density screen's margin calibrated on THOSE points, then the rest of the frame.
+            geo = {"skip_transparent": True, "uniform": (self.sample_points_mode == "uniform"), "screen": True, "audit": False,
+                   "early_stop": False, "stop_stats": False}
+            out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=_lib.PHASE_GEOMETRY,
+                                   out=out, **geo)
+            self._screen_usable(frame=(scene, ws, o.shape[0], S))
+            phases = _lib.PHASE_FIELD | _lib.PHASE_SHADE
+        plan = self._eval_plan(noise, screen) if plan is None else plan
+        # what this frame ran with (early stop is the one default-on feature whose output is error-bounded, not
+        # bit-identical - a caller can see per frame whether it was in use and with which threshold)
+        self.last_frame_info = {"density_screen": bool(plan["screen"]), "screen_audit": bool(plan["audit"]),
+                                "early_stop": bool(plan["early_stop"]),
+                                "early_stop_eps": _lib.early_stop_eps(S) if plan["early_stop"] else None,
+                                "early_stop_bound_x_max_colour": (S + 1) * _lib.early_stop_eps(S) if plan["early_stop"] else 0.0}
         out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out, **plan)
         if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
             snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
             ev = torch.cuda.Event()
             ev.record()
             self._stop_probe = (packed.generation, snap, ev)
+        if plan["audit"] and self.screen_audit == "auto" and (phases == 0 or phases & _lib.PHASE_SHADE):
+            snap = ws.buf[:256].clone()
+            ev = torch.cuda.Event()
+            ev.record()
+            self._audit_probe = (snap, ev)
         return out
+
+    def _read_audit_probe(self, wait=False):
+        """screen_audit = "auto": look at the counters of an audited frame once it has finished (no wait unless asked)"""
+        if self._audit_probe is None:
+            return None
+        snap, ev = self._audit_probe
+        if not wait and not ev.query():
+            return None
+        ev.synchronize()
+        self._audit_probe = None
+        return self._judge_audit(snap.view(torch.int32).cpu())
+
+    def _judge_audit(self, c):
+        res = {"audited": int(c[_lib.CNT_AUDIT]), "violations": int(c[_lib.CNT_AUDIT + 4]),
+               "max_sigma": float(c[_lib.CNT_AUDIT + 5:_lib.CNT_AUDIT + 6].view(torch.float32)[0])}
+        self.last_audit = res
+        if res["violations"] > 0 and self.density_screen:
+            self.density_screen = False
+            warnings.warn("dsnerf_amd: the density screen dropped samples with positive density (%d of %d audited, max sigma %.3g): "
+                          "screen switched off" % (res["violations"], res["audited"], res["max_sigma"]))
+        return res
 
     def _read_stop_probe(self, wait=False):
         """early_stop = "auto": pick up the statistics of the probe frame once it has finished (no wait unless asked)."""
@@ -509,21 +571,17 @@ class Renderer:
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED}
 
     def last_screen_audit(self, ws=None):
-        """(screen_audit = True) what the audit of the last eval frame found - synchronises.  dict(audited, violations,
-        max_sigma): `violations` audited samples (declared empty by the screen) have an accurate density > 0; they were rendered
-        correctly (audited samples take the accurate pass), but their un-audited peers were not, so the screen is switched off
-        for this renderer when it happens."""
+        """what the audit of the last audited eval frame found - synchronises.  dict(audited, violations, max_sigma): `violations`
+        audited samples (declared empty by the screen) have an accurate density > 0; they were rendered correctly (audited samples
+        take the accurate pass), but their un-audited peers were not, so the screen is switched off for this renderer when it
+        happens.  With screen_audit = "auto" this is the pending audited frame if there is one, else the last one judged."""
+        if self.screen_audit == "auto":
+            res = self._read_audit_probe(wait=True)
+            return res if res is not None else getattr(self, "last_audit", None)
         ws = ws or self._ws
         if ws.buf is None:
             return None
-        c = ws.buf[:256].view(torch.int32).cpu()
-        res = {"audited": int(c[_lib.CNT_AUDIT]), "violations": int(c[_lib.CNT_AUDIT + 4]),
-               "max_sigma": float(c[_lib.CNT_AUDIT + 5:_lib.CNT_AUDIT + 6].view(torch.float32)[0])}
-        if res["violations"] > 0 and self.density_screen:
-            self.density_screen = False
-            warnings.warn("dsnerf_amd: the density screen dropped samples with positive density (%d of %d audited, max sigma %.3g): "
-                          "screen switched off" % (res["violations"], res["audited"], res["max_sigma"]))
-        return res
+        return self._judge_audit(ws.buf[:256].view(torch.int32).cpu())
 
     # Training steps whose activations / tangents / adjoints left the fp16 range of the split-fp16 kernels have no exact twin to fall
     # back to: the forward counts such samples (workspace word 48), the backward drops their second-order / adjoint terms and counts
@@ -575,8 +633,8 @@ class Renderer:
         R = o.shape[0]
         chunk = R if chunk is None else int(chunk)
         screen = None
-        if scene is not self.scene:      # calibration runs on the renderer's own scene (any frame state of these parameters)
-            pk = self.net.packed(self.device)
+        pk = self.net.packed(self.device)
+        if scene is not self.scene and pk.screen is not None:      # (not calibrated yet: _render_eval does it on this frame's points)
             screen = self.skip_transparent and not self.net.training and self.density_screen and pk.screen_pays(self._early_stop_in_use(pk))
         outs = []
         for i in range(0, R, chunk):
@@ -636,16 +694,8 @@ class Renderer:
         cur = torch.cuda.current_stream(self.device)
         self.net.packed(self.device)                         # shared, read-only state is materialised on the caller's stream
         self._t_vals(self.cfg.MODEL.COARSE_RAY_SAMPLING)
-        if not self.net.training and self.density_screen and self.skip_transparent:
-            batches = iter(batches)
-            first = next(batches, None)
-            if first is None:
-                return []
-            if self.net.packed(self.device).screen is None:     # calibrate on the first frame's state, on the caller's stream
-                self._set_frame(first)
-                self._screen_usable()
-            import itertools
-            batches = itertools.chain([first], batches)
+        # (the density screen is calibrated by the first frame itself, on its own points: _render_eval; slot 0 is the renderer's own
+        #  scene and its frame is enqueued first)
         keys = ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")
         results = []
         for k, batch in enumerate(batches):

@@ -474,6 +474,18 @@ size_t dsn_render_workspace_bytes(int R, int S) {
     return dsn_carve(nullptr, R, S).bytes;
 }
 
+// the same calibration on the points of a FRAME: see dsnerf.h
+int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, const void* render_workspace, int R, int S,
+                               int64_t n_points, void* workspace, float* out4, void* stream) {
+    DSN_REQUIRE(scene && packed && workspace && render_workspace, "dsn_calibrate_screen_frame: null argument");
+    DSN_REQUIRE(V > 0 && F > 0 && n_points > 0 && R > 0 && S > 0, "dsn_calibrate_screen_frame: bad sizes");
+    DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    const DsnWorkspace w = dsn_carve((void*)render_workspace, R, S);
+    dsn_launch_calibrate_screen(s, (float*)packed, n_points, workspace, out4, (hipStream_t)stream, w.x_c, w.active, w.count + DSN_CNT_ACTIVE);
+    return dsn_check_launch("dsn_calibrate_screen_frame");
+}
+
+
 int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,

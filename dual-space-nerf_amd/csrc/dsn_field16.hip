@@ -1789,8 +1789,20 @@ void dsn_launch_screen_audit(const int32_t* audit_list, const int32_t* audit_cou
 // margin = 10 d, at least F16_SCREEN_FLOOR; above F16_SCREEN_CAP the screen is useless for this network: margin = +inf.
 // ---------------------------------------------------------------------------------------------
 #define F16_SCREEN_FLOOR 0.002f
-#define F16_SCREEN_CAP 0.05f
-__global__ void __launch_bounds__(256) k_calib_points(const float4* __restrict__ cent, int F, int64_t n, float* __restrict__ x) {
+#define F16_SCREEN_CAP 0.15f
+#define F16_SCREEN_HEADROOM 10.0f
+// The margin rule (round 3).  With sigma~ the screen's density, sigma the accurate one, S1 the magnitude of the summed terms and
+// dev = |sigma~ - sigma| / (S1 + 1), rel = |sigma| / (S1 + 1): a sample is dropped WRONGLY iff sigma > 0 and sigma~ < -m (S1 + 1), which
+// needs dev > m + rel.  The margin gives every calibration point the same headroom K = 10 in DEVIATION against that condition,
+//     K dev <= m + rel   for all points   <=>   m = K max(dev - rel / K),
+// floored at 0.002 and switched off (+inf) above 0.15.  Round 2 used m = K max(dev), the same rule with rel taken as 0: equal for
+// networks whose density is small against its terms (the hash-initialised sets: rel ~ 1 / 20), tighter than needed where the large
+// deviations sit at large |sigma|.  The CONVERGED set (w4) is what the cap is for: its empty space is strongly negative (sigma ~
+// -S1 / 2: a margin of 0.2 would still drop 99.8 % of it), but around sigma = 0 its fp16 evaluation is off by 2-5 % of S1 - the
+// maximum over a million points of a heavy-tailed quantity (p99: 0.3 %), which came out at 0.022 on one frame and 0.050 on another.
+// A margin of 0.2-0.5 on that footing is a statistical bet, not a bound: the screen stays off for such parameters
+// (profiles/r03_w4_screen_calibration.txt).
+__global__ void __launch_bounds__(256) k_calib_points(const float4* __restrict__ cent, int F, int64_t n, float* __restrict__ x, float box) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 c = cent[(int)(i % F)];
@@ -1798,29 +1810,64 @@ __global__ void __launch_bounds__(256) k_calib_points(const float4* __restrict__
     float o[3];
     for (int k = 0; k < 3; ++k) {
         h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-        o[k] = ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.3f;
+        o[k] = ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * box;
     }
     x[3 * i] = c.x + o[0]; x[3 * i + 1] = c.y + o[1]; x[3 * i + 2] = c.z + o[2];
 }
+// calibration points from a FRAME (round 3): the canonical points of its non-transparent samples (x_c [N,3], list / *count as the
+// geometry phase of dsn_render_rays leaves them), every point taken as it is for the first half of the set and moved by a hash
+// offset of up to +-halo per axis for the second half (the neighbourhood other rays / poses of the sequence will visit); a frame
+// without non-transparent samples falls back to the centroid cube
+__global__ void __launch_bounds__(256) k_calib_points_frame(const float* __restrict__ x_c, const int32_t* __restrict__ list,
+                                                             const int32_t* __restrict__ count, const float4* __restrict__ cent, int F,
+                                                             int64_t n, float halo, float box, float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t cnt = (int64_t)(*count);
+    uint32_t h = (uint32_t)i * 2654435761u + 0x9e3779b9u;
+    float o[3];
+    for (int k = 0; k < 3; ++k) {
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        o[k] = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+    }
+    if (cnt <= 0) {
+        const float4 c = cent[(int)(i % F)];
+        x[3 * i] = c.x + o[0] * box; x[3 * i + 1] = c.y + o[1] * box; x[3 * i + 2] = c.z + o[2] * box;
+        return;
+    }
+    const int64_t half = n / 2 > 0 ? n / 2 : 1;
+    const int64_t k = i % half;                                   // both halves walk the same evenly spread subset of the list
+    const int64_t slot = (int64_t)(((__int128)k * cnt) / half) % cnt;
+    const int64_t s = (int64_t)list[slot];
+    const float j = i >= half ? 2.0f * halo : 0.0f;
+    x[3 * i] = x_c[3 * s] + o[0] * j; x[3 * i + 1] = x_c[3 * s + 1] + o[1] * j; x[3 * i + 2] = x_c[3 * s + 2] + o[2] * j;
+}
 __global__ void __launch_bounds__(256) k_calib_reduce(const float* __restrict__ sg, const float* __restrict__ s1,
                                                       const float* __restrict__ sig, int64_t n, uint32_t* __restrict__ acc) {
-    float d = 0.0f;
+    float d = 0.0f, t = 0.0f;
     int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float a = sg[i], b = s1[i], c = sig[i];
         const float q = fabsf(a - c) / (b + 1.0f);
-        if (q == q && fabsf(q) < INFINITY) d = fmaxf(d, q); else ++bad;     // fp16 overflow inside the screen: sample is kept anyway
+        if (q == q && fabsf(q) < INFINITY) {
+            d = fmaxf(d, q);                                                 // largest deviation (reported)
+            t = fmaxf(t, q - fabsf(c) / (F16_SCREEN_HEADROOM * (b + 1.0f)));  // what the margin is made from (see above; >= 0)
+        } else ++bad;     // fp16 overflow inside the screen: sample is kept anyway
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { d = fmaxf(d, __shfl_xor(d, o)); bad += __shfl_xor(bad, o); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(acc, __float_as_uint(d)); atomicAdd(acc + 1, (uint32_t)bad); }
+    for (int o = 32; o >= 1; o >>= 1) { d = fmaxf(d, __shfl_xor(d, o)); t = fmaxf(t, __shfl_xor(t, o)); bad += __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(acc, __float_as_uint(d)); atomicAdd(acc + 1, (uint32_t)bad); atomicMax(acc + 3, __float_as_uint(t)); }
 }
 __global__ void k_calib_finish(const uint32_t* __restrict__ acc, float* __restrict__ packed_margin, float* __restrict__ out4, float n) {
+    // out4[7] (input, >= 0): the statistic carried over from calibrations of other frame states of the same parameters - the margin and
+    // the dropped share (out4[4]) are then those of the joint set
     const float d = __uint_as_float(acc[0]);
-    float m = fmaxf(10.0f * d, F16_SCREEN_FLOOR);
+    float t = __uint_as_float(acc[3]);
+    if (out4 && out4[7] > t) t = out4[7];
+    float m = fmaxf(F16_SCREEN_HEADROOM * t, F16_SCREEN_FLOOR);
     if (!(m <= F16_SCREEN_CAP)) m = INFINITY;
     *packed_margin = m;
-    if (out4) { out4[0] = d; out4[1] = m; out4[2] = (float)acc[1] / n; out4[3] = n; }
+    if (out4) { out4[0] = d; out4[1] = m; out4[2] = (float)acc[1] / n; out4[3] = n; out4[5] = t; }
 }
 // how many of the calibration points the screen drops with the margin just set (out4[4] = fraction): tells the caller whether
 // the screen pays for itself on this network (a network that is dense everywhere near the surface keeps every sample)
@@ -1835,7 +1882,8 @@ __global__ void __launch_bounds__(256) k_calib_dropped(const float* __restrict__
 }
 __global__ void k_calib_dropped_finish(const uint32_t* __restrict__ acc, float* __restrict__ out, float n) { out[4] = (float)acc[2] / n; }
 size_t dsn_calibrate_workspace_size(int64_t n) { return 256 + dsn_align256(12 * (size_t)n) + 4 * dsn_align256(4 * (size_t)n); }
-void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st) {
+void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st,
+                                 const float* frame_x_c, const int32_t* frame_list, const int32_t* frame_count) {
     char* p = (char*)workspace;
     uint32_t* acc = (uint32_t*)p;             p += 256;
     float* x = (float*)p;                     p += dsn_align256(12 * (size_t)n);
@@ -1844,7 +1892,13 @@ void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n
     float* sig = (float*)p;                   p += dsn_align256(4 * (size_t)n);
     int32_t* lst = (int32_t*)p;
     (void)hipMemsetAsync(acc, 0, 256, st);
-    hipLaunchKernelGGL(k_calib_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.cent_canon, s.F, n, x);
+    const char* be = getenv("DSN_CALIB_BOX");      // (experiments: edge of the cube of offsets around the canonical centroids, metres)
+    const float box = be ? (float)atof(be) : 0.3f;
+    if (frame_x_c)
+        hipLaunchKernelGGL(k_calib_points_frame, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frame_x_c, frame_list, frame_count,
+                           s.cent_canon, s.F, n, 0.02f, box, x);
+    else
+        hipLaunchKernelGGL(k_calib_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.cent_canon, s.F, n, x, box);
     dsn_launch_screen16(packed, s.frame, x, n, nullptr, nullptr, sg, lst, (int32_t*)(acc + 8), sg, s1, st, nullptr, nullptr, 0);
     dsn_launch_field(packed, s.frame, x, n, nullptr, nullptr, sig, nullptr, nullptr, st);
     hipLaunchKernelGGL(k_calib_reduce, dim3(1024), dim3(256), 0, st, sg, s1, sig, n, acc);

@@ -66,7 +66,9 @@ void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const flo
 void dsn_launch_screen_audit(const int32_t* audit_list, const int32_t* audit_count, int audit_cap, const float* sigma, int32_t* out,
                              hipStream_t st);
 size_t dsn_calibrate_workspace_size(int64_t n);
-void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st);
+void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n, void* workspace, float* out4, hipStream_t st,
+                                 const float* frame_x_c = nullptr, const int32_t* frame_list = nullptr,
+                                 const int32_t* frame_count = nullptr);
 void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st);
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,

@@ -278,13 +278,14 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
 // ---------------------------------------------------------------------------------------------
 // Cell-major query of the fine lists (fused path).  k_warp's per-lane list scan is bound by the vector L1
 // return path: every lane pulls 16 B per candidate (~290 candidates per sample) even when neighbouring lanes
-// read the same entry.  Here the samples are counting-sorted by fine cell first; one wave then owns 64 samples
+// read the same entry.  Here the samples are counting-sorted by fine cell first; one wave then owns 128 samples (two per lane)
 // of ONE cell, the candidate list is read through the scalar cache (uniform address -> s_load, operands in
 // SGPRs) and only the distance arithmetic runs on the VALU.  Same list, same order, same fma chain, same strict
 // '<' as dsn_nearest_lists, hence the same index bit for bit.  Samples outside the fine grid keep nn = -1 and
 // are searched by k_warp as before.
 // ---------------------------------------------------------------------------------------------
 #define NNS_THREADS 256
+#define NNS_PER 128           // samples of one cell a wave of k_nns_search takes (two per lane)
 
 __device__ __forceinline__ void nns_point(const float* __restrict__ pts, const float* __restrict__ ray_o,
                                           const float* __restrict__ ray_d, const float* __restrict__ z_vals, int64_t i, int S,
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
     }
 }
 
-// exclusive scans over the cells: sample offsets and wave offsets (ceil(count / 64) waves per cell); counts are
+// exclusive scans over the cells: sample offsets and wave offsets (ceil(count / NNS_PER) waves per cell); counts are
 // cleared for their second life as scatter cursors.  Single workgroup, LDS-staged tiles (see k_grid_scan).
 __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
         __syncthreads();
         int v[SCAN_PER], a = 0, b = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; a += v[k]; b += (v[k] + 63) >> 6; }
+        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; a += v[k]; b += (v[k] + NNS_PER - 1) / NNS_PER; }
         int tot_a, tot_b;
         int ra = carry_a + dsn_block_exscan(a, s_w, tot_a);
         int rb = carry_b + dsn_block_exscan(b, s_w, tot_b);
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
         for (int i = t; i < 1024 * SCAN_PER; i += 1024) if (base + i < ncell) offs[base + i] = s_n[i];
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += (v[k] + 63) >> 6; }
+        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += (v[k] + NNS_PER - 1) / NNS_PER; }
         __syncthreads();
         for (int i = t; i < 1024 * SCAN_PER; i += 1024)
             if (base + i < ncell) { wave_offs[base + i] = s_n[i]; counts[base + i] = 0; }
@@ -437,69 +438,86 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
     if (WARP ? (int)(vb * (NNS_THREADS / 64)) >= nwaves : w >= nwaves) return;      // (WARP: block-uniform - the append below has barriers)
     const bool wave_on = w < nwaves;
     const int c = __builtin_amdgcn_readfirstlane(wave_cell[wave_on ? w : 0]);
-    const int slot = (w - __builtin_amdgcn_readfirstlane(wave_offs[c])) * 64 + lane;
-    const bool valid = wave_on && slot < __builtin_amdgcn_readfirstlane(counts[c]);
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) q = sorted[__builtin_amdgcn_readfirstlane(offs[c]) + slot];
-    const float p[3] = {q.x, q.y, q.z};
+    // TWO samples per lane (slots lane and lane + 64 of the wave's 128): the distance arithmetic runs on packed fp32
+    // (v_pk_add / v_pk_mul / v_pk_fma_f32 with the candidate broadcast from SGPRs: 6 instructions per candidate and PAIR of samples
+    // instead of 12 - the same IEEE operations per component, so the same distances bit for bit); compare + select stay per sample
+    const int slot = (w - __builtin_amdgcn_readfirstlane(wave_offs[c])) * NNS_PER + lane;
+    const int cnt_c = __builtin_amdgcn_readfirstlane(counts[c]);
+    const bool valid[2] = {wave_on && slot < cnt_c, wave_on && slot + 64 < cnt_c};
+    float4 q[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const int so = __builtin_amdgcn_readfirstlane(offs[c]);
+    if (valid[0]) q[0] = sorted[so + slot];
+    if (valid[1]) q[1] = sorted[so + slot + 64];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 px = {q[0].x, q[1].x}, py = {q[0].y, q[1].y}, pz = {q[0].z, q[1].z};
     const int o = __builtin_amdgcn_readfirstlane(off_f[c]);
     const int n = wave_on ? __builtin_amdgcn_readfirstlane(off_f[c + 1]) - o : 0;
     const float4* __restrict__ e = list_f + o;
-    float best = INFINITY;
-    int bi = 0;
+    float best[2] = {INFINITY, INFINITY};
+    int bi[2] = {0, 0};
+    // squared distance exactly as dsn_d2: dx * dx, then fma(dy, dy, .), then fma(dz, dz, .) - per component of the pair
+    auto step = [&](const float4 a) {
+        const f32x2 cx = {a.x, a.x}, cy = {a.y, a.y}, cz = {a.z, a.z};
+        const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
+        f32x2 d = dx * dx;
+        d = __builtin_elementwise_fma(dy, dy, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+        const int id = __float_as_int(a.w);
+        if (d.x < best[0]) { best[0] = d.x; bi[0] = id; }
+        if (d.y < best[1]) { best[1] = d.y; bi[1] = id; }
+    };
     int k = 0;
     for (; k + 8 <= n; k += 8) {                     // wave-uniform addresses: 128 B of candidates per scalar-load batch
         float4 a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = e[k + j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = dsn_d2(p[0], p[1], p[2], a[j]);
-            if (d < best) { best = d; bi = __float_as_int(a[j].w); }
-        }
+        for (int j = 0; j < 8; ++j) step(a[j]);
     }
-    for (; k < n; ++k) {
-        const float4 a = e[k];
-        const float d = dsn_d2(p[0], p[1], p[2], a);
-        if (d < best) { best = d; bi = __float_as_int(a.w); }
-    }
+    for (; k < n; ++k) step(e[k]);
     if (!WARP) {
-        if (valid) nn[__float_as_int(q.w)] = bi;
+        if (valid[0]) nn[__float_as_int(q[0].w)] = bi[0];
+        if (valid[1]) nn[__float_as_int(q[1].w)] = bi[1];
         return;
     }
-    bool active = false;
-    const int64_t i = (int64_t)__float_as_int(q.w);
-    if (valid) {
-        const DsnFaceRec fw = dsn_load_face(wp.face_world, bi);
-        float u, v, h, xc[3] = {0.f, 0.f, 0.f};
-        dsn_project(p, fw, u, v, h);
-        const bool tr = (u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f);
-        if (!(tr && wp.lazy_canon)) {
-            const DsnFaceRec fc = dsn_load_face(wp.face_canon, bi);
-            dsn_map2face(u, v, h, fc, xc);
+    bool active[2] = {false, false};
+    int64_t idx[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        idx[h2] = (int64_t)__float_as_int(q[h2].w);
+        if (valid[h2]) {
+            const float p[3] = {q[h2].x, q[h2].y, q[h2].z};
+            const DsnFaceRec fw = dsn_load_face(wp.face_world, bi[h2]);
+            float u, v, h, xc[3] = {0.f, 0.f, 0.f};
+            dsn_project(p, fw, u, v, h);
+            const bool tr = (u > 5.f) || (u < -4.f) || (v > 5.f) || (v < -4.f) || (fabsf(h) > 0.1f);
+            if (!(tr && wp.lazy_canon)) {
+                const DsnFaceRec fc = dsn_load_face(wp.face_canon, bi[h2]);
+                dsn_map2face(u, v, h, fc, xc);
+            }
+            const int64_t i = idx[h2];
+            wp.transparent[i] = tr ? 1 : 0;
+            wp.x_c[3 * i] = xc[0]; wp.x_c[3 * i + 1] = xc[1]; wp.x_c[3 * i + 2] = xc[2];
+            active[h2] = !tr;
         }
-        wp.transparent[i] = tr ? 1 : 0;
-        wp.x_c[3 * i] = xc[0]; wp.x_c[3 * i + 1] = xc[1]; wp.x_c[3 * i + 2] = xc[2];
-        active = !tr;
     }
-    if (wp.active_list) {      // workgroup-aggregated append, as in k_warp: one atomic per 256 samples
-        __shared__ int s_cnt[NNS_THREADS / 64];
+    if (wp.active_list) {      // workgroup-aggregated append, as in k_warp: one atomic per 512 samples
+        __shared__ int s_cnt[NNS_THREADS / 64][2];
         __shared__ int s_base;
-        const unsigned long long m = __ballot(active);
+        const unsigned long long m0 = __ballot(active[0]), m1 = __ballot(active[1]);
         const int wave = threadIdx.x >> 6;
-        if (lane == 0) s_cnt[wave] = __popcll(m);
+        if (lane == 0) { s_cnt[wave][0] = __popcll(m0); s_cnt[wave][1] = __popcll(m1); }
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
-            for (int k = 0; k < NNS_THREADS / 64; ++k) tot += s_cnt[k];
+            for (int kk = 0; kk < NNS_THREADS / 64; ++kk) tot += s_cnt[kk][0] + s_cnt[kk][1];
             s_base = tot ? atomicAdd(wp.active_count, tot) : 0;
         }
         __syncthreads();
-        if (active) {
-            int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
-            for (int k = 0; k < wave; ++k) off += s_cnt[k];
-            wp.active_list[off] = (int32_t)i;
-        }
+        int off = s_base;
+        for (int kk = 0; kk < wave; ++kk) off += s_cnt[kk][0] + s_cnt[kk][1];
+        if (active[0]) wp.active_list[off + __popcll(m0 & ((1ull << lane) - 1ull))] = (int32_t)idx[0];
+        if (active[1]) wp.active_list[off + s_cnt[wave][0] + __popcll(m1 & ((1ull << lane) - 1ull))] = (int32_t)idx[1];
     }
 }
 
@@ -524,7 +542,7 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
-    const int64_t max_waves = N / 64 + DSN_NN_FINE_MAXCELL + 1;
+    const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
     hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
                        wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, (int32_t*)nullptr, wp);
@@ -551,7 +569,7 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
-    const int64_t max_waves = N / 64 + DSN_NN_FINE_MAXCELL + 1;
+    const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     hipLaunchKernelGGL(k_nns_search<false>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
                        wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn, NnsWarp{});
 }

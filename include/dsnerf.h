@@ -185,7 +185,7 @@ DSN_EXPORT int dsn_image_psnr(const float* img_rgb, const double* gt_f64, const 
                    int H, int W, double* out4, void* workspace, void* stream);
 
 /* The density screen as a stage (what dsn_render_rays runs first in eval mode): for the listed points (or all N) the
- * plain-fp16 trunk; points whose fp16 density is negative by the safety margin (36x the largest fp16-vs-fp32 deviation measured) get that negative value in sigma [N] and are dropped, the
+ * plain-fp16 trunk; points whose fp16 density is negative by the safety margin (calibrated for the parameters: dsn_calibrate_screen) get that negative value in sigma [N] and are dropped, the
  * others are appended to keep_list (keep_count zeroed by the caller) for dsn_field_forward. */
 DSN_EXPORT int dsn_field_screen(const void* scene, int V, int F, const void* packed, const float* x_c, int64_t N,
                      const int32_t* active_list, const int32_t* active_count, float* sigma, int32_t* keep_list,
@@ -193,12 +193,24 @@ DSN_EXPORT int dsn_field_screen(const void* scene, int V, int F, const void* pac
 
 /* The screen's margin is a property of the PARAMETERS and travels in `packed`: dsn_pack_params writes the conservative default
  * (0.01); dsn_calibrate_screen measures it for the packed parameters and the scene's current frame state - n_points points
- * around the canonical surface, screen vs exact-fp32 density, margin = max(10 x the largest deviation |sigma~ - sigma| /
- * (S1 + 1), 0.002), or +inf (nothing is ever declared empty) when that exceeds 0.05 - and writes it into `packed`, all on the
- * stream.  out (device, optional, 8 floats) = {largest deviation, margin, fraction of points the screen overflowed on,
- * n_points, fraction of the points the screen drops with that margin (the caller's cue whether the screen pays: it costs
- * ~0.3 of an accurate forward pass per sample), 0, 0, 0}.  dsn_set_screen_margin sets it by hand.  workspace: dsn_calibrate_workspace_bytes(n_points). */
+ * around the canonical surface, screen density sigma~ and magnitude S1 against the exact-fp32 density sigma.  With
+ * dev = |sigma~ - sigma| / (S1 + 1) and rel = |sigma| / (S1 + 1) a sample is dropped wrongly iff sigma > 0 and dev > margin + rel, so
+ * the margin leaves every calibration point a factor 10 of headroom in deviation:  margin = max(10 max(dev - rel / 10), 0.002), or
+ * +inf (nothing is ever declared empty) when that exceeds 0.15 - and writes it into `packed`, all on the stream.
+ * out (device, optional, 8 floats) = {largest deviation max(dev), margin, fraction of points the screen overflowed on, n_points,
+ * fraction of the points the screen drops with that margin (the caller's cue whether the screen pays: it costs ~0.3 of an accurate
+ * forward pass per sample), the statistic max(dev - rel / 10), 0, [7]}; out[7] is an INPUT: the statistic of earlier calls on other
+ * frame states of the same parameters (0 = none), folded into the margin and the dropped share of this call.
+ * dsn_set_screen_margin sets the margin by hand.  workspace: dsn_calibrate_workspace_bytes(n_points). */
 DSN_EXPORT size_t dsn_calibrate_workspace_bytes(int64_t n_points);
+/* The same calibration on the points that are being RENDERED (round 3): `render_workspace` holds a frame of R rays x S samples
+ * behind the geometry phase of dsn_render_rays (DSN_PHASE_GEOMETRY with DSN_SKIP_TRANSPARENT - or a whole frame); the n_points
+ * calibration points are the canonical points of its non-transparent samples, evenly spread over the list - as they are for the first
+ * half of the set, moved by up to +-2 cm per axis for the second half.  The cube around the canonical centroids that
+ * dsn_calibrate_screen draws from (+-0.15 m) reaches far outside the |h| <= 0.1 m shell a non-transparent sample can lie in
+ * (utils/render_utils.py:103-109) and - for a trained field - outside everything the training ever saw; what is never rendered
+ * should not set the margin, what is rendered must.  Same `out`, same workspace size; a frame without non-transparent samples falls
+ * back to the cube.  Declared behind dsn_render_rays' flags. */
 DSN_EXPORT int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t n_points, void* workspace, float* out4,
                          void* stream);
 DSN_EXPORT int dsn_set_screen_margin(void* packed, float margin, void* stream);
@@ -300,6 +312,8 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
 #define DSN_PHASE_FIELD 512
 #define DSN_PHASE_SHADE 1024
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
+DSN_EXPORT int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, const void* render_workspace, int R, int S,
+                               int64_t n_points, void* workspace, float* out8, void* stream);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,

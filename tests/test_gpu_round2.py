@@ -183,24 +183,35 @@ def test_training_counts_range_overflow():
 # ------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("wname", ["", "_w2", "_w3", "_w4"])
 def test_screen_calibration_bounds_the_frame(wname):
-    """PackedParams.calibrate_screen on each parameter set: the calibrated margin (10x the largest deviation seen on 1 M points
-    around the canonical surface) is >= 4x the largest deviation over a whole 512 x 512 x 64 frame of another pose, no sample
-    the screen drops with that margin has an accurate density >= 0, and the frame is bit-identical with the screen on / off"""
+    """PackedParams.calibrate_screen on each parameter set.  A sample is dropped wrongly iff its accurate density is positive and the
+    screen's deviation dev = |sigma~ - sigma| / (S1 + 1) exceeds margin + rel, rel = |sigma| / (S1 + 1); the calibrated margin leaves
+    every one of its 1 M points around the canonical surface a factor 10 of headroom in deviation against that.  On a whole
+    512 x 512 x 64 frame of ANOTHER pose every evaluated sample still has a factor >= 3, no sample the screen drops has an accurate
+    density >= 0, and the frame is bit-identical with the screen on / off.  The converged set (w4) is judged unsafe - see below"""
     from dsnerf_amd import _lib
     canon, faces, batch = full_frame(hw=512, seed=23, pose_seed=41)
     r = renderer_with(state("x" + wname), canon, faces)
     r.eval()
     r._set_frame(batch)
     packed = r.net.packed(r.device)
-    info = packed.calibrate_screen(r.scene)
+    S = 64
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    # calibration on the points of a frame, as Renderer / bench.py do it (the frame of ANOTHER pose and camera seed is checked below)
+    _, _, cal = full_frame(hw=256, seed=3, pose_seed=5)
+    r._set_frame(cal)
+    cws = _lib.RenderWorkspace(r.device)
+    _lib.render_rays(r.scene, packed, cws, r._dev(cal["ray_o"][0]), r._dev(cal["ray_d"][0]), r._dev(cal["near"][0]).clone(),
+                     r._dev(cal["far"][0]).clone(), S, r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
+    info = packed.calibrate_screen(r.scene, frame=(cws, 256 * 256, S))
+    r._set_frame(batch)
+    assert info["points_from"] == "frame"
     if wname == "_w4":
-        # The CONVERGED set defeats the plain-fp16 trunk: sigma in [-316, 1013] comes out of large cancelling terms and the fp16
-        # evaluation is off by 4-5 % of their magnitude (cap 0.5 %) - the calibration says so, the margin is +inf, Renderer leaves the
-        # screen out (every non-transparent sample takes the accurate pass), and forcing it on still drops nothing.
-        assert not info["safe"] and not info["usable"] and info["margin"] == float("inf") and info["deviation"] > 0.005, info
+        # The CONVERGED set defeats the plain-fp16 trunk where it matters: around sigma = 0 the fp16 evaluation is off by 4-5 % of the
+        # magnitude of the summed terms (the hash-initialised sets: 0.02-0.06 %), so a factor 10 of headroom would need a margin of
+        # 0.2-0.5 - beyond the cap of 0.15 (the statistic is the maximum of a heavy-tailed quantity: 0.02-0.05 from frame to frame).  The calibration says so, the margin
+        # is +inf, Renderer leaves the screen out (every non-transparent sample takes the accurate pass); forced on it drops nothing.
+        assert not info["safe"] and not info["usable"] and info["margin"] == float("inf") and info["margin_statistic"] > 0.015, info
         assert not r._screen_usable()
-        S = 64
-        o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
         outs = []
         for screen in (True, False):
             n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
@@ -212,12 +223,12 @@ def test_screen_calibration_bounds_the_frame(wname):
         for k in ("color", "acc_map", "depth_map", "weights"):
             assert torch.equal(outs[0][k], outs[1][k]), k
         return
-    assert info["safe"] and 0.002 <= info["margin"] <= 0.05 and info["overflow_fraction"] < 0.5, info
-    # the screen pays only where it drops a good share of the samples: the default set yes, the trained set (dense near the
-    # surface: every calibration point has sigma > 0) no - Renderer leaves it off there
-    assert info["usable"] == (info["dropped_fraction"] >= 0.35) and (wname != "" or info["usable"]) and (wname != "_w2" or not info["usable"]), info
-    S = 64
-    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    assert info["safe"] and 0.002 <= info["margin"] <= 0.15 and info["overflow_fraction"] < 0.5, info
+    assert info["margin"] == pytest.approx(max(10.0 * info["margin_statistic"], 0.002), rel=1e-5)
+    # the screen pays only where it drops a good share of the samples: the default set yes, the set trained for 400 steps (dense near the
+    # surface: every calibration point has sigma > 0) no - Renderer leaves it off there; the converged set yes
+    assert info["usable"] == (info["dropped_fraction"] >= 0.35), info
+    assert (wname != "" or info["usable"]) and (wname != "_w2" or not info["usable"]), info
     n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
     pts, z = _lib.sample(r.scene, o, d, n, f, S, r._t_vals(S), None)
     w = _lib.warp(r.scene, pts, d, S, want_dir=False, want_active=True)
@@ -227,14 +238,17 @@ def test_screen_calibration_bounds_the_frame(wname):
     sg, s1 = _lib.screen_debug(r.scene, packed, w["x_c"])
     sig, sg, s1 = sig[act], sg[act], s1[act]
     ok = torch.isfinite(sg) & torch.isfinite(s1)
-    dev_frame = float(((sg - sig).abs() / (s1 + 1.0))[ok].max())
+    dev = (sg - sig).abs() / (s1 + 1.0)
+    rel = sig.abs() / (s1 + 1.0)
     m = info["margin"]
     empty = ok & (sg < -(m * s1 + m))
     assert int((empty & (sig >= 0)).sum()) == 0
-    assert m >= 4.0 * dev_frame, (m, dev_frame, info)
-    print(f"weights '{wname}': calibration deviation {info['deviation']:.2e} -> margin {m:.2e} (drops {info['dropped_fraction']:.2f} of the "
-          f"calibration points); frame deviation {dev_frame:.2e}; "
-          f"{float(empty.float().mean()):.3f} of {act.numel()} evaluated samples declared empty")
+    headroom = float(((m + rel) / dev.clamp_min(1e-12))[ok].min())       # >= 10 on the calibration points by construction
+    assert headroom >= 3.0, (headroom, info)
+    dev_frame = float(dev[ok].max())
+    print(f"weights '{wname}': calibration deviation {info['deviation']:.2e}, statistic {info['margin_statistic']:.2e} -> margin {m:.2e} (drops "
+          f"{info['dropped_fraction']:.2f} of the calibration points); frame: largest deviation {dev_frame:.2e}, smallest headroom "
+          f"{headroom:.1f}x; {float(empty.float().mean()):.3f} of {act.numel()} evaluated samples declared empty")
     outs = []
     for screen in (True, False):
         n2, f2 = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
@@ -243,9 +257,9 @@ def test_screen_calibration_bounds_the_frame(wname):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
-def pathological_state():
+def pathological_state(gain=400.0):
     """a network the plain-fp16 screen cannot follow: the odd rows of stage2.2 are copies of the even ones plus 1e-3 noise, and
-    stage2.4 reads the DIFFERENCE of each pair times 400 - exact arithmetic sees O(1) values, fp16 activations (11 bits) see
+    stage2.4 reads the DIFFERENCE of each pair times `gain` - exact arithmetic sees O(1) values, fp16 activations (11 bits) see
     mostly rounding noise"""
     from dsnerf_amd import synth
     sd = {k: v.copy() for k, v in state().items()}
@@ -253,27 +267,37 @@ def pathological_state():
     noise = (synth.hash_uniform(128 * 256, 901).reshape(128, 256) - 0.5).astype(np.float32) * np.float32(2e-3)
     w5[1::2] = w5[0::2] + noise
     b5[1::2] = b5[0::2]
-    v = w6[:, 0::2].copy() * np.float32(400.0)
+    v = w6[:, 0::2].copy() * np.float32(gain)
     w6[:, 0::2] = v
     w6[:, 1::2] = -v
     return sd
 
 
 def test_pathological_network_switches_the_screen_off():
-    """when the calibration finds deviations beyond the cap the screen is left out: Renderer warns, renders without it, and
-    the frame is bit-identical to an explicit screen-off render"""
+    """networks built to defeat fp16 (cancellation amplified 400 x and 4000 x).  Whatever the calibration decides - a wide margin, or
+    "unsafe" (margin beyond the cap: Renderer warns and leaves the screen out) - the frame is bit-identical to an explicit
+    screen-off render; the stronger one must be judged unsafe"""
+    import warnings
     from dsnerf_amd import _lib
     canon, faces, batch = full_frame(hw=160)
-    r = renderer_with(pathological_state(), canon, faces)
-    r.eval()
-    with pytest.warns(UserWarning, match="density screen"):
-        out = r.render(dict(batch))["coarse"]
-    assert r.screen_info is not None and not r.screen_info["safe"] and not r.screen_info["usable"] and r.screen_info["deviation"] > 0.005, r.screen_info
-    r.density_screen = False
-    ref = r.render(dict(batch))["coarse"]
-    for k in ("color", "acc_map", "depth_map", "weights"):
-        assert torch.equal(out[k], ref[k]), k
-    assert torch.isfinite(out["color"]).all() and float(out["acc_map"].max()) > 0.01
+    verdicts = []
+    for gain in (400.0, 4000.0):
+        r = renderer_with(pathological_state(gain), canon, faces)
+        r.eval()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = r.render(dict(batch))["coarse"]
+        info = r.screen_info
+        warned = any("density screen" in str(w.message) for w in caught)
+        assert info is not None and info["deviation"] > 0.005 and warned == (not info["safe"]), (gain, info)
+        assert info["safe"] == (info["margin"] <= _lib.SCREEN_MARGIN_CAP) and (info["safe"] or not info["usable"]), info
+        verdicts.append(info["safe"])
+        r.density_screen = False
+        ref = r.render(dict(batch))["coarse"]
+        for k in ("color", "acc_map", "depth_map", "weights"):
+            assert torch.equal(out[k], ref[k]), (gain, k)
+        assert torch.isfinite(out["color"]).all() and float(out["acc_map"].max()) > 0.01
+    assert verdicts[-1] is False, verdicts
     # and a fresh default network is calibrated usable by the same path
     r2 = renderer_with(state(), canon, faces)
     r2.eval()
@@ -877,7 +901,7 @@ def test_renderer_decides_early_stop_from_the_first_frame():
         # with termination in use the screen's dropped share counts among the samples still evaluated: w3's 34 % of all points is
         # 68 % of what is left once the dense interior is gone, so the screen comes on although its calibration alone said no
         pk = r.net.packed(r.device)
-        assert r._screen_usable() and (pk.screen["usable"] is (not want))
+        assert r._screen_usable() and pk.screen["points_from"] == "frame"      # (calibrated by the first frame, on its own points)
         b = r.render_view(batch, device_output=True)
         torch.cuda.synchronize()
         st = _lib.read_stop_stats(r._ws)

@@ -75,10 +75,13 @@ def test_converged_checkpoint_on_the_bench_frame():
     r = renderer_with(state("x_w4"), canon, faces)
     r.eval()
     r._set_frame(batch)
-    info = r.net.packed(r.device).calibrate_screen(r.scene)
-    assert not info["safe"] and not r._screen_usable(), info          # the trained field defeats plain fp16: the screen stays out (margin +inf)
     S = 64
     o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    cws = _lib.RenderWorkspace(r.device)
+    _lib.render_rays(r.scene, r.net.packed(r.device), cws, o, d, r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone(), S,
+                     r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
+    info = r.net.packed(r.device).calibrate_screen(r.scene, frame=(cws, o.shape[0], S))      # on the frame's own points, as Renderer does
+    assert not info["safe"] and info["points_from"] == "frame", info      # (2-5 % deviation around sigma = 0: a margin of 0.2-0.5, beyond the cap of 0.15 - screen off)
 
     def run(**kw):
         n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
@@ -88,7 +91,7 @@ def test_converged_checkpoint_on_the_bench_frame():
         return out, _lib.read_stop_stats(ws)
 
     ref, st0 = run(screen=False, stop_stats=True)
-    scr, _ = run(screen=True)                                         # forced on with its +inf margin: drops nothing
+    scr, _ = run(screen=True)
     for k in ("color", "acc_map", "depth_map", "weights"):
         assert torch.equal(ref[k], scr[k]), k
     acc = ref["acc_map"]
@@ -247,3 +250,33 @@ def test_fused_search_and_warp_equals_the_two_kernel_form(wname, far_rays, monke
     assert na == nb > 0
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
+
+
+def test_screen_audit_runs_by_itself():
+    """Renderer.screen_audit = "auto" (the default): the first eval frame and every 8th after it carry the audit, the counters are read
+    back without a wait at a later frame, audited and plain frames are bit-identical - and a margin that drops positive densities
+    (set by hand) is caught within one audit period and switches the screen off, after which the frames are exact again"""
+    import warnings
+    from dsnerf_amd import can_render
+    canon, faces, batch = full_frame(hw=256)
+    r = renderer_with(state(), canon, faces)
+    r.eval()
+    assert r.screen_audit == "auto"
+    frames = [r.render(dict(batch))["coarse"] for _ in range(can_render.SCREEN_AUDIT_EVERY + 2)]
+    torch.cuda.synchronize()
+    res = r.last_screen_audit()
+    assert res is not None and res["audited"] > 100 and res["violations"] == 0 and r.density_screen, res
+    for f in frames[1:]:
+        for k in ("color", "acc_map", "depth_map", "weights"):
+            assert torch.equal(frames[0][k], f[k]), k
+    r.net.packed(r.device).set_screen_margin(-0.02)         # "empty" up to sigma~ < 0.02 (S1 + 1): drops positive densities
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        bad = [r.render(dict(batch))["coarse"] for _ in range(2 * can_render.SCREEN_AUDIT_EVERY + 2)]
+        torch.cuda.synchronize()
+        r.last_screen_audit()
+    assert any("switched off" in str(w.message) for w in caught) and r.density_screen is False
+    again = r.render(dict(batch))["coarse"]
+    for k in ("color", "acc_map", "depth_map", "weights"):
+        assert torch.equal(frames[0][k], again[k]), k
+    assert not all(torch.equal(frames[0]["color"], b["color"]) for b in bad[:3])      # (the bad margin really did change pixels)
