@@ -74,9 +74,9 @@ def parse():
                          "dense near the surface: the density screen calibrates itself off), w3 = large-magnitude hash set, w4 = "
                          "CONVERGED on the synthetic body by this repo's HIP trainer (scripts/train_w4.py, tests/golden/weights_w4.npz)")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="with --strong on ONE GPU: render each of the N ranks' round-robin tile shares of the frame alone, one after "
+                    help="on ONE GPU: with --strong render each of the N ranks' round-robin tile shares of the frame alone, one after "
                          "the other, and report the N times, max / mean (the load balance of the tile deal) and the strong-scaling "
-                         "efficiency they predict")
+                         "efficiency they predict; without --strong the N ranks' own frames of the weak line")
     ap.add_argument("--strong", action="store_true",
                     help="strong-scaling mode (BASELINE configs[3]): ONE 1024 x 1024 x 128 frame, its rays dealt to the ranks in "
                          "round-robin 3072-ray tiles (RayParallel.tile_indices), rendered pixels all-gathered inside the timed "
@@ -138,6 +138,8 @@ def main():
         return
     if args.strong:
         return strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist)
+    if args.emulate_world > 1 and world == 1:
+        return weak_emulated(args, dsnerf_amd, _lib, synth, dev)
     H = W = args.hw
     S = args.samples
     R = H * W
@@ -360,6 +362,7 @@ def main():
                                                "reference-trainer steps (solid, unsaturated), w3 = hash init x3.5 (dense guess), w4 = converged "
                                                "with scripts/train_w4.py: the representative checkpoint")
     if rank == 0 and world == 1 and not args.no_roofline:
+        scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)      # (the frame state of THESE parameters: by_weights has used the scene)
         result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args)
@@ -521,8 +524,6 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
             full[dev_idx[0]] = px[:Rl]
 
     def barrier():
-        if pipe is not None:
-            pipe.flush()                 # (the shading of the last frame: every step's frame is complete inside the timed region)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -565,6 +566,74 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
         print(json.dumps(res), flush=True)
 
 
+def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
+    """The weak-scaling line's per-rank work, measured on ONE GPU: with N ranks every rank renders its own frame of the multi-frame
+    batch (pose / posed-mesh seeds 3 + rank, 5 + rank as in main()) and one all-gather of [R,6] pixels follows.  Each emulated rank's
+    frame is rendered alone here (two frames in flight, as the ranks do); the spread of the N times is the load imbalance a real run
+    waits for, max over ranks is its step time before the exchange."""
+    H = W = args.hw
+    S = args.samples
+    R = H * W
+    Nw = int(args.emulate_world)
+    canon, faces = synth.make_body()
+    sd = load_weights(synth, args.weights)
+    packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
+    depth = max(1, args.pipeline)
+    scenes = [_lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev) for _ in range(depth)]
+    wss = [_lib.RenderWorkspace(dev) for _ in range(depth)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    info, screen, ranks = None, True, []
+    for r_ in range(Nw):
+        xyz = synth.pose_body(canon, seed=3 + r_)
+        rays = synth.make_rays(H, W, xyz, fit_box=True)
+        d_xyz, d_poses = T(xyz), T(synth.make_poses(seed=5 + r_))
+        o, d, near0, far0 = T(rays["ray_o"]), T(rays["ray_d"]), T(rays["near"]), T(rays["far"])
+        if info is None:
+            scenes[0].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+            _lib.render_rays(scenes[0], packed, wss[0], o, d, near0.clone(), far0.clone(), S, t_vals, want_weights=False,
+                             phases=_lib.PHASE_GEOMETRY)
+            info = packed.calibrate_screen(scenes[0], frame=(wss[0], R, S))
+            screen = bool(info["usable"])
+        nears, fars, outs = [near0.clone() for _ in range(depth)], [far0.clone() for _ in range(depth)], [None] * depth
+
+        def step(k):
+            j = k % depth
+            with torch.cuda.stream(streams[j]):
+                nears[j].copy_(near0)
+                fars[j].copy_(far0)
+                scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
+                outs[j] = _lib.render_rays(scenes[j], packed, wss[j], o, d, nears[j], fars[j], S, t_vals, want_weights=False, out=outs[j],
+                                           screen=screen)
+
+        for k in range(args.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        cnt = wss[(args.steps - 1) % depth].buf[:256].view(torch.int32).cpu()
+        ranks.append({"rank": r_, "ms_per_frame": ms, "non_transparent": int(cnt[_lib.CNT_ACTIVE]), "accurate_pass": int(cnt[_lib.CNT_KEEP]),
+                      "positive_density": int(cnt[_lib.CNT_POS])})
+    t = np.array([x["ms_per_frame"] for x in ranks])
+    ag_ms = 0.03 + 1e3 * (24.0 * R * (Nw - 1)) / ((Nw - 1) * 153e9)      # every rank receives N - 1 slabs of 24 B x R over its N - 1 links
+    res = {"metric": f"weak-scaling load balance: the {Nw} ranks' frames ({H}x{W} x {S} samples/ray) rendered one after the other on ONE GPU",
+           "value": Nw * R / ((float(t.max()) + ag_ms) * 1e-3), "unit": "rays/s (PREDICTED for the emulated world: max frame + priced all-gather)",
+           "n_gpus": 1, "emulated_world": Nw, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.max()) + ag_ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+           "dtype": "split-f16x3 + plain-f16 density screen",
+           "config": {"workload": "one frame per emulated rank (BASELINE configs[4] / the weak line of bench.py --gpus N)", "weights": args.weights,
+                      "ranks": ranks, "frame_ms_max": float(t.max()), "frame_ms_mean": float(t.mean()), "frame_ms_min": float(t.min()),
+                      "max_over_mean": float(t.max() / t.mean()), "all_gather_ms_PRICED_not_measured": ag_ms,
+                      "predicted_weak_scaling_efficiency": float(t.mean() / (t.max() + ag_ms)),
+                      "density_screen_calibration": info}}
+    _flush_c_stdio()
+    print(json.dumps(res), flush=True)
+
+
 def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
     """Load balance of the strong-scaling partition, measured on ONE GPU (no multi-GPU node is available to the
     builder): the 1024 x 1024 x 128 frame of configs[3] is dealt to N = --emulate-world ranks exactly as strong_bench does
@@ -592,7 +661,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
     d_xyz, d_poses = T(xyz), T(poses)
     t_vals = torch.linspace(0.0, 1.0, steps=S).to(dev)
     scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
-    info = packed.calibrate_screen(scene)
+    info = packed.calibrate_screen(scene)      # (the centroid cube: the shares are rendered with one margin, whichever rank calibrates)
 
     def time_share(idx):
         mine = idx.numpy()
@@ -727,7 +796,7 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
         dt = float(tt.item())
     from dsnerf_amd import _lib
     rows = _lib.grad_row_counts(r._grad_ws, R, S)
-    return dt, float(loss), int(r.range_overflow_count()), {"samples": R * S, "forward_rows": rows[0], "backward_rows": rows[1]}
+    return dt, float(loss.detach()), int(r.range_overflow_count()), {"samples": R * S, "forward_rows": rows[0], "backward_rows": rows[1]}
 
 
 def train_roofline(ms, R, S):

@@ -12,7 +12,7 @@
 // inside fp16; forward activations must stay below 65504 (they are O(10) for NeRF trunks).  Every epilogue keeps a
 // running maximum of the values it splits (one v_max3 per two elements); a sample that reaches F16_RANGE anywhere is
 // FLAGGED: its sigma is written as NaN and the exact-fp32 kernel re-evaluates it (dsn_launch_field_fix, dsn_field.hip) -
-// checkpoints whose activations or adjoints leave the fp16 range render correctly, only slower (tests/test_gpu_range.py).
+// checkpoints whose activations or adjoints leave the fp16 range render correctly, only slower (tests/test_gpu_round2.py: test_fp16_range_fallback_*).
 //
 // Structure.  Same transposed formulation and register chaining as k_field (dsn_field.hip): one
 // wavefront owns 32 points, the accumulator layout of the 32x32 MFMA is re-used as the next
