@@ -62,7 +62,9 @@ int dsn_set_body(void* scene, const float* canon_vertex, const int32_t* faces, i
         return dsn_fail("%s", "dsn_set_body: copy failed");
     dsn_launch_face_setup(s.canon, s.faces, F, s.face_canon, s.cent_canon, st);
     // canonical-space queries are x_c = face frame re-embedding with |h| <= 0.1 and uv in [-4,5]: wide pads
-    dsn_launch_build_nn(s.cent_canon, F, s.nn_canon, 0.25f, 0.7f, st);
+    // (fine level: pad 0.12 m - a non-transparent sample lies within |h| <= 0.1 m of its face, utils/render_utils.py:103-109, so its
+    //  canonical point is inside; whatever is further out takes the coarse level / the sweep, same index)
+    dsn_launch_build_nn(s.cent_canon, F, s.nn_canon, 0.12f, 0.7f, st, false, true);
     return dsn_check_launch("dsn_set_body");
 }
 

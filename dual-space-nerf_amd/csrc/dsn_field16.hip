@@ -1918,6 +1918,13 @@ void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st) {
 // 9 -> 128 -> 128 -> 1 per point; the 20 weight blocks (80 KB) are L1/L2-resident, so every wave reads its
 // operands straight from memory (no LDS ring: the matrix work per point is 50x smaller than the trunk's).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void light_block0(const char* blkp, int lane, const half8 (&xh)[2], const half8 (&xl)[2], f32x16& aM, f32x16& aC) {
+    const half8 h0 = *reinterpret_cast<const half8*>(blkp + lane * 16);
+    const half8 l0 = *reinterpret_cast<const half8*>(blkp + 1024 + lane * 16);
+    aM = MFMA16(h0, xh[0], aM);
+    aC = MFMA16(h0, xl[0], aC);
+    aC = MFMA16(l0, xh[0], aC);
+}
 __device__ __forceinline__ void light_block(const char* __restrict__ blkp, int lane, const half8 (&xh)[2], const half8 (&xl)[2],
                                             f32x16& aM, f32x16& aC, bool second_step) {
     const half8 h0 = *reinterpret_cast<const half8*>(blkp + lane * 16);
@@ -1934,6 +1941,11 @@ __device__ __forceinline__ void light_block(const char* __restrict__ blkp, int l
     }
 }
 
+// Round 3: persistent workgroups with the weights in LDS.  Every wave used to read its 72 KB of weight operands straight from
+// memory for every 32 samples - more than a CU's L1 holds, so 2.25 KB per sample came from L2: 4.4 GB per launch on the bench frame,
+// 10 TB/s, the kernel was L2-bound (0.41 ms).  Now a workgroup stages the 20 blocks once (72 KB: two workgroups per CU) and walks
+// its tiles of 128 samples with ds_read_b128 operands.  Same products in the same order: bit-identical colours.
+#define LIGHT_LDS_BYTES (4 * 2048 + 16 * 4096)
 __global__ void __launch_bounds__(256, 2)
 k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
           const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
@@ -1942,12 +1954,25 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
           float* __restrict__ colour, float* __restrict__ tr_hl1, float* __restrict__ tr_hl2, float* __restrict__ tr_pre) {
     // tr_*: (training forward) the two hidden layers after their ReLU, row-major [N,128], and the pre-activation of the output
     // [N] - what the backward of the lighting MLP needs, so that it does not have to evaluate the MLP again
+    __shared__ __attribute__((aligned(16))) char s_w[LIGHT_LDS_BYTES];      // [LT0: 4 x (hi, lo of k-step 0) | LT1: 16 x 4 KB]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
     const int64_t count = active_list ? (int64_t)(*active_count) : N;
-    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (slot0 >= count) return;
+    const int64_t ntiles = (count + 127) / 128;
+    if ((int64_t)blockIdx.x >= ntiles) return;      // block-uniform
+    {
+        const char* g16 = reinterpret_cast<const char*>(packed + OFF16_BASE);
+        const uint4* g0 = reinterpret_cast<const uint4*>(g16 + (size_t)(OFF_LT0 / DSN_BLK) * 4096);
+        const uint4* g1 = reinterpret_cast<const uint4*>(g16 + (size_t)(OFF_LT1 / DSN_BLK) * 4096);
+        uint4* d = reinterpret_cast<uint4*>(s_w);
+        for (int i = threadIdx.x; i < 4 * 128; i += 256) d[i] = g0[(i >> 7) * 256 + (i & 127)];      // first 2 KB of each 4 KB block
+        for (int i = threadIdx.x; i < 16 * 256; i += 256) d[4 * 128 + i] = g1[i];
+    }
+    __syncthreads();
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t slot0 = (tile * 4 + wave) * 32;
+    if (slot0 >= count) continue;                    // (no barrier inside the loop)
     int64_t slot = slot0 + (lane & 31);
     const bool valid = slot < count;
     if (!valid) slot = count - 1;
@@ -1975,7 +2000,6 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     in9[6] = dsn_div(d[0], vn); in9[7] = dsn_div(d[1], vn); in9[8] = dsn_div(d[2], vn);
     in9[9] = 0.0f;
 
-    const char* w16 = reinterpret_cast<const char*>(packed + OFF16_BASE);
     // input operand: k-slot j of step 0 holds feature 2j + half (j < 5), zero beyond
     half8 xh[2], xl[2];
     {
@@ -1988,7 +2012,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x16 aM = rows16(packed + OFF_BLT0, m, half), aC = zero16();
-        light_block(w16 + (size_t)(OFF_LT0 / DSN_BLK + m) * 4096, lane, xh, xl, aM, aC, false);
+        light_block0(s_w + m * 2048, lane, xh, xl, aM, aC);
         f32x16 v = fold16(aM, aC);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
@@ -2001,7 +2025,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 aM = rows16(packed + OFF_BLT1, m, half), aC = zero16();
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
-            light_block(w16 + (size_t)(OFF_LT1 / DSN_BLK + m * 4 + kb) * 4096, lane, h1h[kb], h1l[kb], aM, aC, true);
+            light_block(s_w + 4 * 2048 + (m * 4 + kb) * 4096, lane, h1h[kb], h1l[kb], aM, aC, true);
         f32x16 v = fold16(aM, aC);
         const f32x16 w2 = rows16(packed + OFF_WLT2, m, half);
 #pragma unroll
@@ -2017,6 +2041,7 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         colour[3 * pt + 1] = wgt * essence[3 * pt + 1];
         colour[3 * pt + 2] = wgt * essence[3 * pt + 2];
     }
+  }
 }
 
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
@@ -2025,6 +2050,6 @@ void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const floa
                         float* tr_hl1, float* tr_hl2, float* tr_pre) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_light16, dim3((unsigned)blocks), dim3(256), 0, st, packed, fs, n_w, x_w, ray_o, ray_d, z_vals,
-                       essence, N, S, active_list, active_count, colour, tr_hl1, tr_hl2, tr_pre);
+    hipLaunchKernelGGL(k_light16, dim3((unsigned)std::min<int64_t>(blocks, 2 * (int64_t)dsn_cu_count())), dim3(256), 0, st, packed, fs, n_w,
+                       x_w, ray_o, ray_d, z_vals, essence, N, S, active_list, active_count, colour, tr_hl1, tr_hl2, tr_pre);
 }

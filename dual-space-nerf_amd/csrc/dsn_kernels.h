@@ -46,7 +46,7 @@ void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* gra
                        bool exhaustive, hipStream_t st);
 // dsn_nn.hip
 void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
-                         bool fine_only = false);
+                         bool fine_only = false, bool dense_fine = false);
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false);

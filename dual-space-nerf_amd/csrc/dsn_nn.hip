@@ -267,8 +267,10 @@ __global__ void k_grid_disable(DsnGrid* __restrict__ g) {
 }
 
 void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
-                         bool fine_only) {
-    const int t_fine = dsn_clampi(3 * F, 512, 44000);
+                         bool fine_only, bool dense_fine) {
+    // dense_fine (the canonical mesh: built once, queried by a per-lane list scan in k_normal): as many fine cells as the level
+    // holds - shorter lists per query; the posed mesh's lists are rebuilt per frame and stay at 3 F cells
+    const int t_fine = dense_fine ? dsn_clampi(5 * F, 512, 62000) : dsn_clampi(3 * F, 512, 44000);
     const int t_coarse = dsn_clampi(F / 3, 64, 5000);
     dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), true, st);
     if (fine_only) hipLaunchKernelGGL(k_grid_disable, dim3(1), dim3(1), 0, st, nn.coarse.g);
