@@ -513,27 +513,36 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     int32_t* cnt = skip ? w.count : nullptr;
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
     if (do_geom) {
-    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+    const char* cm_env = getenv("DSN_CELLMAJOR_MIN");      // test / tuning override
+    const long long cellmajor_min = cm_env ? atoll(cm_env) : (long long)DSN_CELLMAJOR_MIN;
+    const bool cellmajor = !exh && N >= (int64_t)cellmajor_min;
+    const bool fused_nn = cellmajor && !getenv("DSN_NN_UNFUSED");
+    if (fused_nn) {
+        // the sampler classifies the samples by fine cell while it writes their z (the first step of the cell-major search)
+        int32_t *counts = nullptr, *outside0 = nullptr;
+        dsn_nn_cellmajor_begin(w.nn_small, &counts, &outside0, st);
+        dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st,
+                             s.nn_world.fine.g, (int32_t*)w.grad, counts, outside0);
+    } else
+        dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     if (skip) {
         if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
     }
-    const char* cm_env = getenv("DSN_CELLMAJOR_MIN");      // test / tuning override
-    const long long cellmajor_min = cm_env ? atoll(cm_env) : (long long)DSN_CELLMAJOR_MIN;
-    if (!exh && N >= (int64_t)cellmajor_min) {
+    if (cellmajor) {
         // cell-major search: samples counting-sorted by fine cell, lists through the scalar cache, and the rest of the warp stage
         // fused behind the search (dsn_nn.hip, k_nns_search<WARP>).  Scratch: buffers that are not written before the field's
         // reverse pass / the normal and lighting kernels - cell ids in the gradient buffer (N ints of 3 N), the sorted (point, id)
         // records in n_w | colour (16 N bytes of 24 N; a colour is read only where the density is positive: no clearing).
         // Samples outside the fine grid (none for rays clipped to the body's bounds) are left to a k_warp pass of their own.
         int32_t* g3 = (int32_t*)w.grad;
-        if (getenv("DSN_NN_UNFUSED")) {      // (cross-check / A-B switch: round 2's form - search writes nn[], k_warp reads it)
+        if (!fused_nn) {      // (DSN_NN_UNFUSED, cross-check / A-B switch: round 2's form - search writes nn[], k_warp reads it)
             dsn_launch_nn_cellmajor(s.nn_world, nullptr, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, g3 + N, w.nn_small, st);
             dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                             g3 + N, skip);
         } else {
             int32_t* outside = nullptr;
             dsn_launch_nn_cellmajor_warp(s.nn_world, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, w.nn_small, s.face_world, s.face_canon,
-                                         w.transparent, w.x_c, list, cnt, skip, &outside, st);
+                                         w.transparent, w.x_c, list, cnt, skip, &outside, st, true);
             dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                             nullptr, skip, g3, outside);
         }

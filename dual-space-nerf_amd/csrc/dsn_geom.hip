@@ -208,13 +208,20 @@ __device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_be
 }
 
 // z_vals (and pts) of the block's rays from their [near, far] in s_near / s_far (utils/pts_utils.py:3-16, 55-58)
+// cls (fused path): the first step of the cell-major nearest-face search rides along - the sample's fine cell goes to cls.cell_of and
+// the cell's counter is bumped once per run of equal cells in the wave (dsn_nn.hip, k_nns_classify: the same code on the z just
+// computed instead of a second pass that reads it back)
+struct GgClassify { const DsnGrid* gf; int32_t* cell_of; int32_t* counts; int32_t* outside; };
 __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far, const float* __restrict__ ray_o,
                                         const float* __restrict__ ray_d, int R, int S, const float* __restrict__ t_vals,
-                                        const float* __restrict__ jitter, float* __restrict__ z_vals, float* __restrict__ pts) {
+                                        const float* __restrict__ jitter, float* __restrict__ z_vals, float* __restrict__ pts,
+                                        const GgClassify cls = GgClassify{nullptr, nullptr, nullptr, nullptr}) {
     const int tid = threadIdx.x;
     const int rays_here = min(GG_THREADS, R - blockIdx.x * GG_THREADS);
     const int total = rays_here * S;
-    for (int e = tid; e < total; e += GG_THREADS) {
+    const int total_up = cls.gf ? (total + 63) & ~63 : total;      // (classification uses wave-wide ballots: whole waves iterate)
+    for (int e = tid; e < total_up; e += GG_THREADS) {
+        if (e >= total) { dsn_nns_classify_one(cls.gf, -1, false, 0.f, 0.f, 0.f, 0, cls.cell_of, cls.counts, cls.outside); continue; }
         int lr = e / S, i = e - lr * S;
         float nn = s_near[lr], ff = s_far[lr];
         float ti = t_vals[i];
@@ -227,11 +234,13 @@ __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far,
             z = lower + (upper - lower) * jitter[g];
         }
         z_vals[g] = z;
-        if (pts) {
+        if (pts || cls.gf) {
             int rr = blockIdx.x * GG_THREADS + lr;
-            pts[3 * g + 0] = ray_o[3 * rr + 0] + ray_d[3 * rr + 0] * z;
-            pts[3 * g + 1] = ray_o[3 * rr + 1] + ray_d[3 * rr + 1] * z;
-            pts[3 * g + 2] = ray_o[3 * rr + 2] + ray_d[3 * rr + 2] * z;
+            const float px = ray_o[3 * rr + 0] + ray_d[3 * rr + 0] * z;      // (the expression of k_warp / nns_point: same point, bit for bit)
+            const float py = ray_o[3 * rr + 1] + ray_d[3 * rr + 1] * z;
+            const float pz = ray_o[3 * rr + 2] + ray_d[3 * rr + 2] * z;
+            if (pts) { pts[3 * g + 0] = px; pts[3 * g + 1] = py; pts[3 * g + 2] = pz; }
+            if (cls.gf) dsn_nns_classify_one(cls.gf, g, true, px, py, pz, 0, cls.cell_of, cls.counts, cls.outside);
         }
     }
 }
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
                                                            float* __restrict__ far, int R, int S,
                                                            const float* __restrict__ t_vals,
                                                            const float* __restrict__ jitter, float* __restrict__ z_vals,
-                                                           float* __restrict__ pts) {
+                                                           float* __restrict__ pts, GgClassify cls) {
     __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
     const int tid = threadIdx.x;
     const int r = blockIdx.x * GG_THREADS + tid;
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
     }
     s_near[tid] = n_; s_far[tid] = f_;
     __syncthreads();
-    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts);
+    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts, cls);
 }
 
 // Few rays (a training batch, a 3072-ray chunk): the sweep of one block of rays is split over blockIdx.y vertex slices so the
@@ -291,7 +300,7 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg_finish(const float* __
                                                                   float* __restrict__ near, float* __restrict__ far, int R, int S,
                                                                   const float* __restrict__ t_vals,
                                                                   const float* __restrict__ jitter, float* __restrict__ z_vals,
-                                                                  float* __restrict__ pts) {
+                                                                  float* __restrict__ pts, GgClassify cls) {
     __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
     const int tid = threadIdx.x;
     const int r = blockIdx.x * GG_THREADS + tid;
@@ -309,12 +318,13 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg_finish(const float* __
     }
     s_near[tid] = n_; s_far[tid] = f_;
     __syncthreads();       // every key of the block has been read before the first z_vals store below
-    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts);
+    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts, cls);
 }
 
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
-                          hipStream_t st) {
+                          hipStream_t st, const DsnGrid* cls_grid, int32_t* cls_cell_of, int32_t* cls_counts, int32_t* cls_outside) {
+    const GgClassify cls = {cls_grid, cls_cell_of, cls_counts, cls_outside};
     const int blocks = (R + GG_THREADS - 1) / GG_THREADS;
     int slices = blocks > 0 ? 1024 / blocks : 1;           // aim at ~4 workgroups per CU
     if (slices > V / 256) slices = V / 256;                // at least 256 vertices per slice
@@ -325,11 +335,11 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
         hipLaunchKernelGGL(k_sample_gg_slice, dim3(blocks, slices), dim3(GG_THREADS), 0, st, xyz, V, slice, ray_o, ray_d, R, S,
                            z_vals);
         hipLaunchKernelGGL(k_sample_gg_finish, dim3(blocks), dim3(GG_THREADS), 0, st, ray_o, ray_d, near, far, R, S, t_vals,
-                           jitter, z_vals, pts);
+                           jitter, z_vals, pts, cls);
         return;
     }
     hipLaunchKernelGGL(k_sample_gg, dim3(blocks), dim3(GG_THREADS), 0, st, xyz, V, ray_o,
-                       ray_d, near, far, R, S, t_vals, jitter, z_vals, pts);
+                       ray_d, near, far, R, S, t_vals, jitter, z_vals, pts, cls);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,11 @@ void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_id
                            hipStream_t st, const float* pose_feat16 = nullptr);
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
-                          hipStream_t st);
+                          hipStream_t st, const DsnGrid* cls_grid = nullptr, int32_t* cls_cell_of = nullptr,
+                          int32_t* cls_counts = nullptr, int32_t* cls_outside = nullptr);
+// scratch of the cell-major search that the sampler fills when it classifies on the way (cleared here): per-cell counters and
+// the counter of samples outside the fine grid
+void dsn_nn_cellmajor_begin(void* small, int32_t** counts, int32_t** outside, hipStream_t st);
 void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o, const float* ray_d,
                      const float* z_vals, int64_t N, int S, int32_t* face_idx, float* uv, float* h,
                      uint8_t* transparent, float* x_c, float* ray_d_can, int32_t* active_list, int32_t* active_count,
@@ -38,7 +42,7 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
 void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
                                   int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
                                   uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
-                                  int32_t** outside, hipStream_t st);
+                                  int32_t** outside, hipStream_t st, bool classified = false);
 void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, const float* smpl_w, const float* A, int bw_type,
                          int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,

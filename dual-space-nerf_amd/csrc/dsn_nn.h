@@ -177,6 +177,49 @@ __device__ __forceinline__ int dsn_nearest_lists(const DsnGrid* __restrict__ gf,
     return bi;
 }
 
+// Runs of equal cell inside a wave: the 64 lanes of a wave are consecutive samples, i.e. (pieces of) rays, and a
+// straight line visits a convex cell in ONE contiguous run - so "distinct cells of the wave" are found by comparing
+// with the previous lane, and each run head issues one atomic for the whole run (no per-cell loop).  A cell that does
+// come back in a later run of the same wave (ray boundary inside the wave) simply gets a second atomic.
+struct NnsRun { bool head; int head_lane; int len; int rank; };
+__device__ __forceinline__ NnsRun nns_run(int c, int lane) {
+    const int prev = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);         // heads at or below this lane (lane 63: all)
+    NnsRun r;
+    r.head = head;
+    r.head_lane = 63 - __clzll((long long)(lane == 63 ? heads : below));
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;      // next head after this lane
+    r.len = next - r.head_lane;       // same for every lane of the run
+    r.rank = lane - r.head_lane;
+    return r;
+}
+
+// one sample's step of the cell-major classification, called by every lane of a wave (wave-wide ballots inside): its fine cell
+// -> cell_of[i], the cell's counter bumped once per run, samples outside the fine grid counted in *outside (optional).  Shared by
+// k_nns_classify (dsn_nn.hip) and the sampler's emit loop (dsn_geom.hip: the fused path classifies while it writes z).
+__device__ __forceinline__ int dsn_nns_classify_one(const DsnGrid* __restrict__ gf, int64_t i, bool valid, float px, float py, float pz,
+                                                    int, int32_t* __restrict__ cell_of, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ outside) {
+    const int lane = threadIdx.x & 63;
+    int c = -1;
+    if (valid) {
+        c = dsn_grid_cell(*gf, px, py, pz);
+        cell_of[i] = c;
+    }
+    const NnsRun r = nns_run(c, lane);
+    if (r.head && c >= 0) atomicAdd(counts + c, r.len);
+    // samples outside the fine grid (none for rays clipped to the body's bounds): counted, the fused search + warp leaves them to
+    // a second pass (k_warp on the samples with cell_of < 0)
+    if (outside) {
+        const unsigned long long om = __ballot(valid && c < 0);
+        if (om && lane == 0) atomicAdd(outside, __popcll(om));
+    }
+    return c;
+}
+
 // fine level only: -1 when the point is outside the fine grid
 __device__ __forceinline__ int dsn_nearest_fine_try(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ off_f,
                                                     const float4* __restrict__ list_f, float px, float py, float pz) {

@@ -300,49 +300,16 @@ __device__ __forceinline__ void nns_point(const float* __restrict__ pts, const f
     p[2] = ray_o[3 * ray + 2] + ray_d[3 * ray + 2] * z;
 }
 
-// Runs of equal cell inside a wave: the 64 lanes of a wave are consecutive samples, i.e. (pieces of) rays, and a
-// straight line visits a convex cell in ONE contiguous run - so "distinct cells of the wave" are found by comparing
-// with the previous lane, and each run head issues one atomic for the whole run (no per-cell loop).  A cell that does
-// come back in a later run of the same wave (ray boundary inside the wave) simply gets a second atomic.
-struct NnsRun { bool head; int head_lane; int len; int rank; };
-__device__ __forceinline__ NnsRun nns_run(int c, int lane) {
-    const int prev = __shfl_up(c, 1);
-    const bool head = lane == 0 || c != prev;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long below = heads & ((2ull << lane) - 1ull);         // heads at or below this lane (lane 63: all)
-    NnsRun r;
-    r.head = head;
-    r.head_lane = 63 - __clzll((long long)(lane == 63 ? heads : below));
-    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;      // next head after this lane
-    r.len = next - r.head_lane;       // same for every lane of the run
-    r.rank = lane - r.head_lane;
-    return r;
-}
-
 __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __restrict__ gf, const float* __restrict__ pts,
                                                               const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                               const float* __restrict__ z_vals, int64_t N, int S,
                                                               int32_t* __restrict__ cell_of, int32_t* __restrict__ nn,
                                                               int32_t* __restrict__ counts, int32_t* __restrict__ outside) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int c = -1;
-    if (i < N) {
-        float p[3];
-        nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
-        c = dsn_grid_cell(*gf, p[0], p[1], p[2]);
-        cell_of[i] = c;
-        if (c < 0 && nn) nn[i] = -1;
-    }
-    const NnsRun r = nns_run(c, lane);
-    if (r.head && c >= 0) atomicAdd(counts + c, r.len);
-    // samples outside the fine grid (none for rays clipped to the body's bounds): counted, the fused search + warp leaves them to
-    // a second pass (k_warp on the samples with cell_of < 0)
-    if (outside) {
-        const unsigned long long om = __ballot(i < N && c < 0);
-        if (om && lane == 0) atomicAdd(outside, __popcll(om));
-    }
+    float p[3] = {0.f, 0.f, 0.f};
+    if (i < N) nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
+    const int c = dsn_nns_classify_one(gf, i, i < N, p[0], p[1], p[2], 0, cell_of, counts, outside);
+    if (i < N && c < 0 && nn) nn[i] = -1;
 }
 
 // exclusive scans over the cells: sample offsets and wave offsets (ceil(count / NNS_PER) waves per cell); counts are
@@ -528,19 +495,22 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
 void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
                                   int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
                                   uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
-                                  int32_t** outside, hipStream_t st) {
+                                  int32_t** outside, hipStream_t st, bool classified) {
+    // classified: the sampler has filled cell_of / counts / the outside counter already (dsn_nn_cellmajor_begin + dsn_launch_sample_gg)
     char* q = (char*)small;
     int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
     int32_t* offs = (int32_t*)q;       q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
     int32_t* wave_offs = (int32_t*)q;  q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
     int32_t* totals = (int32_t*)q;     q += 256;
     int32_t* wave_cell = (int32_t*)q;
-    (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
-    (void)hipMemsetAsync(totals, 0, 256, st);
     *outside = totals + 2;
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
-    hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, cell_of, (int32_t*)nullptr,
-                       counts, totals + 2);
+    if (!classified) {
+        (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
+        (void)hipMemsetAsync(totals, 0, 256, st);
+        hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, cell_of, (int32_t*)nullptr,
+                           counts, totals + 2);
+    }
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
@@ -548,6 +518,15 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
     const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
     hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
                        wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, (int32_t*)nullptr, wp);
+}
+
+void dsn_nn_cellmajor_begin(void* small, int32_t** counts, int32_t** outside, hipStream_t st) {
+    char* q = (char*)small;
+    *counts = (int32_t*)q;
+    int32_t* totals = (int32_t*)(q + 3 * dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1)));
+    *outside = totals + 2;
+    (void)hipMemsetAsync(*counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
+    (void)hipMemsetAsync(totals, 0, 256, st);
 }
 
 size_t dsn_nn_sort_scratch_size(int64_t N) {

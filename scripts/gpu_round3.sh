@@ -5,6 +5,7 @@ TAG=${1:-a}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out/r03_$TAG
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tee ${O}_tests.txt
+timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -E "smoke ok|Error|error" | cut -c1-200 | tee ${O}_smoke.txt
 timeout 900 python bench.py > ${O}_bench.log 2> ${O}_bench.err; tail -1 ${O}_bench.log > ${O}_bench.json; python - ${O}_bench.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); c = d['config']
