@@ -932,9 +932,15 @@ __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC
         yl[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, v);
     }
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(vv[0]), "v"(vv[1]));      // range guard (see k_tangent16)
-    if (st) {
-        const int r = 2 * kb;
-        *reinterpret_cast<float2*>(st + 8 * (r >> 2) + (r & 3)) = make_float2(vv[0] * stscale, vv[1] * stscale);
+    if (st && kb == 7) {      // the block's 16 values again, stored together as four 16-byte pieces (see epi_slice; 8-byte pieces slice by
+                              // slice: 1.18 -> 1.09 ms)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = dsn_keep_active((pM[4 * q + e] + pC[4 * q + e]) * F16_FWD_INV, mword, 4 * q + e) * stscale;
+            *reinterpret_cast<float4*>(st + 8 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 __device__ __forceinline__ void layer16_tan(W16& w, int& blk, int lane, const half8 (&xh)[8][2], const half8 (&xl)[8][2],

@@ -60,6 +60,13 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + T_THREADS - 1) / T
 struct Rows { const int32_t* list; const int32_t* cnt; };
 __device__ __forceinline__ int64_t rows_n(const Rows& r, int64_t N) { return r.cnt ? (int64_t)(*r.cnt) : N; }
 __device__ __forceinline__ int64_t rows_at(const Rows& r, int64_t k) { return r.list ? (int64_t)r.list[k] : k; }
+// the same for a WAVE-UNIFORM k, read through the constant address space: only for loads from there does hipcc pick a scalar load
+// (s_load_dword, waited for on lgkmcnt) - a plain global pointer gives a vector load whose s_waitcnt vmcnt(0) sits between the row
+// number and every load that depends on it, draining the loads in flight.  The lists are not written while their readers run.
+__device__ __forceinline__ int64_t rows_at_u(const Rows& r, int64_t k) {
+    typedef const __attribute__((address_space(4))) int32_t* cptr;
+    return r.list ? (int64_t)*reinterpret_cast<cptr>((uintptr_t)(r.list + k)) : k;
+}
 // rows a workgroup of a row-chunked kernel takes: an even share of the listed rows, in multiples of `mult`, at least `least`
 __device__ __forceinline__ int64_t rows_share(int64_t NL, int mult, int least) {
     int64_t rows = (NL + gridDim.x - 1) / gridDim.x;
@@ -265,7 +272,8 @@ __global__ void __launch_bounds__(T_THREADS) k_t_mask_colsum256(float* __restric
 __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict__ a, int C, int64_t N, int rows_per_block,
                                                          float* __restrict__ out, Rows rw) {
     __shared__ float s[T_THREADS];
-    const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    // (C is 128 or 256: a wave lies inside one row group, so the row numbers are wave-uniform - scalar loads, rows_at_u)
+    const int c = threadIdx.x % C, r0 = __builtin_amdgcn_readfirstlane(threadIdx.x / C), rs = T_THREADS / C;
     const int64_t NL = rows_n(rw, N);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
@@ -273,13 +281,21 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
     float acc = 0.0f;
     if (r0 < rs) {
         int64_t n = base + r0;
+        int64_t id[8];
+        // the row numbers of a step are fetched one step ahead (rows beyond the chunk: the last row's, never used)
+        auto fetch = [&](int64_t n_) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int64_t q = n_ + k * (int64_t)rs; id[k] = rows_at_u(rw, q < end ? q : end - 1); }
+        };
+        if (n < end) fetch(n);
         for (; n + 7 * (int64_t)rs < end; n += 8 * (int64_t)rs) {      // eight independent loads in flight per thread
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a[rows_at(rw, n + k * (int64_t)rs) * C + c];
+            for (int k = 0; k < 8; ++k) v[k] = a[id[k] * C + c];
+            fetch(n + 8 * (int64_t)rs);
             acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; n < end; n += rs) acc += a[rows_at(rw, n) * C + c];
+        for (; n < end; n += rs) acc += a[rows_at_u(rw, n) * C + c];
     }
     s[threadIdx.x] = acc;
     __syncthreads();
@@ -295,7 +311,8 @@ template <int OUT>
 __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict__ X, int C, const float* __restrict__ dY, int64_t N,
                                                           int rows_per_block, float* __restrict__ dW, float* __restrict__ db, Rows rw) {
     __shared__ float s[OUT][T_THREADS];
-    const int c = threadIdx.x % C, r0 = threadIdx.x / C, rs = T_THREADS / C;
+    // (C is 128 or 256: wave-uniform row numbers, fetched a step ahead with scalar loads - see k_t_colsum)
+    const int c = threadIdx.x % C, r0 = __builtin_amdgcn_readfirstlane(threadIdx.x / C), rs = T_THREADS / C;
     const int64_t NL = rows_n(rw, N);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
@@ -304,22 +321,29 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
 #pragma unroll
     for (int o = 0; o < OUT; ++o) { acc[o] = 0.0f; bs[o] = 0.0f; }
     int64_t n = base + r0;
+    int64_t id[4];
+    auto fetch = [&](int64_t n_) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t q = n_ + k * (int64_t)rs; id[k] = rows_at_u(rw, q < end ? q : end - 1); }
+    };
+    if (n < end) fetch(n);
     for (; n + 3 * (int64_t)rs < end; n += 4 * (int64_t)rs) {            // four rows in flight per thread
         float x[4], y[4][OUT];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t row = rows_at(rw, n + k * (int64_t)rs);
+            const int64_t row = id[k];
             x[k] = X[row * C + c];
 #pragma unroll
             for (int o = 0; o < OUT; ++o) y[k][o] = dY[row * OUT + o];
         }
+        fetch(n + 4 * (int64_t)rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int o = 0; o < OUT; ++o) { acc[o] = fmaf(x[k], y[k][o], acc[o]); bs[o] += y[k][o]; }
     }
     for (; n < end; n += rs) {
-        const int64_t row = rows_at(rw, n);
+        const int64_t row = rows_at_u(rw, n);
         const float x = X[row * C + c];
 #pragma unroll
         for (int o = 0; o < OUT; ++o) { const float y = dY[row * OUT + o]; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
@@ -696,21 +720,31 @@ __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, i
     // step a single step of look-ahead (0.5 us) is shorter than the HBM latency under load
     constexpr int DEPTH = (OT * IT >= 16) ? 4 : 8;
     float af[DEPTH][OT], bf[DEPTH][IT], an[DEPTH][OT], bn[DEPTH][IT];
+    // listed rows: the 2 DEPTH row numbers of a load step are wave-uniform - fetched with scalar loads (rows_at_u) one step before
+    // the loads that use them are issued
+    int64_t ids[2 * DEPTH];
+    auto fetch = [&](int64_t n) {
+#pragma unroll
+        for (int q = 0; q < 2 * DEPTH; ++q) { const int64_t k = n + q; ids[q] = rows_at_u(rw, k < n1 ? k : n1 - 1); }
+    };
     auto load = [&](int64_t n, float (*fa)[OT], float (*fb)[IT]) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
             const int64_t lrow = n + 2 * s + half;
             const bool ok = lrow < n1;
-            const int64_t row = ok ? rows_at(rw, lrow) : 0;
+            const int64_t row = half ? ids[2 * s + 1] : ids[2 * s];
 #pragma unroll
             for (int a = 0; a < OT; ++a) fa[s][a] = ok ? pa[row * ldy + a * 32] : 0.0f;
 #pragma unroll
             for (int b = 0; b < IT; ++b) fb[s][b] = (ok && (wi * IT + b) * 32 + col < in_valid) ? pb[row * ldx + b * 32] : 0.0f;
         }
     };
-    if (n0 < n1) load(n0, af, bf);
+    fetch(n0);
+    load(n0, af, bf);
+    fetch(n0 + 2 * DEPTH);
     for (int64_t n = n0; n < n1; n += 2 * DEPTH) {
         load(n + 2 * DEPTH, an, bn);   // rows beyond the chunk read as zero
+        fetch(n + 4 * DEPTH);
         if (want_bias) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s)
