@@ -545,7 +545,8 @@ class Renderer:
         return self._judge_audit(snap.view(torch.int32).cpu())
 
     def _judge_audit(self, c):
-        res = {"audited": int(c[_lib.CNT_AUDIT]), "violations": int(c[_lib.CNT_AUDIT + 4]),
+        # (word + 6: the audited samples the judging kernel went through - the raw counter at + 0 runs on past the list's capacity)
+        res = {"audited": int(c[_lib.CNT_AUDIT + 6]), "violations": int(c[_lib.CNT_AUDIT + 4]),
                "max_sigma": float(c[_lib.CNT_AUDIT + 5:_lib.CNT_AUDIT + 6].view(torch.float32)[0])}
         self.last_audit = res
         if res["violations"] > 0 and self.density_screen:

@@ -406,7 +406,8 @@ struct DsnWorkspace {
 #define DSN_CNT_ACTIVE 0      // non-transparent samples
 #define DSN_CNT_POS 16        // samples with sigma > 0 (reverse pass, normals, lighting)
 #define DSN_CNT_KEEP 32       // samples the density screen sent to the accurate pass
-#define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: samples audited, [44] of those with accurate sigma > 0, [45] their max sigma (float bits)
+#define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: audit candidates (runs past the capacity), [44] audited samples with accurate sigma > 0,
+                              //                   [45] their max sigma (float bits), [46] samples audited (<= capacity)
 #define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
 #define DSN_CNT_BYTES 512
 #define DSN_CNT_SLICE 64      // DSN_EARLY_STOP: [64..95] active samples per slice (at most 32 slices), [12] alive in the current slice,

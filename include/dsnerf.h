@@ -311,6 +311,8 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
 #define DSN_PHASE_GEOMETRY 256
 #define DSN_PHASE_FIELD 512
 #define DSN_PHASE_SHADE 1024
+/* (The test overrides DSN_RECORD_CAP / DSN_STOP_SLICE change the workspace layout and are read at every call: set them before
+ *  the workspace is sized and leave them alone while it is in use.) */
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 DSN_EXPORT int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, const void* render_workspace, int R, int S,
                                int64_t n_points, void* workspace, float* out8, void* stream);
