@@ -1773,10 +1773,12 @@ void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const flo
 }
 
 // DSN_SCREEN_AUDIT: out[0] += number of audited samples (declared empty by the screen, evaluated by the accurate pass anyway)
-// whose accurate density is > 0; out[1] = max over them of that density (float bits; positive floats order like their bits)
+// whose accurate density is > 0; out[1] = max over them of that density (float bits; positive floats order like their bits);
+// out[2] = the number of samples audited (the list's capacity at most)
 __global__ void __launch_bounds__(256) k_screen_audit(const int32_t* __restrict__ audit_list, const int32_t* __restrict__ audit_count,
                                                       int audit_cap, const float* __restrict__ sigma, int32_t* __restrict__ out) {
-    const int n = min(*audit_count, audit_cap);
+    const int n = min(*audit_count, audit_cap);      // (the counter runs on past the capacity: only the first audit_cap were remembered)
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = n;      // what was actually audited, for the host mirror
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float s = sigma[audit_list[i]];
         if (s > 0.0f) { atomicAdd(out, 1); atomicMax(out + 1, __float_as_int(s)); }
