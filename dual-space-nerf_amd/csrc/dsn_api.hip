@@ -409,6 +409,7 @@ struct DsnWorkspace {
 #define DSN_CNT_AUDIT 40      // DSN_SCREEN_AUDIT: audit candidates (runs past the capacity), [44] audited samples with accurate sigma > 0,
                               //                   [45] their max sigma (float bits), [46] samples audited (<= capacity)
 #define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
+#define DSN_CNT_FLAGGED 20    // eval mode: samples the split-fp16 passes flagged for the exact-fp32 fallback (k_field<fix> looks here first)
 #define DSN_CNT_BYTES 512
 #define DSN_CNT_SLICE 64      // DSN_EARLY_STOP: [64..95] active samples per slice (at most 32 slices), [12] alive in the current slice,
 #define DSN_STOP_MAX_SLICES 32
@@ -558,6 +559,8 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     }
     }       // geometry phase
     if (do_field) {
+    // (eval mode: the count words were cleared in the geometry phase; the split-fp16 passes count what they flag for k_field<fix>)
+    int32_t* const fcnt = skip ? w.count + DSN_CNT_FLAGGED : nullptr;
     if (flags & DSN_FIELD_FP32)
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     else if (skip && (flags & DSN_EARLY_STOP)) {
@@ -590,7 +593,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             }
             // (the sigma > 0 list and its relu records keep growing from slice to slice)
             dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, Nk, sl, sc, w.sigma, w.essence, w.masks, w.pos, pcnt, st,
-                                   w.rec_cap);
+                                   w.rec_cap, fcnt);
             if (k + 1 < K) dsn_launch_advance_T(w.sigma, w.transparent, z, ray_d, R, S, s0, s1, w.T, st);
         }
         // shading list: weights from the densities alone (the compositor without a colour and without per-ray outputs; flagged
@@ -602,10 +605,10 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, dsn_stop_eps(S), sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
                             w.count + DSN_CNT_STOP + 1, w.colour, st);
         dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, sel,
-                               w.count + DSN_CNT_SEL);
+                               w.count + DSN_CNT_SEL, fcnt);
         if (w.rec_cap < N)
-            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.rec_cap, w.sigma, w.essence, w.grad, st);
-        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.sigma, w.essence, w.grad, st);
+            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.rec_cap, w.sigma, w.essence, w.grad, st, fcnt);
+        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.sigma, w.essence, w.grad, st, fcnt);
         if (audit) dsn_launch_screen_audit(w.audit, w.count + DSN_CNT_AUDIT, w.audit_cap, w.sigma, w.count + DSN_CNT_AUDIT + 4, st);
         list = lit;
         cnt = w.count + DSN_CNT_LIT;
@@ -625,16 +628,17 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             cnt = kcnt;
         }
         dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.masks, w.pos, pcnt, st,
-                               w.rec_cap);
-        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap);
+                               w.rec_cap, fcnt);
+        dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, nullptr, nullptr,
+                               fcnt);
         list = w.pos;
         cnt = pcnt;
         // samples of the sigma > 0 list beyond the record capacity (none on ordinary frames: the launch is N - cap empty
         // workgroups' worth of looking): forward + reverse in one launch, bit-identical values
         if (w.rec_cap < N)
-            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, list, cnt, w.rec_cap, w.sigma, w.essence, w.grad, st);
+            dsn_launch_field16_from((const float*)packed, s.frame, w.x_c, N, list, cnt, w.rec_cap, w.sigma, w.essence, w.grad, st, fcnt);
         // range fallback: whatever either pass flagged (sigma = NaN; such samples are on the sigma > 0 list) in exact fp32
-        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
+        dsn_launch_field_fix((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st, fcnt);
         if (audit) dsn_launch_screen_audit(w.audit, w.count + DSN_CNT_AUDIT, w.audit_cap, w.sigma, w.count + DSN_CNT_AUDIT + 4, st);
     } else {
         dsn_launch_field16((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);

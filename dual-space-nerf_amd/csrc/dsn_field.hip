@@ -438,8 +438,10 @@ template <bool FIX>
 __global__ void __launch_bounds__(FIELD_THREADS, 1)
 k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
         int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad) {
+        float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, const int32_t* __restrict__ flag_count) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (fix) the split-fp16 launches count what they flag: nothing flagged - the normal case - and there is nothing to look for
+    if (FIX && flag_count && *flag_count == 0) return;
     const int64_t count = active_list ? (int64_t)(*active_count) : N;
     if (!FIX) {      // (its own instantiation: the loop below costs the plain kernel 6 % through register allocation)
         const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
@@ -468,17 +470,17 @@ void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float*
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field<false>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad);
+                       active_count, sigma, essence, grad, (const int32_t*)nullptr);
 }
 // range fallback of the split-fp16 kernels: exact-fp32 re-evaluation of the listed samples whose sigma is NaN
 void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                           const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                          float* grad, hipStream_t st) {
+                          float* grad, hipStream_t st, const int32_t* flag_count) {
     int64_t blocks = (N + FIELD_PTS_PER_BLOCK - 1) / FIELD_PTS_PER_BLOCK;
     if (blocks == 0) return;
     if (blocks > 2048) blocks = 2048;        // grid-stride (see k_field)
     hipLaunchKernelGGL(k_field<true>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, st, packed, fs, x_c, N, active_list,
-                       active_count, sigma, essence, grad);
+                       active_count, sigma, essence, grad, flag_count);
 }
 
 // ---------------------------------------------------------------------------------------------

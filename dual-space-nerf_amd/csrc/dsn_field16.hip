@@ -517,7 +517,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
           float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad,
           uint4* __restrict__ masks, int32_t* __restrict__ pos_list, int32_t* __restrict__ pos_count,
           float* __restrict__ tr_h, float* __restrict__ tr_a, float* __restrict__ tr_rr, int64_t slot_base, int64_t rec_cap,
-          const int32_t* __restrict__ sel) {
+          const int32_t* __restrict__ sel, int32_t* __restrict__ flag_count) {
+    // flag_count (optional): incremented once per sample this launch flags for the exact-fp32 fallback (sigma = NaN); k_field<fix>
+    //            looks at it first and leaves when nothing was flagged
     // slot_base: the launch works on list slots slot_base ... (FULL mode as the overflow pass of the eval split, see dsn_render_rays)
     // rec_cap  : capacity of the relu-record array in samples.  FWD / BWD index the records by the sample's slot on the
     //            sigma > 0 list (FWD writes a record only for the samples it appends there, BWD reads slot s of the list it
@@ -702,6 +704,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     // range guard, forward half: a flagged sample carries sigma = NaN until the exact-fp32 kernel has re-evaluated it
     const bool flag_fwd = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
     if (valid && half == 0) sigma[pt] = flag_fwd ? dsn_nan_flag() : sg;
+    if (MODE != F16_TRAIN && flag_fwd && valid && half == 0 && flag_count) atomicAdd(flag_count, 1);
     bool write_rec = ST && valid;
     if (MODE == F16_FWD) {
         // samples with positive density -> the reverse-pass list (flagged samples too: the fallback behind the reverse pass
@@ -851,7 +854,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const bool flagged = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
     if (flagged && valid && half == 0) {
         if (MODE == F16_TRAIN) { if (pos_count) atomicAdd(pos_count, 1); }    // training: counted, reported by the host mirror
-        else sigma[pt] = dsn_nan_flag();
+        else { sigma[pt] = dsn_nan_flag(); if (flag_count) atomicAdd(flag_count, 1); }
     }
     if (MODE == F16_TRAIN) break;   // (the training kernel keeps one tile per workgroup: its extra live state leaves no room for the loop's)
     __syncthreads();      // tile done: the ring is free for the next tile's first chunk
@@ -860,22 +863,24 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 
 void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                         const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                        float* grad, hipStream_t st) {
+                        float* grad, hipStream_t st, int32_t* flag_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, grad, (uint4*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0, (const int32_t*)nullptr);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, (int64_t)0, (const int32_t*)nullptr,
+                       flag_count);
 }
 // the same single-launch evaluation on slots slot_base ... of a list: the overflow pass of the eval split (samples of the
 // sigma > 0 list whose relu record did not fit get forward AND reverse here; identical values, see dsn_render_rays)
 void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* list,
-                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st) {
+                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st,
+                             int32_t* flag_count) {
     int64_t blocks = (N - slot_base + 127) / 128;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_field16<F16_FULL>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N, list, count, sigma,
                        essence, grad, (uint4*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, slot_base, (int64_t)0, (const int32_t*)nullptr);
+                       (float*)nullptr, slot_base, (int64_t)0, (const int32_t*)nullptr, flag_count);
 }
 // training: dense evaluation that also leaves h_l [7][N,256], the masked sigma-adjoints a_l [7][N,256] and the rgb hidden
 // layer [N,128] in row-major arrays for the weight-gradient products of dsn_train.hip
@@ -888,29 +893,30 @@ void dsn_launch_field16_train(const float* packed, const DsnFrameState* fs, cons
     // row_list / row_count (optional): only the listed samples are evaluated (their rows are written, the others left alone)
     hipLaunchKernelGGL(k_field16<F16_TRAIN>, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        row_list, row_count, sigma, essence, grad, (uint4*)masks, (int32_t*)nullptr,
-                       range_count, tr_h, tr_a, tr_rr, (int64_t)0, N, (const int32_t*)nullptr);
+                       range_count, tr_h, tr_a, tr_rr, (int64_t)0, N, (const int32_t*)nullptr, (int32_t*)nullptr);
 }
 // eval-mode split: forward on the active samples (+ masks, + list of sigma > 0 samples) ...
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap) {
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap, int32_t* flag_count) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_field16<F16_FWD>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        active_list, active_count, sigma, essence, (float*)nullptr, (uint4*)masks, pos_list, pos_count,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, (const int32_t*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, (const int32_t*)nullptr, flag_count);
 }
 // ... reverse pass on the sigma > 0 samples only
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
-                            hipStream_t st, float* sigma, int64_t rec_cap, const int32_t* sel, const int32_t* sel_count) {
+                            hipStream_t st, float* sigma, int64_t rec_cap, const int32_t* sel, const int32_t* sel_count,
+                            int32_t* flag_count) {
     // sel / sel_count (DSN_EARLY_STOP): walk only the listed slots of pos_list (all below rec_cap); N bounds their number
     int64_t blocks = ((rec_cap < N ? rec_cap : N) + 127) / 128;
     if (blocks == 0) return;
     // sigma: only ever WRITTEN here, with the NaN flag of a sample whose adjoints left the fp16 range (see the header)
     hipLaunchKernelGGL(k_field16<F16_BWD>, dim3((unsigned)std::min<int64_t>(blocks, dsn_cu_count())), dim3(F16_THREADS), 0, st, packed, fs, x_c, N,
                        pos_list, sel ? sel_count : pos_count, sigma, (float*)nullptr, grad, (uint4*)masks, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, sel);
+                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, rec_cap, sel, flag_count);
 }
 
 // ---------------------------------------------------------------------------------------------

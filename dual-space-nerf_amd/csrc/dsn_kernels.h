@@ -56,13 +56,15 @@ void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t
                           float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false);
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap);
+                            void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap,
+                            int32_t* flag_count = nullptr);
 void dsn_launch_field16_from(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* list,
-                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st);
+                             const int32_t* count, int64_t slot_base, float* sigma, float* essence, float* grad, hipStream_t st,
+                             int32_t* flag_count = nullptr);
 void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* pos_list, const int32_t* pos_count, float* grad, const void* masks,
                             hipStream_t st, float* sigma, int64_t rec_cap, const int32_t* sel = nullptr,
-                            const int32_t* sel_count = nullptr);
+                            const int32_t* sel_count = nullptr, int32_t* flag_count = nullptr);
 void dsn_launch_screen16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N, const int32_t* active_list,
                          const int32_t* active_count, float* sigma, int32_t* keep_list, int32_t* keep_count, float* dbg_sigma,
                          float* dbg_s1, hipStream_t st, int32_t* audit_list = nullptr, int32_t* audit_count = nullptr,
@@ -86,13 +88,14 @@ void dsn_launch_pack_params(const float* const* params33_dev_array, float* packe
 void dsn_launch_field(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                       const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                       float* grad, hipStream_t st);
-// exact-fp32 re-evaluation of the listed samples whose sigma is NaN (range fallback of the split-fp16 kernels)
+// exact-fp32 re-evaluation of the listed samples whose sigma is NaN (range fallback of the split-fp16 kernels); flag_count
+// (optional): what the split-fp16 launches counted while flagging - zero: the kernel leaves without looking
 void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                           const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                          float* grad, hipStream_t st);
+                          float* grad, hipStream_t st, const int32_t* flag_count = nullptr);
 void dsn_launch_field16(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                         const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
-                        float* grad, hipStream_t st);
+                        float* grad, hipStream_t st, int32_t* flag_count = nullptr);
 void dsn_launch_light(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                       const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                       int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st);
