@@ -379,6 +379,7 @@ int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, co
 // workspace carve for the fused path
 #define DSN_CELLMAJOR_MIN (1 << 20)   // below ~1 M samples the five extra launches cost more than they save (measured:
                                       // -0.12 ms at 128x128x32, +0.42 ms at 256x256x64)
+#define DSN_TRAIN_FAR_SEARCH_MIN (1 << 15)   // train mode: batches from here on search their far canonical points cell-major
 struct DsnWorkspace {
     int32_t* count;       // [128] (first word = number of active samples)
     int32_t* active;      // [N]
@@ -694,7 +695,16 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     // (skipped rows keep whatever their density slot held: the compositor masks transparent samples itself)
     dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st,
                              w.count + DSN_CNT_RANGE, c.list1, c.rowcnt);
-    dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st);
+    // The canonical points of transparent samples (evaluated when their noise is positive) lie far from the body, outside the fine
+    // grid: the coarse-level cell-major search finds their nearest face first (same lists, same index as k_normal's own walk;
+    // scratch: buffers of the render workspace that train mode does not use) and k_normal takes it from there
+    const int32_t* nn_far = nullptr;
+    const char* far_env = getenv("DSN_TRAIN_FAR_SEARCH_MIN");      // test / tuning override (a huge value switches it off)
+    if (!exh && N >= (far_env ? atoll(far_env) : (long long)DSN_TRAIN_FAR_SEARCH_MIN)) {
+        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, (void*)w.n_w, w.pos, w.nn_small, st);
+        nn_far = w.pos;
+    }
+    dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st, nn_far);
     dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, c.list1, c.rowcnt, w.colour, st,
                        c.hl1, c.hl2, c.pre);
     // (a colour is read only where relu(density + noise) > 0: skipped rows never are)

@@ -578,7 +578,9 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const flo
                                                           int64_t N, const int32_t* __restrict__ active_list,
                                                           const int32_t* __restrict__ active_count,
                                                           int32_t* __restrict__ face_idx_canon,
-                                                          float* __restrict__ n_w) {
+                                                          float* __restrict__ n_w, const int32_t* __restrict__ nn_far) {
+    // nn_far (optional): the answer for points outside the fine grid, where the coarse-level cell-major search has found one
+    // (dsn_launch_nn_cellmajor_coarse: training batches); -1 elsewhere
     __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];
     int64_t count = active_list ? (int64_t)(*active_count) : N;
     int64_t slot0 = (int64_t)blockIdx.x * WARP_THREADS;
@@ -591,7 +593,10 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const flo
     int fi = 0;
     if (EXHAUSTIVE) fi = dsn_nearest_bruteforce(cent_canon, F, p[0], p[1], p[2], s_tile);
     else {
-        if (valid) fi = dsn_nearest_fine_try(nn.gf, nn.off_f, nn.list_f, p[0], p[1], p[2]);
+        if (valid) {
+            const int far = nn_far ? nn_far[i] : -1;
+            fi = far >= 0 ? far : dsn_nearest_fine_try(nn.gf, nn.off_f, nn.list_f, p[0], p[1], p[2]);
+        }
         // Canonical points outside the fine grid (dense training batches: transparent samples away from the body) scan a coarse
         // list (hundreds to thousands of gathered centroids) or all F centroids.  When only a few lanes of the wave are in that
         // position, the wave takes them one at a time and scans each list together (64 candidates per step, then an argmin with
@@ -650,15 +655,15 @@ __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const flo
 
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
-                       bool exhaustive, hipStream_t st) {
+                       bool exhaustive, hipStream_t st, const int32_t* nn_far) {
     int64_t blocks = (N + WARP_THREADS - 1) / WARP_THREADS;
     DsnNNArgs nn = dsn_nn_args(s.nn_canon);
     if (exhaustive)
         hipLaunchKernelGGL(k_normal<true>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_canon, s.face_world,
-                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
+                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, (const int32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_normal<false>, dim3((unsigned)blocks), dim3(WARP_THREADS), 0, st, nn, s.cent_canon, s.face_world,
-                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w);
+                           s.face_canon, s.F, x_c, grad, N, active_list, active_count, face_idx_canon, n_w, nn_far);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -35,6 +35,9 @@ void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o
                      const int32_t* only_cell_of = nullptr, const int32_t* only_count = nullptr);
 // dsn_nn.hip: cell-major exact search of the fine lists (nn [N]: index, or -1 where the fine grid does not cover)
 size_t dsn_nn_sort_scratch_size(int64_t N);
+// nn [N] <- exact nearest centroid for the (live) points outside the fine grid and inside the coarse one, -1 for all others
+void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, const float* pts, const uint8_t* live, int64_t N,
+                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
 void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
                              int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
 // the same search with the rest of the warp stage fused behind it (transparent, x_c, active list written by the search kernel);
@@ -47,7 +50,7 @@ void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, con
                          int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
                        const int32_t* active_list, const int32_t* active_count, int32_t* face_idx_canon, float* n_w,
-                       bool exhaustive, hipStream_t st);
+                       bool exhaustive, hipStream_t st, const int32_t* nn_far = nullptr);
 // dsn_nn.hip
 void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
                          bool fine_only = false, bool dense_fine = false);

@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
                                                             const int32_t* __restrict__ wave_cell, const int32_t* __restrict__ wave_offs,
                                                             const int32_t* __restrict__ totals, const int32_t* __restrict__ offs,
                                                             const int32_t* __restrict__ counts, const float4* __restrict__ sorted,
-                                                            int32_t* __restrict__ nn, NnsWarp wp) {
+                                                            int32_t* __restrict__ nn, NnsWarp wp, const float4* __restrict__ cent) {
+    // cent (optional, WARP = false): the lists hold face INDICES (the coarse level: 4-byte entries) and the centroids come from
+    // this array - two dependent scalar loads per candidate instead of one, hidden by the eight waves a SIMD holds of this kernel
     const int lane = threadIdx.x & 63;
     // XCD-aware block -> wave map.  Consecutive waves work on the same cell and read the same candidate list; workgroup b
     // runs on XCD b % 8 (MI355X_MICROARCH.md), each with its own L2, so the plain map b -> waves 4b .. 4b+3 sends every
@@ -436,6 +438,78 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
         if (d.y < best[1]) { best[1] = d.y; bi[1] = id; }
     };
     int k = 0;
+    if (!WARP && cent) {
+        const int32_t* __restrict__ ids = reinterpret_cast<const int32_t*>(list_f) + o;
+        auto at = [&](int f) { float4 a = cent[f]; a.w = __int_as_float(f); return a; };
+        // (far points are few per coarse cell - a wave with at most 64 of them leaves the second slot of every lane empty: one
+        //  sample per lane, the plain fma chain of dsn_d2)
+        const bool single = cnt_c - (w - __builtin_amdgcn_readfirstlane(wave_offs[c])) * NNS_PER <= 64;      // wave-uniform
+        if (single) {
+            float b0 = INFINITY;
+            int i0 = 0;
+            const float qx = q[0].x, qy = q[0].y, qz = q[0].z;
+            auto step1 = [&](const float4 a) {
+                const float d = dsn_d2(qx, qy, qz, a);
+                if (d < b0) { b0 = d; i0 = __float_as_int(a.w); }
+            };
+            constexpr int NB1 = 4;
+            const int nb1 = n / NB1;
+            int g1[NB1], g2[NB1];
+            float4 c0[NB1], c1[NB1];
+            if (nb1 > 0) {
+#pragma unroll
+                for (int j = 0; j < NB1; ++j) g1[j] = ids[j];
+#pragma unroll
+                for (int j = 0; j < NB1; ++j) c0[j] = at(g1[j]);
+#pragma unroll
+                for (int j = 0; j < NB1; ++j) g1[j] = ids[NB1 * (1 < nb1 ? 1 : 0) + j];
+                for (int b = 0; b < nb1; ++b) {
+                    if (b + 1 < nb1) {
+#pragma unroll
+                        for (int j = 0; j < NB1; ++j) c1[j] = at(g1[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB1; ++j) g2[j] = ids[NB1 * (b + 2 < nb1 ? b + 2 : 0) + j];
+#pragma unroll
+                    for (int j = 0; j < NB1; ++j) step1(c0[j]);
+#pragma unroll
+                    for (int j = 0; j < NB1; ++j) { c0[j] = c1[j]; g1[j] = g2[j]; }
+                }
+            }
+            for (int kk = NB1 * nb1; kk < n; ++kk) step1(at(ids[kk]));
+            if (valid[0]) nn[__float_as_int(q[0].w)] = i0;
+            return;
+        }
+        // Two dependent scalar loads per candidate (index, then centroid), and scalar loads return out of order - the only wait is
+        // "all of them".  So the loop runs one batch ahead on each: while batch b is compared, the centroids of batch b + 1 (whose
+        // indices arrived a batch ago) and the indices of batch b + 2 are in flight; one wait per batch, behind the arithmetic.
+        constexpr int NB = 4;                       // (batches of 8 need more scalar registers than there are: spills into VGPR lanes)
+        const int nb = n / NB;
+        int f1[NB], f2[NB];
+        float4 a0[NB], a1[NB];
+        auto load_ids = [&](int b, int (&f)[NB]) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) f[j] = ids[NB * (b < nb ? b : 0) + j];      // (beyond the list: batch 0 again, never used)
+        };
+        auto load_cent = [&](const int (&f)[NB], float4 (&a)[NB]) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) a[j] = at(f[j]);
+        };
+        if (nb > 0) {
+            load_ids(0, f1);
+            load_cent(f1, a0);                      // a0 = batch 0
+            load_ids(1, f1);                        // f1 = indices of batch 1
+            for (int b = 0; b < nb; ++b) {
+                if (b + 1 < nb) load_cent(f1, a1);  // centroids of batch b + 1
+                load_ids(b + 2, f2);                // indices of batch b + 2
+#pragma unroll
+                for (int j = 0; j < NB; ++j) step(a0[j]);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { a0[j] = a1[j]; f1[j] = f2[j]; }
+            }
+        }
+        for (k = NB * nb; k < n; ++k) step(at(ids[k]));
+    } else {
     for (; k + 8 <= n; k += 8) {                     // wave-uniform addresses: 128 B of candidates per scalar-load batch
         float4 a[8];
 #pragma unroll
@@ -444,6 +518,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
         for (int j = 0; j < 8; ++j) step(a[j]);
     }
     for (; k < n; ++k) step(e[k]);
+    }
     if (!WARP) {
         if (valid[0]) nn[__float_as_int(q[0].w)] = bi[0];
         if (valid[1]) nn[__float_as_int(q[1].w)] = bi[1];
@@ -517,7 +592,7 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
     hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
-                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, (int32_t*)nullptr, wp);
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, (int32_t*)nullptr, wp, (const float4*)nullptr);
 }
 
 void dsn_nn_cellmajor_begin(void* small, int32_t** counts, int32_t** outside, hipStream_t st) {
@@ -552,5 +627,46 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     hipLaunchKernelGGL(k_nns_search<false>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
-                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn, NnsWarp{});
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn, NnsWarp{}, (const float4*)nullptr);
+}
+
+// The same cell-major search at the COARSE level, for the points that lie outside the fine grid (and inside the coarse one): a
+// training batch evaluates transparent samples whose noise is positive, and their canonical points sit far from the body - 44 % of
+// the rows k_normal sees, each lane gathering a ~1000-entry coarse list of its own (0.6 of the kernel's 0.9 ms).  Sorted by coarse
+// cell, a wave shares one list through the scalar cache.  Same lists, same order, same strict '<' as dsn_nearest_lists.
+//   live (optional): only points with live[i] != 0 take part.  nn[i] = -1 for every point that is not searched here.
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_classify_coarse(const DsnGrid* __restrict__ gf, const DsnGrid* __restrict__ gc,
+                                                                     const float* __restrict__ pts, const uint8_t* __restrict__ live,
+                                                                     int64_t N, int32_t* __restrict__ cell_of, int32_t* __restrict__ nn,
+                                                                     int32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int c = -1;
+    if (i < N && (!live || live[i])) {
+        const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        if (dsn_grid_cell(*gf, px, py, pz) < 0) c = dsn_grid_cell(*gc, px, py, pz);
+    }
+    if (i < N) { cell_of[i] = c; if (c < 0) nn[i] = -1; }
+    const NnsRun r = nns_run(c, lane);
+    if (r.head && c >= 0) atomicAdd(counts + c, r.len);
+}
+void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, const float* pts, const uint8_t* live, int64_t N,
+                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st) {
+    char* q = (char*)small;
+    int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* offs = (int32_t*)q;       q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* wave_offs = (int32_t*)q;  q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
+    int32_t* totals = (int32_t*)q;     q += 256;
+    int32_t* wave_cell = (int32_t*)q;
+    static_assert(DSN_NN_COARSE_MAXCELL <= DSN_NN_FINE_MAXCELL, "the sort scratch is sized for the fine level");
+    (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_COARSE_MAXCELL + 1), st);
+    const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
+    hipLaunchKernelGGL(k_nns_classify_coarse, gN, b, 0, st, v.fine.g, v.coarse.g, pts, live, N, cell_of, nn, counts);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell);
+    hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,
+                       offs, counts, (float4*)sorted);
+    const int64_t max_waves = N / NNS_PER + DSN_NN_COARSE_MAXCELL + 1;
+    hipLaunchKernelGGL(k_nns_search<false>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.coarse.offsets, (const float4*)v.coarse.list,
+                       wave_cell, wave_offs, totals, offs, counts, (const float4*)sorted, nn, NnsWarp{}, cent);
 }

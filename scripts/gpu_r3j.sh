@@ -7,7 +7,7 @@ python -c "
 import json
 d=json.load(open('${O}_train_$wt.json')); print('$wt', {k: d[k] for k in d if 'ms' in k or 'rows' in k})"
 done
-timeout 300 python bench.py --train --steps 30 --warmup 5 2>/dev/null | tail -1 > ${O}_train_nopre.json
+DSN_TRAIN_FAR_SEARCH_MIN=99999999999 timeout 300 python bench.py --train --steps 30 --warmup 5 2>/dev/null | tail -1 > ${O}_train_nopre.json
 python -c "
 import json
 d=json.load(open('${O}_train_nopre.json')); print('nopre', {k: d[k] for k in d if 'ms' in k})"

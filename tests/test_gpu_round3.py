@@ -219,6 +219,41 @@ def test_training_row_skip_is_exact(name, monkeypatch):
         assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.parametrize("name", ["full_train_grads", "full_train_grads_w4"])
+def test_training_far_point_search_is_bit_identical(name, monkeypatch):
+    """Round 3: a training batch evaluates transparent samples with positive noise; their canonical points lie outside the fine
+    nearest-face grid, and big batches send them through a coarse-level cell-major search before k_normal (a wave shares one
+    coarse list instead of every lane gathering its own).  Same lists, same order, same tie rule: outputs equal the per-lane
+    walk's bit for bit, gradients up to the summation order of the atomics - and the batch really has such points"""
+    import test_gpu_render as TR
+    from helpers import load
+    g = load(name)
+
+    def run():
+        r = TR.make_renderer(g, name)
+        r.cfg.MODEL.raw_noise_std = max(float(g["raw_noise_std"]), 1.0)
+        r.train()
+        torch.manual_seed(int(g["seed"]))
+        out = r.render(TR.make_batch(g))["coarse"]
+        loss = ((out["color"] - torch.from_numpy(g["target_rgb"]).cuda()) ** 2).mean() + 0.1 * out["acc_map"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in out.items()}, {k: p.grad.detach().clone() for k, p in r.net.named_parameters()})
+
+    monkeypatch.setenv("DSN_TRAIN_FAR_SEARCH_MIN", "1")
+    out_a, grad_a = run()
+    monkeypatch.setenv("DSN_TRAIN_FAR_SEARCH_MIN", str(1 << 40))
+    out_b, grad_b = run()
+    monkeypatch.delenv("DSN_TRAIN_FAR_SEARCH_MIN")
+    assert float(out_a["acc_map"].max()) > 0.01
+    for k in out_a:
+        assert torch.equal(torch.nan_to_num(out_a[k], nan=-1.0), torch.nan_to_num(out_b[k], nan=-1.0)), k
+    for k in grad_a:
+        a, b = grad_a[k].double(), grad_b[k].double()
+        assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
+    assert float(grad_a["lighting_mlp.lights_encoding.0.weight"].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("wname,far_rays", [("", False), ("x_w4", False), ("", True)])
 def test_fused_search_and_warp_equals_the_two_kernel_form(wname, far_rays, monkeypatch):
     """Round 3: in the fused path the cell-major nearest-face kernel also does the rest of the warp stage (projection, transparency,
