@@ -392,6 +392,14 @@ def main():
                                                                          caller_torch_op=True)
         ex["host_threads"] = torch.get_num_threads()
         ex["host_cpu_quota_cores"] = _lib.cpu_quota_cores()
+        # the per-sample workspace is the caller's to size: the same render_view in four ray chunks (the reference's own loop runs
+        # 3072-ray chunks, can_render.py:172-245) needs a quarter of it, for this much time
+        chunk = (H * W) // 4
+        ex["chunked_frame"] = {"chunk_rays": chunk,
+                               "workspace_gb_whole_frame": _lib.lib().dsn_render_workspace_bytes(H * W, S) / 1e9,
+                               "workspace_gb_chunked": _lib.lib().dsn_render_workspace_bytes(chunk, S) / 1e9,
+                               "host_to_host_ms": host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
+                                                               chunk=chunk)}
         # BASELINE configs[2] in the same line: 8192 x 64 training step (render + MSE + backward + Adam)
         t_dt, t_loss, t_ovf, t_rows = train_measure(args, dsnerf_amd, synth, dev, 1, 0, False, 20, 5)
         if os.path.exists(os.path.join(ROOT, "tests", "golden", "weights_w4.npz")):
@@ -418,7 +426,7 @@ def main():
         print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
 
 
-def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S, caller_torch_op=False):
+def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S, caller_torch_op=False, chunk=None):
     """The reference's render_view contract (can_render.py:248-278): a batch of HOST tensors in (what its DataLoader hands
     over), four HOST images out, one frame at a time through the Renderer mirror.  PCIe-inclusive: never `value`.
     The fresh per-frame near / far tensors (render_view updates them in place) are made with numpy, like the product of a DataLoader
@@ -458,7 +466,7 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
             b["near"], b["far"] = torch.from_numpy(batch["near"].numpy().copy()), torch.from_numpy(batch["far"].numpy().copy())
         torch.cuda.synchronize()
         t = time.perf_counter()
-        out = r.render_view(b)
+        out = r.render_view(b, chunk=chunk)      # (chunk: rays per dsn_render_rays call; the workspace is sized for one chunk)
         assert not out["coarse_color"].is_cuda
         if i >= 4:
             ms.append(1e3 * (time.perf_counter() - t))
