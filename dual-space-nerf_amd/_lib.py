@@ -118,7 +118,12 @@ def fit_host_pool():
     quota = cpu_quota_cores()
     if quota is None or os.environ.get("DSN_HOST_POOL", "") == "keep":
         return before, before, quota
-    want = max(1, int(quota) - 2)
+    # one process per GPU: the quota is shared by the processes of this node (torchrun exports LOCAL_WORLD_SIZE)
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    want = max(1, int(quota / local_world) - 2)
     if before > want:
         torch.set_num_threads(want)
     return before, torch.get_num_threads(), quota
