@@ -66,6 +66,36 @@ def test_render_view_between_the_callers_torch_cpu_ops():
     assert np.median(busy) <= 1.25 * np.median(plain) + 1e-3, (np.median(plain), np.median(busy), sorted(busy))
 
 
+@pytest.mark.parametrize("wname", ["", "x_w4"])
+def test_render_view_in_ray_chunks_equals_the_whole_frame(wname):
+    """The per-sample workspace is the caller's to size: render_view(batch, chunk=...) renders the frame in ray
+    chunks on a workspace sized for ONE chunk - the same images bit for bit (rays are independent; the exact-by-margin screen and
+    the exact fallbacks do not see chunk boundaries; early stop stays off here: its probe is per call)."""
+    from dsnerf_amd import _lib
+    H = 256
+    canon, faces, batch = full_frame(hw=H)
+
+    def run(chunk):
+        r = renderer_with(state(wname) if wname else state(), canon, faces)
+        r.eval()
+        r.early_stop = False
+        b = dict(batch)
+        b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        out = r.render_view(b, chunk=chunk)
+        torch.cuda.synchronize()
+        return out, r._ws.cap
+
+    whole, cap_whole = run(None)
+    parts, cap_parts = run(H * H // 4)
+    ragged, _ = run(H * H // 4 + 777)
+    S = 64
+    assert cap_parts == _lib.lib().dsn_render_workspace_bytes(H * H // 4, S) < 0.5 * cap_whole      # (a quarter at 512 x 512)
+    assert float(whole["coarse_color"].max()) > 0.05
+    for k in whole:
+        assert torch.equal(torch.nan_to_num(whole[k], nan=-1.0), torch.nan_to_num(parts[k], nan=-1.0)), k
+        assert torch.equal(torch.nan_to_num(whole[k], nan=-1.0), torch.nan_to_num(ragged[k], nan=-1.0)), k
+
+
 def test_converged_checkpoint_on_the_bench_frame():
     """w4 (trained to convergence by the HIP trainer, pinned by reference-generated goldens) on a 256 x 256 frame of the bench
     camera: the field is bimodal (most rays are either empty or opaque), termination pays, and the sliced frame stays within its
