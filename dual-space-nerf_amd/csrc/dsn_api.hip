@@ -425,9 +425,11 @@ static inline float dsn_stop_eps(int S) {
     const float e = 1e-4f / (2.0f * (float)(S + 1));
     return e < cap ? e : cap;
 }
-static inline int dsn_slice_len(int S) {
+// samples per slice: 4 on big frames (finer termination: the converged set's 512 x 512 x 64 frame 10.32 -> 9.99 ms, w3 12.52 -> 12.22 with
+// two frames in flight; profiles/r03_stop_slice_sweep.txt), 8 where the three launches per slice weigh more than the samples they save
+static inline int dsn_slice_len(int R, int S) {
     const char* e = getenv("DSN_STOP_SLICE");      // experiments: samples per slice
-    int L = e ? atoi(e) : 8;
+    int L = e ? atoi(e) : ((int64_t)R * S >= ((int64_t)1 << 22) ? 4 : 8);
     if (L < 1) L = 8;
     if (L > 64) L = 64;
     return (S + L - 1) / L <= DSN_STOP_MAX_SLICES ? L : (S + DSN_STOP_MAX_SLICES - 1) / DSN_STOP_MAX_SLICES;
@@ -566,7 +568,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         dsn_launch_field((const float*)packed, s.frame, w.x_c, N, list, cnt, w.sigma, w.essence, w.grad, st);
     else if (skip && (flags & DSN_EARLY_STOP)) {
         // eval mode, front to back: slices of L samples along the rays; a ray whose transmittance has fallen below eps is finished
-        const int L = dsn_slice_len(S), K = (S + L - 1) / L;
+        const int L = dsn_slice_len(R, S), K = (S + L - 1) / L;
         const int64_t cap = (int64_t)R * L;
         const bool screen = !(flags & DSN_NO_SCREEN);
         const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
@@ -660,7 +662,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st, skip);
     if ((flags & DSN_STOP_STATS) && skip)
-        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(S), dsn_stop_eps(S), w.count + DSN_CNT_STOP + 2, st);
+        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(R, S), dsn_stop_eps(S), w.count + DSN_CNT_STOP + 2, st);
     }       // shading phase
     return dsn_check_launch("dsn_render_rays");
 }
