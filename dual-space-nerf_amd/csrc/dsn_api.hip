@@ -411,7 +411,9 @@ struct DsnWorkspace {
                               //                   [45] their max sigma (float bits), [46] samples audited (<= capacity)
 #define DSN_CNT_RANGE 48      // dsn_render_rays_train: samples whose activations / adjoints left the fp16 range
 #define DSN_CNT_FLAGGED 20    // eval mode: samples the split-fp16 passes flagged for the exact-fp32 fallback (k_field<fix> looks here first)
-#define DSN_CNT_BYTES 512
+#define DSN_CNT_ALIVE_K 96    // DSN_EARLY_STOP: [96..127] live samples of slice k, [128..159] samples of slice k the screen kept (a counter
+#define DSN_CNT_KEEP_K 128    //                 of its own per slice: no clearing launches inside the slice loop)
+#define DSN_CNT_BYTES 1024
 #define DSN_CNT_SLICE 64      // DSN_EARLY_STOP: [64..95] active samples per slice (at most 32 slices), [12] alive in the current slice,
 #define DSN_STOP_MAX_SLICES 32
 #define DSN_CNT_ALIVE 12      //                 [13] reverse-pass slots, [14] shaded samples
@@ -581,14 +583,13 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             const int32_t* sl = w.slices + (int64_t)k * cap;
             const int32_t* sc = w.count + DSN_CNT_SLICE + k;
             if (k > 0) {
-                if (hipMemsetAsync(w.count + DSN_CNT_ALIVE, 0, 4, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
-                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, dsn_stop_eps(S), w.alive, w.count + DSN_CNT_ALIVE, w.count + DSN_CNT_STOP, st);
+                int32_t* acnt = w.count + DSN_CNT_ALIVE_K + k;
+                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, dsn_stop_eps(S), w.alive, acnt, w.count + DSN_CNT_STOP, st);
                 sl = w.alive;
-                sc = w.count + DSN_CNT_ALIVE;
+                sc = acnt;
             }
             if (screen) {
-                int32_t* kcnt = w.count + DSN_CNT_KEEP;
-                if (k > 0 && hipMemsetAsync(kcnt, 0, 4, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays: memset failed");
+                int32_t* kcnt = w.count + DSN_CNT_KEEP_K + k;
                 dsn_launch_screen16((const float*)packed, s.frame, w.x_c, Nk, sl, sc, w.sigma, w.keep, kcnt, nullptr, nullptr, st,
                                     audit ? w.audit : nullptr, audit ? w.count + DSN_CNT_AUDIT : nullptr, w.audit_cap);
                 sl = w.keep;
