@@ -532,6 +532,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     // vmcnt wait would drain the LDS-DMA queue): [bias0 256 | OFF_B1.. 2304 (6 biases, rgb bias, W_den, W_rgb3) | scalars 8]
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
+    __shared__ int s_app[8];      // forward kernel: per-wave counts + base of the tile's append to the sigma > 0 list
     const int tid0 = threadIdx.x;
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -712,9 +713,18 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         const bool pos = valid && half == 0 && (sg > 0.0f || flag_fwd);
         const unsigned long long bm = __ballot(pos);
         const int cnt = __popcll(bm);
-        int base = 0;
-        if (lane == 0 && cnt) base = atomicAdd(pos_count, cnt);
-        base = __shfl(base, 0);
+        // workgroup-aggregated append: the tile's samples stay together on the sigma > 0 list (they are neighbours in the cell-major
+        // order of the nearest-face sort, and k_normal / the reverse pass / k_light16 read their lists 64 - 128 entries per wave /
+        // workgroup: per-wave appends interleave 32-sample pieces of different tiles)
+        if (lane == 0) s_app[wave] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            const int tot = s_app[0] + s_app[1] + s_app[2] + s_app[3];
+            s_app[4] = tot ? atomicAdd(pos_count, tot) : 0;
+        }
+        __syncthreads();
+        int base = s_app[4];
+        for (int k = 0; k < wave; ++k) base += s_app[k];
         const int my = base + __popcll(bm & ((1ull << lane) - 1ull));
         if (pos) pos_list[my] = (int32_t)pt;
         // its relu record goes to the same slot (both half-waves hold a half of it); none beyond the capacity
