@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--early-stop", default="auto", choices=["auto", "on", "off"],
                     help="front-to-back slices with ray termination (DSN_EARLY_STOP): auto = like Renderer, from the statistics of one "
                          "probe frame at set-up (used when it would leave out >= 4 %% of the non-transparent samples)")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="frames in flight (own scene / workspace each); 1 = strictly serial.  How they overlap: --overlap")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="frames in flight (own scene / workspace each); 1 = strictly serial.  How they overlap: --overlap.  Measured "
+                         "(profiles/r03_frames_in_flight.txt): 3 against 2 is -1.5 %% on the default frame, -2.6 %% on the converged set, 4 is no better")
     ap.add_argument("--overlap", default="frame", choices=["phase", "frame"],
                     help="frame (default): one HIP stream per frame in flight; phase: one stream for the field kernels and one for "
                          "everything else (_lib.PhasePipeline: geometry of frame k+1 and shading of frame k-1 BESIDE the field kernels of "
@@ -167,7 +168,8 @@ def main():
     gathered = [torch.empty(world * R, 6, dtype=torch.float32, device=dev) if use_dist else None for _ in range(depth)]
     packed_px = [torch.empty(R, 6, dtype=torch.float32, device=dev) for _ in range(depth)]
     for j in range(depth):          # allocate every slot's workspace up front (setup, not a step: W may be smaller than the depth)
-        wss[j].get(R, S)
+        wss[j].get(R, S).zero_()    # ... and touch it: the first GPU access to fresh device memory costs ~12 ms per 3.4 GB (measured: a slot
+    torch.cuda.synchronize()        #     first used inside the timed region made 3 frames in flight look 5 % SLOWER than 2 at W = 2)
 
     def prepare(state_dict):
         """what Renderer does once per checkpoint (set-up, not a step): pack the parameters, measure the density screen's margin
@@ -258,6 +260,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not a step: every slot (scene blob, workspace, output buffers, stream) renders one frame before anything is timed, as slot 0
+    # has in prepare() - a slot's first frame carries its one-off costs (first GPU access to its buffers, allocations: 4-12 ms), and
+    # with W < depth it would fall into the timed region (measured: 3 frames in flight looked 2-5 % slower than 2 at W = 2 and are
+    # 1.5 % faster in steady state).  Then W warm-up steps and exactly K timed steps, as always.
+    for _ in range(depth):
+        step()
+    barrier()
+    k_step = 0
     for _ in range(args.warmup):
         step()
     barrier()
@@ -314,6 +324,7 @@ def main():
             "early_stop": stop_info,
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "overlap": ("none" if depth == 1 else args.overlap), "ms_per_frame_alone": ms_serial,
+            "setup_frames_per_slot": 1,      # (untimed, before the W warm-up steps: a slot's first frame carries its one-off costs)
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,

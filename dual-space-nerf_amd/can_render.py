@@ -677,7 +677,7 @@ class Renderer:
         # by one thread (see _dev)
         return {k: torch.from_numpy(stage[k].numpy().copy()) for k in keys}
 
-    def render_views(self, batches, frames_in_flight=2, device_output=True, chunk=None):
+    def render_views(self, batches, frames_in_flight=3, device_output=True, chunk=None):
         """The per-frame loop of novel_pose_vis.py:41-66 / test.py:55-64 (`for batch in loader: render.render_view(batch)`) as
         ONE call over an iterable of batches, with `frames_in_flight` frames on their own HIP streams (own scene blob and
         workspace each): the per-frame setup, sampling and warp kernels of frame k+1 run beside the matrix-bound field kernels
