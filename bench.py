@@ -209,6 +209,9 @@ def main():
 
     pipe = _lib.PhasePipeline(dev) if (args.overlap == "phase" and depth > 1) else None
 
+    # frames in flight: the persistent field kernels take 7/8 of the compute units (DSN_SHARE_CUS, what Renderer.render_views sets);
+    # off for the frames timed alone
+    share_cus = [depth > 1 and os.environ.get("DSN_BENCH_SHARE_CUS", "1") != "0"]
     audit_every = dsnerf_amd.can_render.SCREEN_AUDIT_EVERY      # what Renderer does by default (screen_audit = "auto")
     audit_of = {}
 
@@ -218,7 +221,7 @@ def main():
         outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                    skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
                                    screen=not cur["no_screen"], early_stop=cur["early"], phases=phases,
-                                   audit=audit_of.get(j, False))
+                                   audit=audit_of.get(j, False), share_cus=share_cus[0])
 
     def exchange(j):
         if use_dist:
@@ -278,6 +281,7 @@ def main():
     dt = time.perf_counter() - t0
     # latency of one frame alone (no overlap with a neighbour), for the record
     k_step = 0
+    share_cus[0] = False
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(3):
@@ -324,6 +328,7 @@ def main():
             "early_stop": stop_info,
             "ms_per_frame": ms_step,
             "frames_in_flight": depth, "overlap": ("none" if depth == 1 else args.overlap), "ms_per_frame_alone": ms_serial,
+            "persistent_kernels_share_cus": bool(depth > 1 and os.environ.get("DSN_BENCH_SHARE_CUS", "1") != "0"),
             "setup_frames_per_slot": 1,      # (untimed, before the W warm-up steps: a slot's first frame carries its one-off costs)
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
@@ -337,6 +342,7 @@ def main():
         # 5 timed frames each, for every parameter set the repo pins with reference-generated goldens.  w4 is the converged one.
         headline = cur
         by = {}
+        share_cus[0] = depth > 1 and os.environ.get("DSN_BENCH_SHARE_CUS", "1") != "0"      # (frames in flight again)
         for name in ("default", "w2", "w3", "w4"):
             if name in ("w2", "w4") and not os.path.exists(os.path.join(ROOT, "tests", "golden", f"weights_{name}.npz")):
                 continue
@@ -369,6 +375,7 @@ def main():
         cur = headline
         k_step = 0
         result["config"]["by_weights"] = by
+        share_cus[0] = False
         result["config"]["by_weights_note"] = ("same frame and pipeline for every parameter set; default = hash-random init (thin fog), w2 = 400 "
                                                "reference-trainer steps (solid, unsaturated), w3 = hash init x3.5 (dense guess), w4 = converged "
                                                "with scripts/train_w4.py: the representative checkpoint")

@@ -49,6 +49,7 @@ NO_SCREEN = 16
 SCREEN_AUDIT = 32
 EARLY_STOP, STOP_STATS = 64, 128
 PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
+SHARE_CUS = 2048              # frames in flight: the persistent field kernels take 7/8 of the compute units (dsnerf.h)
 CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
 EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
 SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.15      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
@@ -512,7 +513,8 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0):
+                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0,
+                share_cus=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors.
     phases: 0 = the whole frame; PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE = only those parts, on the current stream (the caller
     orders the three calls of a frame with its own events and passes the same `out` / workspace to all of them: PhasePipeline).
@@ -546,6 +548,8 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     if stop_stats:
         flags |= STOP_STATS
     flags |= int(phases) & (PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE)
+    if share_cus:
+        flags |= SHARE_CUS
     buf = ws.get(R, S)
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT

@@ -520,7 +520,8 @@ class Renderer:
                                 "early_stop": bool(plan["early_stop"]),
                                 "early_stop_eps": _lib.early_stop_eps(S) if plan["early_stop"] else None,
                                 "early_stop_bound_x_max_colour": (S + 1) * _lib.early_stop_eps(S) if plan["early_stop"] else 0.0}
-        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out, **plan)
+        out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out,
+                               share_cus=getattr(self, "_frames_overlap", False), **plan)
         if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
             snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
             ev = torch.cuda.Event()
@@ -685,7 +686,13 @@ class Renderer:
         device_output=True keeps the images on the GPU (the D2H copies of host outputs are issued on each frame's stream and
         overlap the next frames too)."""
         with _HostPoolGuard(self.host_pool_limit):
-            return self._render_views(batches, frames_in_flight, device_output, chunk)
+            # (with frames overlapping, the persistent field kernels leave an eighth of the compute units to the neighbours' small
+            #  kernels: DSN_SHARE_CUS, -1.4 % per frame; a frame alone keeps them all)
+            self._frames_overlap = int(frames_in_flight) > 1
+            try:
+                return self._render_views(batches, frames_in_flight, device_output, chunk)
+            finally:
+                self._frames_overlap = False
 
     def _render_views(self, batches, frames_in_flight, device_output, chunk):
         n = max(1, int(frames_in_flight))

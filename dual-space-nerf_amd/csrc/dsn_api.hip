@@ -22,6 +22,16 @@ static int dsn_check_launch(const char* what) {
 }
 #define DSN_REQUIRE(cond, msg) do { if (!(cond)) return dsn_fail("%s", msg); } while (0)
 
+thread_local int g_dsn_persistent_override = 0;
+namespace {
+struct DsnShareCus {      // DSN_SHARE_CUS for the duration of one dsn_render_rays call
+    explicit DsnShareCus(bool on) {
+        if (on) { const int n = dsn_cu_count_raw(); g_dsn_persistent_override = std::max(8, (n * 7 / 8) / 8 * 8); }
+    }
+    ~DsnShareCus() { g_dsn_persistent_override = 0; }
+};
+}
+
 struct DsnSceneHeader { int magic, V, F, has_body, has_frame; };
 #define DSN_MAGIC 0x44534e31
 
@@ -510,6 +520,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     DsnWorkspace w = dsn_carve(workspace, R, S);
     const int64_t N = (int64_t)R * S;
     float* z = out_z ? out_z : w.z;
+    const DsnShareCus share((flags & DSN_SHARE_CUS) != 0);
     // Phases (DSN_PHASE_*): none of the three bits = the whole frame on `stream`.  With bits set only those parts are enqueued, so
     // that a caller with several frames in flight can put the geometry / shading kernels of one frame on a stream of their own
     // BESIDE the matrix-bound field kernels of another (events between the calls are the caller's; the state that travels

@@ -5,7 +5,11 @@
 // persistent-workgroup kernels launch one workgroup per compute unit (DSN_PERSISTENT_GROUPS overrides the count: experiments)
 #include <algorithm>
 #include <cstdlib>
-inline int dsn_cu_count() {
+// (DSN_SHARE_CUS: dsn_render_rays sets the number of persistent workgroups for the launches of ITS call on ITS thread)
+extern thread_local int g_dsn_persistent_override;
+inline int dsn_cu_count_raw();
+inline int dsn_cu_count() { return g_dsn_persistent_override > 0 ? g_dsn_persistent_override : dsn_cu_count_raw(); }
+inline int dsn_cu_count_raw() {
     static const int n = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;

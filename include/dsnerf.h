@@ -311,6 +311,11 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
 #define DSN_PHASE_GEOMETRY 256
 #define DSN_PHASE_FIELD 512
 #define DSN_PHASE_SHADE 1024
+/* Frames in flight.  The field kernels are persistent: one workgroup per compute unit walks the tiles of a launch.  With several
+ * frames in flight on streams of their own, DSN_SHARE_CUS makes them take 7/8 of the compute units (a multiple of 8: one per XCD less
+ * ... 28 of 32 per XCD on the MI355X) and leaves the rest to the neighbours' small kernels: -1.4 % per frame with three frames in
+ * flight, +3 to +6 % for a frame that runs alone (profiles/r03_frames_in_flight.txt) - set it only when frames overlap.  Same values. */
+#define DSN_SHARE_CUS 2048
 /* (The test overrides DSN_RECORD_CAP / DSN_STOP_SLICE change the workspace layout and are read at every call: set them before
  *  the workspace is sized and leave them alone while it is in use.) */
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
