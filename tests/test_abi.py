@@ -39,6 +39,12 @@ def test_version_and_sizes(lib):
     n = lib.dsn_render_workspace_bytes(1024, 64)
     assert n >= 1024 * 64 * (4 + 1 + 4 + 12 * 5 + 4)
     assert lib.dsn_render_workspace_bytes(0, 64) == 0
+    # the per-sample workspace of the benchmark frame and of a quarter of its rays (sample-indexed arrays, 3.4 GB per
+    # frame in flight - a regression guard, and what Renderer.render_view(batch, chunk=65536) trades for +5-10 % time)
+    whole, quarter = lib.dsn_render_workspace_bytes(512 * 512, 64), lib.dsn_render_workspace_bytes(512 * 512 // 4, 64)
+    assert 3.3e9 < whole < 3.5e9 and whole / (512 * 512 * 64) < 206
+    assert 0.24 * whole < quarter < 0.26 * whole
+    assert lib.dsn_render_workspace_bytes(1024 * 1024, 128) < 46e9
 
 
 def test_errors_are_loud(lib):
