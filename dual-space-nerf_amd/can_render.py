@@ -628,10 +628,12 @@ class Renderer:
     def batchify_rays_view(self, ray_o, ray_d, near, far, batch, chunk=None, scene=None, ws=None):
         scene = self.scene if scene is None else scene
         ws = self._ws if ws is None else ws
+        # the frame's state first: its kernels (0.45 ms of nearest-face lists for the posed mesh) need the 82 KB of vertices only and
+        # run while this thread stages the 8 MB of rays through page-locked memory (-0.1 ms per render_view, A/B in one call)
+        self._set_frame(batch, scene=scene)
         o, d = self._dev(ray_o[0]), self._dev(ray_d[0])
         n, f = self._dev(near[0]).clone(), self._dev(far[0]).clone()
         S = self.cfg.MODEL.COARSE_RAY_SAMPLING
-        self._set_frame(batch, scene=scene)
         R = o.shape[0]
         chunk = R if chunk is None else int(chunk)
         screen = None
