@@ -1994,23 +1994,50 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         for (int i = threadIdx.x; i < 16 * 256; i += 256) d[4 * 128 + i] = g1[i];
     }
     __syncthreads();
+    // The inputs of a tile (its samples' normals, depths, rays) are gathers behind a list entry: two dependent trips to memory in
+    // front of 108 MFMAs, and a CU holds only two waves per SIMD of this kernel - the kernel was bound by that latency (0.30 ms
+    // for 0.05 ms of matrix work).  They are fetched one tile ahead now (the list entry two tiles ahead).
+    struct LightIn { float nw[3], o[3], d[3], z; };
+    auto tile_pt = [&](int64_t t, bool& ok) -> int64_t {
+        int64_t sl = (t * 4 + wave) * 32 + (lane & 31);
+        ok = t < ntiles && sl < count;
+        if (!ok) sl = count - 1;
+        return active_list ? (int64_t)active_list[sl] : sl;
+    };
+    auto fetch_in = [&](int64_t p, LightIn& a) {
+        const int64_t r = p / S;
+        a.nw[0] = n_w[3 * p]; a.nw[1] = n_w[3 * p + 1]; a.nw[2] = n_w[3 * p + 2];
+        a.d[0] = ray_d[3 * r]; a.d[1] = ray_d[3 * r + 1]; a.d[2] = ray_d[3 * r + 2];
+        if (x_w_pts) { a.o[0] = x_w_pts[3 * p]; a.o[1] = x_w_pts[3 * p + 1]; a.o[2] = x_w_pts[3 * p + 2]; a.z = 0.0f; }
+        else { a.o[0] = ray_o[3 * r]; a.o[1] = ray_o[3 * r + 1]; a.o[2] = ray_o[3 * r + 2]; a.z = z_vals[p]; }
+    };
+    bool valid_c, valid_n, valid_nn;
+    int64_t pt_c = tile_pt(blockIdx.x, valid_c);
+    LightIn in_c, in_n;
+    fetch_in(pt_c, in_c);
+    int64_t pt_n = tile_pt((int64_t)blockIdx.x + gridDim.x, valid_n);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t slot0 = (tile * 4 + wave) * 32;
+    const bool valid = valid_c;
+    const int64_t pt = pt_c;
+    const LightIn cur = in_c;
+    // next tile's inputs and the list entry of the one after it: in flight under this tile's arithmetic
+    fetch_in(pt_n, in_n);
+    const int64_t pt_nn = tile_pt(tile + 2 * (int64_t)gridDim.x, valid_nn);
+    pt_c = pt_n; valid_c = valid_n; in_c = in_n;
+    pt_n = pt_nn; valid_n = valid_nn;
     if (slot0 >= count) continue;                    // (no barrier inside the loop)
-    int64_t slot = slot0 + (lane & 31);
-    const bool valid = slot < count;
-    if (!valid) slot = count - 1;
-    const int64_t pt = active_list ? (int64_t)active_list[slot] : slot;
-    const int64_t ray = pt / S;
+    // (needed at the very end: fetched now, waited for behind the arithmetic)
+    const float ess[3] = {essence[3 * pt], essence[3 * pt + 1], essence[3 * pt + 2]};
 
     float in9[10];
-    in9[0] = n_w[3 * pt]; in9[1] = n_w[3 * pt + 1]; in9[2] = n_w[3 * pt + 2];
+    in9[0] = cur.nw[0]; in9[1] = cur.nw[1]; in9[2] = cur.nw[2];
     float xw[3];
-    const float d[3] = {ray_d[3 * ray], ray_d[3 * ray + 1], ray_d[3 * ray + 2]};
-    if (x_w_pts) { xw[0] = x_w_pts[3 * pt]; xw[1] = x_w_pts[3 * pt + 1]; xw[2] = x_w_pts[3 * pt + 2]; }
+    const float d[3] = {cur.d[0], cur.d[1], cur.d[2]};
+    if (x_w_pts) { xw[0] = cur.o[0]; xw[1] = cur.o[1]; xw[2] = cur.o[2]; }
     else {
-        const float z = z_vals[pt];
-        xw[0] = ray_o[3 * ray] + d[0] * z; xw[1] = ray_o[3 * ray + 1] + d[1] * z; xw[2] = ray_o[3 * ray + 2] + d[2] * z;
+        const float z = cur.z;
+        xw[0] = cur.o[0] + d[0] * z; xw[1] = cur.o[1] + d[1] * z; xw[2] = cur.o[2] + d[2] * z;
     }
     if (fs->has_rot != 0.0f) {
         const float ax = xw[0] - fs->rot_center[0], ay = xw[1] - fs->rot_center[1];
@@ -2061,9 +2088,9 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     const float wgt = (o > 0.0f ? o : expm1f(o)) + 1.0f;   // ELU(alpha=1) + 1
     if (tr_pre && valid && half == 0) tr_pre[pt] = o;
     if (valid && half == 0) {
-        colour[3 * pt + 0] = wgt * essence[3 * pt + 0];
-        colour[3 * pt + 1] = wgt * essence[3 * pt + 1];
-        colour[3 * pt + 2] = wgt * essence[3 * pt + 2];
+        colour[3 * pt + 0] = wgt * ess[0];
+        colour[3 * pt + 1] = wgt * ess[1];
+        colour[3 * pt + 2] = wgt * ess[2];
     }
   }
 }
