@@ -42,7 +42,15 @@ SPLIT_PRODUCTS = 3                           # split-fp16: 3 f16 MFMA products p
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  Launched by torch.distributed.run (WORLD_SIZE in the environment) it must equal the "
+                         "world size; WITHOUT a launcher and N > 1 bench.py re-executes itself under `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (weak, --strong and --train alike), so `python bench.py "
+                         "--gpus 8` measures 8 GPUs, never one")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise ONLY the launcher and the collectives of the selected mode (weak / --strong / --train) on the CPU with "
+                         "the gloo backend and a stand-in for the render (no GPU, no HIP library): proves that --gpus N starts N ranks which "
+                         "join the same collectives and that rank 0 prints one JSON line with n_gpus = N.  Not a measurement")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--hw", type=int, default=512, help="image side (BASELINE configs[1]: 512)")
@@ -111,34 +119,190 @@ def _flush_c_stdio():
         pass
 
 
+class Ranks:
+    """The process group of a bench run: one rank per GPU over RCCL (backend "nccl" on ROCm), or gloo on the CPU for --dry-launch.
+    Everything the three modes need from it: barrier, the max over ranks of the timed region, every rank's own time, and what the
+    JSON line reports about the group (`ranks`: did the collective library really see N ranks?)."""
+
+    def __init__(self, args):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = bool(args.dry_launch)
+        if args.gpus is not None and args.gpus != self.world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {self.world} ranks")
+        # DSN_BENCH_FORCE_DIST=1 (debug): take the RCCL path (process group, per-frame all-gather, barriers) with ONE rank too, so the
+        # multi-GPU code can be exercised on a 1-GPU box
+        self.on = self.world > 1 or os.environ.get("DSN_BENCH_FORCE_DIST") == "1"
+        self.backend = None
+        if self.dry:
+            self.dev = torch.device("cpu")
+        else:
+            assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists for the product path)"
+            assert self.local < torch.cuda.device_count(), (f"rank {self.rank}: local rank {self.local} has no GPU "
+                                                            f"({torch.cuda.device_count()} visible)")
+            self.dev = torch.device("cuda", self.local)
+            torch.cuda.set_device(self.dev)
+        if self.on:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            self.backend = "gloo" if self.dry else "nccl"
+            if self.dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world)
+            assert dist.get_world_size() == self.world and (args.gpus is None or dist.get_world_size() == args.gpus)
+
+    def sync(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.on:
+            self.dist.barrier()
+        self.sync()
+
+    def times(self, dt):
+        """(max over ranks, [every rank's own seconds]) of a timed region - one all-gather of one double per rank"""
+        if not self.on:
+            return dt, [dt]
+        mine = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        every = torch.empty(self.world, dtype=torch.float64, device=self.dev)
+        self.dist.all_gather_into_tensor(every, mine)
+        every = [float(x) for x in every.cpu()]
+        return max(every), every
+
+    def info(self, per_rank_s=None, steps=1):
+        """what the JSON line says about the group: the world the COLLECTIVE LIBRARY reports (not the flag), counted once more with an
+        all-reduce of ones, the backend and its version, and every rank's own time per step"""
+        seen = 1
+        if self.on:
+            one = torch.ones(1, dtype=torch.int32, device=self.dev)
+            self.dist.all_reduce(one)
+            seen = int(one.item())
+        ver = None
+        if self.backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+        return {"world_size": self.dist.get_world_size() if self.on else 1, "ranks_counted_by_all_reduce": seen,
+                "backend": ({"nccl": "nccl (= RCCL on ROCm)", "gloo": "gloo (dry launch, CPU)"}.get(self.backend)),
+                "rccl_version": ver, "launcher": os.environ.get("DSN_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                                                                else ("none (single process)" if self.world == 1 else "external")),
+                "per_rank_ms_per_step": None if per_rank_s is None else [1e3 * t / steps for t in per_rank_s]}
+
+    def finish(self):
+        if self.on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command under torch.distributed.run (what the
+    driver's own N > 1 invocation does) and hand its exit status on.  The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {n_dev} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, DSN_BENCH_LAUNCHER="bench.py --gpus N -> torch.distributed.run", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4" if args.dry_launch else str(max(1, (os.cpu_count() or 8) // max(1, args.gpus)))))
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_launch(args, rk):
+    """--dry-launch: the launcher and the collectives of the selected mode, with a stand-in for the render, on the CPU over gloo.
+    What it proves (tests/test_bench_launch.py): `bench.py --gpus N` starts N ranks; they join ONE process group and the same
+    collectives the measured modes issue (weak: all_gather_into_tensor of one [R,6] frame per rank; --strong: round-robin tile deal,
+    all-gather of equal slabs, un-dealing; --train: one flat all-reduce of the 33 gradients); every rank's pixels / gradients land
+    where they belong; rank 0 prints ONE JSON line with n_gpus = N.  It measures nothing: `value` is null."""
+    import dsnerf_amd
+    dist = rk.dist
+    world, rank = rk.world, rk.rank
+    rp = dsnerf_amd.RayParallel()
+    assert rp.world == world and rp.rank == rank
+    R = 4096 if not args.strong else 10000                  # (strong: not a multiple of the tile, so the slabs are ragged)
+    px_of = lambda rays, r_: torch.stack([rays.float() * (k + 1) + 1000.0 * r_ for k in range(6)], dim=1)      # any per-ray function
+    checks = {}
+    rk.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        if args.train:
+            params = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 500, 33)]
+            for i, p_ in enumerate(params):
+                p_.grad = torch.full_like(p_, float(rank + 1) * (i + 1))
+            rp.average_gradients(params)
+            want = sum(range(1, world + 1)) / world
+            checks["gradients_are_the_mean_over_ranks"] = all(bool(torch.allclose(p_.grad, torch.full_like(p_, want * (i + 1))))
+                                                              for i, p_ in enumerate(params))
+        elif args.strong:
+            tile = 3072
+            out = rp.render_tiled(lambda o, d, n, f: {"color": px_of(o[:, 0], 0)[:, 0:3], "disp_map": px_of(o[:, 0], 0)[:, 3],
+                                                      "acc_map": px_of(o[:, 0], 0)[:, 4], "depth_map": px_of(o[:, 0], 0)[:, 5]},
+                                  torch.arange(R)[:, None].float().expand(R, 3), torch.zeros(R, 3), torch.zeros(R), torch.zeros(R), tile=tile)
+            full = torch.cat([out["color"], out["disp_map"][:, None], out["acc_map"][:, None], out["depth_map"][:, None]], dim=1)
+            checks["frame_reassembled_in_ray_order"] = bool(torch.equal(full, px_of(torch.arange(R), 0)))
+        else:
+            mine = px_of(torch.arange(R), rank)              # this rank's own frame of the batch
+            allp = torch.empty(world * R, 6)
+            if rk.on:
+                dist.all_gather_into_tensor(allp, mine)
+            else:
+                allp.copy_(mine)
+            checks["every_ranks_frame_present"] = all(bool(torch.equal(allp[r_ * R:(r_ + 1) * R], px_of(torch.arange(R), r_)))
+                                                      for r_ in range(world))
+    rk.barrier()
+    dt, per_rank_s = rk.times(time.perf_counter() - t0)
+    info = rk.info(per_rank_s, max(1, args.steps))
+    ok = all(checks.values())
+    if rk.on:                                                # every rank's verdict, not only rank 0's
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    rk.finish()
+    if rank == 0:
+        _flush_c_stdio()
+        print(json.dumps({"metric": "DRY LAUNCH (launcher + collectives only, gloo on CPU, stand-in render): not a measurement",
+                          "value": None, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+                          "vs_baseline": None, "dtype": None, "data": "none", "dry_launch": True,
+                          "mode": "train" if args.train else ("strong" if args.strong else "weak"),
+                          "checks": checks, "ok": ok, "ranks": info}), flush=True)
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        launch_ranks(args)          # (does not return)
+    rk = Ranks(args)
+    world, rank, dev, use_dist = rk.world, rk.rank, rk.dev, rk.on
     import torch.distributed as dist
-    # DSN_BENCH_FORCE_DIST=1 (debug): take the RCCL path (process group, per-frame all-gather, barriers) with ONE rank too, so the
-    # multi-GPU code can be exercised on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("DSN_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists for the product path)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    if args.dry_launch:
+        return dry_launch(args, rk)
 
     import dsnerf_amd
     from dsnerf_amd import _lib, synth
 
     if args.train:
-        return train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist)
+        return train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist, rk)
     if args.eager_baseline:
         print(json.dumps(eager_baseline(args, _lib, synth, dev)))
         return
     if args.strong:
-        return strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist)
+        return strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk)
     if args.emulate_world > 1 and world == 1:
         return weak_emulated(args, dsnerf_amd, _lib, synth, dev)
     H = W = args.hw
@@ -290,10 +454,7 @@ def main():
             pipe.flush()
         torch.cuda.synchronize()
     ms_serial = 1e3 * (time.perf_counter() - t1) / 3
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, per_rank_s = rk.times(dt)          # max over ranks + every rank's own time
 
     n_active = int(ws.buf[:4].view(torch.int32)[0]) if not args.dense else R * S
     n_pos = int(ws.buf[64:68].view(torch.int32)[0]) if (not args.dense and not args.fp32) else n_active
@@ -335,6 +496,7 @@ def main():
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
             "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if use_dist else "none",
         },
+        "ranks": rk.info(per_rank_s, args.steps),
     }
 
     if rank == 0 and world == 1 and not args.no_extras and not (args.dense or args.fp32):
@@ -436,9 +598,7 @@ def main():
             result["eager_gpu_baseline"]["x_faster_per_frame"] = result["eager_gpu_baseline"]["eval_ms_per_512x512_frame"] * \
                 (H * W / (512.0 * 512.0)) / ms_serial
             result["cpu_baseline_torch"] = cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.finish()
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
@@ -491,7 +651,7 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
     return float(np.mean(ms))
 
 
-def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
+def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
     """BASELINE configs[3]: ONE 1024 x 1024 frame at 128 samples per ray, split over the ranks.  The rays are dealt in
     round-robin tiles of 3072 (with the transparent skip the rows through the torso cost several times the rows above the
     head; tiles even that out); every rank renders its tiles with the whole-frame kernels and ONE all_gather_into_tensor of
@@ -563,10 +723,7 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, per_rank_s = rk.times(dt)
     cnt = ws.buf[:256].view(torch.int32).cpu()
     ms = 1e3 * dt / args.steps
     res = {"metric": f"rendered rays/sec ({S} samples/ray), ONE {H}x{W} frame split over the GPUs", "value": R * args.steps / dt,
@@ -583,10 +740,9 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist):
                       "density_screen_calibration": info,
                       "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms * 1e-3) / 1e12,
                       "exchange": (f"all_gather_into_tensor [{slab},6] fp32 per rank (RCCL) + scatter to frame order, in the timed region"
-                                   if use_dist else "none (scatter to frame order only)")}}
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+                                   if use_dist else "none (scatter to frame order only)")},
+           "ranks": rk.info(per_rank_s, args.steps)}
+    rk.finish()
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps(res), flush=True)
@@ -762,7 +918,7 @@ TRAIN_DTYPE = ("split-f16x3 (k_field16<train>, k_tangent16, k_adjoint16, k_t_wgr
                "accumulate) + exact-f32 MFMA for the small lighting / colour-head products (k_t_lin, k_t_wgrad)")
 
 
-def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, warmup, weights=None):
+def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, warmup, weights=None, per_rank=None):
     """trainer.py:66-81 on one synthetic batch per step: zero_grad, render (train mode: jitter + noise, dense), MSE,
     backward (dsn_render_rays_grad), Adam step.  With N>1 every rank renders its own 8192-ray batch of the step and
     the 33 gradients are averaged with ONE 2 MB RCCL all-reduce (parallel.RayParallel.average_gradients) before the
@@ -817,9 +973,13 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        every = [float(x) for x in every.cpu()]
+        dt = max(every)
+        if per_rank is not None:
+            per_rank.extend(every)
     from dsnerf_amd import _lib
     rows = _lib.grad_row_counts(r._grad_ws, R, S)
     return dt, float(loss.detach()), int(r.range_overflow_count()), {"samples": R * S, "forward_rows": rows[0], "backward_rows": rows[1]}
@@ -836,13 +996,13 @@ def train_roofline(ms, R, S):
             "flop_per_sample": flop / (R * S), "samples_per_step": R * S}
 
 
-def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
+def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist, rk):
     import torch.distributed as dist
     S, R = args.samples, args.train_rays
-    dt, final_loss, ovf, rows = train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, args.steps, args.warmup)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    per_rank_s = []
+    dt, final_loss, ovf, rows = train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, args.steps, args.warmup, per_rank=per_rank_s)
+    ranks = rk.info(per_rank_s or [dt], args.steps)
+    rk.finish()
     if rank == 0:
         ms = 1e3 * dt / args.steps
         _flush_c_stdio()
@@ -855,7 +1015,7 @@ def train_bench(args, dsnerf_amd, synth, dev, world, rank, use_dist=False):
                        "range_overflow_samples_last_step": ovf, "rows_last_step": rows,
                        "rows_note": "the forward skips transparent samples with noise <= 0 (alpha = 0 exactly), the backward every row "
                                     "whose cotangents are all zero; the roofline counts the DENSE algorithmic work of the batch"},
-            "roofline": train_roofline(ms, R, S)}), flush=True)
+            "roofline": train_roofline(ms, R, S), "ranks": ranks}), flush=True)
 
 
 def eager_baseline(args, _lib, synth, dev, chunks=5, train=True):

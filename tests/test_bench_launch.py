@@ -1,0 +1,87 @@
+"""`bench.py --gpus N` must measure N GPUs, never one (VERDICT r03 "What's missing" #1): without a launcher around it the script
+re-executes itself under torch.distributed.run; under the driver's own torch.distributed.run it takes WORLD_SIZE from the
+environment and refuses a --gpus that disagrees.  Checked here on the CPU with --dry-launch (gloo, stand-in render): N ranks
+join one process group and the collectives of the selected mode, and rank 0 prints ONE JSON line with n_gpus = N."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def _json_lines(out):
+    lines = []
+    for ln in out.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                lines.append(json.loads(ln))
+            except ValueError:
+                pass
+    return lines
+
+
+@pytest.mark.parametrize("mode", [[], ["--strong"], ["--train"]])
+def test_gpus_flag_launches_that_many_ranks(mode):
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0"] + mode,
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    js = _json_lines(p.stdout)
+    assert len(js) == 1, p.stdout                       # rank 0 only, one line
+    j = js[0]
+    assert p.stdout.strip().splitlines()[-1].strip().startswith("{")          # ... and it is the last line of stdout
+    assert j["n_gpus"] == 2 and j["dry_launch"] is True and j["ok"] is True
+    assert j["ranks"]["world_size"] == 2 and j["ranks"]["ranks_counted_by_all_reduce"] == 2
+    assert len(j["ranks"]["per_rank_ms_per_step"]) == 2
+    assert j["value"] is None                           # a dry launch must not look like a measurement
+    assert all(j["checks"].values())
+    assert j["scaling"] == ("strong" if mode == ["--strong"] else "weak")
+
+
+def test_under_the_drivers_own_launcher():
+    """the driver's N > 1 invocation: python -m torch.distributed.run ... bench.py --gpus N"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-launch"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    js = _json_lines(p.stdout)
+    assert len(js) == 1 and js[0]["n_gpus"] == 2 and js[0]["ranks"]["ranks_counted_by_all_reduce"] == 2
+    assert js[0]["ranks"]["launcher"] == "torch.distributed.run"
+
+
+def test_flag_and_launcher_must_agree():
+    env = _env()
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE = 2" in (p.stderr + p.stdout)
+
+
+def test_one_rank_needs_no_launcher():
+    p = subprocess.run([sys.executable, BENCH, "--dry-launch", "--steps", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    js = _json_lines(p.stdout)
+    assert len(js) == 1 and js[0]["n_gpus"] == 1 and js[0]["ranks"]["launcher"].startswith("none")
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_is_launched():
+    """(this container has no GPU: a real --gpus 2 must fail loudly, not fall back to one rank)"""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
+    assert not _json_lines(p.stdout)
