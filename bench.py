@@ -669,9 +669,9 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
     xyz = synth.pose_body(canon, seed=3)
     rays = synth.make_rays(H, W, xyz, fit_box=True)
     rp = dsnerf_amd.RayParallel()
-    idx_of = [rp.tile_indices(R, 3072, r) for r in range(world)]
-    mine = idx_of[rank].numpy()
-    slab = rp.tile_slab(R, 3072)
+    plan = rp.tile_plan(R, 3072, dev)            # (cached per (R, tile, world, device): indices + un-dealing permutation on the device, built once)
+    mine = plan["mine"].cpu().numpy()
+    slab = plan["slab"]
     packed = _lib.PackedParams(dev).update({k: torch.from_numpy(v) for k, v in sd.items()})
     scene = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
     ws = _lib.RenderWorkspace(dev)
@@ -688,7 +688,6 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
     px = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
     allp = torch.empty(world * slab, 6, dtype=torch.float32, device=dev)
     full = torch.empty(R, 6, dtype=torch.float32, device=dev)
-    dev_idx = [i.to(dev) for i in idx_of]
     out = None
 
     def step():
@@ -704,10 +703,9 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
         px[:Rl, 5] = out["depth_map"]
         if use_dist:
             dist.all_gather_into_tensor(allp, px)
-            for r_ in range(world):                  # = RayParallel.undeal_tiles with the index tensors kept on the device
-                full[dev_idx[r_]] = allp[r_ * slab: r_ * slab + dev_idx[r_].numel()]
+            rp.undeal_tiles(allp, R, 3072, out=full)      # ONE index_select through the cached permutation
         else:
-            full[dev_idx[0]] = px[:Rl]
+            rp.undeal_tiles(px, R, 3072, out=full)
 
     def barrier():
         torch.cuda.synchronize()
@@ -877,16 +875,14 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
         m, mn, Rl, a, k, p_ = time_share(rp.tile_indices(R, tile, r, Nw))
         shares.append({"rank": r, "rays": Rl, "ms": m, "ms_min": mn, "non_transparent": a, "accurate_pass": k, "positive_density": p_})
     # the un-dealing scatter of N equal slabs into frame order (strong_bench's epilogue behind the all-gather)
-    idx_dev = [rp.tile_indices(R, tile, r, Nw).to(dev) for r in range(Nw)]
-    slab = max(i.numel() for i in idx_dev)
+    slab = rp.tile_plan(R, tile, dev, world=Nw)["slab"]
     allp = torch.zeros(Nw * slab, 6, dtype=torch.float32, device=dev)
     full = torch.empty(R, 6, dtype=torch.float32, device=dev)
     und = []
     for i in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for r in range(Nw):
-            full[idx_dev[r]] = allp[r * slab: r * slab + idx_dev[r].numel()]
+        rp.undeal_tiles(allp, R, tile, out=full, world=Nw)      # ONE index_select through the cached permutation
         torch.cuda.synchronize()
         if i >= 2:
             und.append(1e3 * (time.perf_counter() - t0))
@@ -1306,7 +1302,8 @@ def cpu_baseline_torch(synth, canon, faces, xyz, poses, sd, rays, S, args):
         if best is None or dt < best[1]:
             best = (threads, dt)
     threads, dt = best
-    return {"value": n / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+    cores = threads if not quota else max(1, min(threads, int(quota)))      # (threads beyond the cgroup's quota are not cores)
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "threads": threads, "cpu_quota_cores": quota, "kind": "port",
             "sample": f"one {n}-ray chunk of the same frame x {S} samples, torch {torch.__version__} CPU ops with {threads} threads "
                       f"(networks, autograd d sigma/dx, normals, lighting, compositing) + C-oracle geometry, {dt:.1f} s"}
 

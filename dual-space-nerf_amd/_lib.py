@@ -39,6 +39,7 @@ EXPORTS = [
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
+    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -51,6 +52,8 @@ EARLY_STOP, STOP_STATS = 64, 128
 PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
 SHARE_CUS = 2048              # frames in flight: the persistent field kernels take 7/8 of the compute units (dsnerf.h)
 CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
+CNT_COLOUR_MAX = 59           # largest |colour| the compositor of an eval frame weighed (float bits): the scale of the early-stop bound
+EARLY_STOP_COLOUR_HEADROOM = 2.0   # the colour scale handed to the library = this x the largest colour seen so far (Renderer / bench.py)
 EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
 SCREEN_MARGIN_FLOOR, SCREEN_MARGIN_CAP = 0.002, 0.15      # = F16_SCREEN_FLOOR / F16_SCREEN_CAP of csrc/dsn_field16.hip
 SCREEN_HEADROOM = 10.0        # = F16_SCREEN_HEADROOM: every calibration point is this factor in deviation away from a wrong drop
@@ -72,12 +75,13 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dsn_last_error.restype = C.c_char_p
         L.dsn_early_stop_eps.restype = C.c_float
+        L.dsn_early_stop_eps_scaled.restype = C.c_float
         for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 4:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 4 - rebuild it "
+        if L.dsn_abi_version() != 5:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 5 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -107,17 +111,22 @@ def cpu_quota_cores():
         return None
 
 
-def fit_host_pool():
+_pool_warned = False
+
+
+def fit_host_pool(keep=False):
     """Cap torch's intra-op pool at the cgroup's CPU quota (minus two cores for the thread that feeds the GPU and the HIP
     runtime's helper threads).  torch sizes its OpenMP pool from the hardware thread count (128-256 on the GPU boxes) whatever the
     quota (16 cores there): every torch CPU op of the CALLER (test.py:61-76 runs torch.clamp / psnr / .cpu() between frames) then
     wakes a team that burns the whole 100 ms quota period in a few milliseconds of busy-waiting at the pool's dock, the kernel
     freezes the container for the rest of the period, and a 19 ms frame takes 60-90 ms (scripts/h2h_guard_probe.py,
     profiles/r03a_h2h_guard.json: nr_throttled counts them; mean 36 ms in BENCH_r02).  No quota, pool already small, or
-    DSN_HOST_POOL=keep: nothing happens.  Returns (threads before, threads now, quota)."""
+    DSN_HOST_POOL=keep / keep=True (Renderer(host_pool="keep")): nothing happens.  Lowering the caller's setting is said once, as a
+    warning (it is process-global: it also applies to the caller's own CPU work).  Returns (threads before, threads now, quota)."""
+    global _pool_warned
     before = torch.get_num_threads()
     quota = cpu_quota_cores()
-    if quota is None or os.environ.get("DSN_HOST_POOL", "") == "keep":
+    if keep or quota is None or os.environ.get("DSN_HOST_POOL", "") == "keep":
         return before, before, quota
     # one process per GPU: the quota is shared by the processes of this node (torchrun exports LOCAL_WORLD_SIZE)
     try:
@@ -127,6 +136,12 @@ def fit_host_pool():
     want = max(1, int(quota / local_world) - 2)
     if before > want:
         torch.set_num_threads(want)
+        if not _pool_warned:
+            _pool_warned = True
+            import warnings
+            warnings.warn(f"dsnerf_amd: torch.set_num_threads({want}) (was {before}): this process may use {quota:g} cores (cgroup quota"
+                          f"{', shared by ' + str(local_world) + ' local ranks' if local_world > 1 else ''}) and a larger intra-op pool gets it "
+                          "throttled while frames are in flight.  Renderer(host_pool=\"keep\") or DSN_HOST_POOL=keep leave the pool alone.")
     return before, torch.get_num_threads(), quota
 
 
@@ -164,6 +179,7 @@ class PackedParams:
         self.generation = 0        # bumped by every re-pack: what calibrations / caches of derived state key on
         self.screen = None         # dict(deviation, margin, overflow_fraction, points, usable) once calibrate_screen() has run
         self.early_stop = None     # dict(skipped_fraction, usable) once a frame's DSN_STOP_STATS have been read (Renderer / bench.py)
+        self.colour_scale = 1.0    # colour scale of the early-stop threshold in the packed image (set_early_stop_colour_scale)
 
     def update(self, state: dict, force=False):
         """state: name -> tensor (any device).  Re-packs only when a tensor changed (data pointer / version counter).
@@ -181,7 +197,16 @@ class PackedParams:
         self.generation += 1
         self.screen = None         # the packed image carries the conservative default margin again
         self.early_stop = None
+        self.colour_scale = 1.0    # (dsn_pack_params resets it)
         return self
+
+    def set_early_stop_colour_scale(self, scale: float):
+        """colour scale c of DSN_EARLY_STOP's threshold eps(S, c) = min(2^-20, 1e-4 / (2 (S + 1) max(1, c))) for these parameters:
+        frames stay within (S + 1) eps c' of the one-pass frame for colours up to c' - half of the 1e-4 bar, absolute, while c' <= c."""
+        scale = max(1.0, float(scale))
+        _check(lib().dsn_set_early_stop_colour_scale(_ptr(self.buf), C.c_float(scale), _stream()), "dsn_set_early_stop_colour_scale")
+        self.colour_scale = scale
+        return scale
 
     def screen_pays(self, early_stop_on: bool = False) -> bool:
         """Is the (calibrated) density screen worth running?  `usable` of calibrate_screen, except that with ray termination in use
@@ -233,6 +258,13 @@ class PackedParams:
                 d2, _, ovf2, n2, _, t2 = run(max(n_points // 4, 1024))
                 d, t, ovf, total = max(d, d2), max(t, t2), max(ovf, ovf2), total + n2
             _set_pose(scene.buf, self, poses, None, frame_idx, zero_code, ls, r, rc, self.device)      # back to the frame's own state
+        if frame is not None:
+            # ... and the cube around the canonical centroids under the frame's own state (the points of ONE frame - let alone
+            # of its first chunk - are a sample of what a sequence visits; the margin is that of the joint set, never below the cube's)
+            _frame, frame = frame, None
+            d2, _, ovf2, n2, _, t2 = run(max(n_points // 4, 1024))
+            d, t, ovf, total = max(d, d2), max(t, t2), max(ovf, ovf2), total + n2
+            frame = _frame
         # the frame's own state last, with the other states' statistic carried in (out[7]): the margin it leaves in the packed image and
         # the share of points it counts as dropped are those of the joint set
         out[7:8].fill_(t)
@@ -244,7 +276,7 @@ class PackedParams:
         # surface (every calibration point sigma > 0) is better off without it.
         self.screen = {"deviation": d, "margin_statistic": t, "margin": m, "overflow_fraction": ovf, "points": int(total),
                        "dropped_fraction": dropped, "safe": safe, "usable": safe and dropped >= SCREEN_MIN_DROPPED,
-                       "points_from": "frame" if frame is not None else "centroid cube"}
+                       "points_from": "frame + centroid cube" if frame is not None else "centroid cube"}
         return self.screen
 
     def set_screen_margin(self, margin: float):
@@ -625,19 +657,21 @@ class PhasePipeline:
         torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
-def early_stop_eps(S: int) -> float:
-    """the termination / shading threshold of DSN_EARLY_STOP for rays of S samples: min(2^-20, 1e-4 / (2 (S + 1))) - the frame stays
-    within (S + 1) eps x the largest colour of the one-pass frame (include/dsnerf.h)"""
-    return float(lib().dsn_early_stop_eps(int(S)))
+def early_stop_eps(S: int, colour_scale: float = 1.0) -> float:
+    """the termination / shading threshold of DSN_EARLY_STOP for rays of S samples and colours up to colour_scale:
+    min(2^-20, 1e-4 / (2 (S + 1) max(1, colour_scale))) - the frame stays within (S + 1) eps x the largest colour of the one-pass
+    frame (include/dsnerf.h), i.e. within 5e-5 absolute while the colours stay below the scale"""
+    return float(lib().dsn_early_stop_eps_scaled(int(S), C.c_float(colour_scale)))
 
 
 def read_stop_stats(ws):
-    """(synchronises) dict(active, would_skip, skipped, unshaded) of the last dsn_render_rays on this workspace (or of a copy of its
-    first 256 bytes): non-transparent samples; what DSN_STOP_STATS counted (samples early stop would leave out); what
-    DSN_EARLY_STOP left out / did not shade."""
+    """(synchronises) dict(active, would_skip, skipped, unshaded, colour_max) of the last dsn_render_rays on this workspace (or of a
+    copy of its first 256 bytes): non-transparent samples; what DSN_STOP_STATS counted (samples early stop would leave out); what
+    DSN_EARLY_STOP left out / did not shade; the largest |colour| the frame's compositor weighed."""
     buf = ws if isinstance(ws, torch.Tensor) else ws.buf
     c = buf[:256].view(torch.int32).cpu()
-    return {"active": int(c[CNT_ACTIVE]), "would_skip": int(c[CNT_STOP + 2]), "skipped": int(c[CNT_STOP]), "unshaded": int(c[CNT_STOP + 1])}
+    return {"active": int(c[CNT_ACTIVE]), "would_skip": int(c[CNT_STOP + 2]), "skipped": int(c[CNT_STOP]), "unshaded": int(c[CNT_STOP + 1]),
+            "colour_max": float(c[CNT_COLOUR_MAX:CNT_COLOUR_MAX + 1].view(torch.float32)[0])}
 
 
 class GradWorkspace:

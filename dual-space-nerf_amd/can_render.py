@@ -20,8 +20,11 @@ Eval-mode safety nets: the plain-fp16 density screen runs with a
 parameters (first eval frame after the parameters changed: `screen_info`), can be audited on every frame
 (`screen_audit = True`, `last_screen_audit()`), and samples whose activations leave the fp16 range of the split-fp16
 kernels are re-evaluated in exact fp32 inside the library.  `early_stop` ("auto" | True | False): eval frames front to back
-in slices of 8 samples with ray termination at a transmittance of 2^-20 (DSN_EARLY_STOP: within 64 * 2^-20 x colour of the
-one-pass frame) - "auto" decides per parameter version from the statistics of the first eval frame, without a wait.
+in slices of 4-8 samples with ray termination below a transmittance of eps(S, c) = min(2^-20, 1e-4 / (2 (S + 1) max(1, c)))
+(DSN_EARLY_STOP: within (S + 1) eps c = 5e-5 ABSOLUTE of the one-pass frame for colours up to the scale c) - "auto" decides per
+parameter version from the statistics of the first eval frame, which also measures the colours (c = 2 x the largest colour that
+frame weighed; later frames are watched and raise it), without a wait.  The one default-on feature that is error-bounded instead of
+bit-identical: `last_frame_info` says per frame whether it ran and with which threshold.
 """
 from __future__ import annotations
 
@@ -151,9 +154,14 @@ class _ViewSlot:
 
 
 class Renderer:
-    def __init__(self, net, fine_net=None, cfg=None, canonical_vertex=None, body_data=None, device=None):
+    def __init__(self, net, fine_net=None, cfg=None, canonical_vertex=None, body_data=None, device=None, host_pool="fit"):
         """`body_data` (optional, not in the reference): dict with 'f' [F,3] (and optionally 'weights',
-        'kintree_table') used instead of unpickling cfg.DATASETS.SMPL_PATH - the SMPL file is licensed."""
+        'kintree_table') used instead of unpickling cfg.DATASETS.SMPL_PATH - the SMPL file is licensed.
+        `host_pool` (not in the reference): "fit" (default) caps torch's intra-op thread pool - a PROCESS-GLOBAL setting - at the
+        cgroup's CPU quota, once, with a warning when that lowers the caller's setting (why: _lib.fit_host_pool; the GPU boxes show
+        256 hardware threads under a 16-core quota and a pool sized from the former gets the process frozen by the kernel's
+        bandwidth control); "keep" leaves the caller's pool alone (also: environment DSN_HOST_POOL=keep), and then only the
+        per-frame guard (host_pool_limit, restored after every frame) applies."""
         _lib.require_gpu()
         self.net = net
         self.cfg = cfg
@@ -177,16 +185,23 @@ class Renderer:
         self._audit_probe = None          # (count words, event) of an audited frame still to be looked at
         self._audit_frames = 0
         self.screen_info = None           # what the last calibration of the screen found (PackedParams.calibrate_screen)
-        # eval mode: front-to-back slices with ray termination (DSN_EARLY_STOP; pixel error < 64 * 2^-20 x colour).  "auto": the first
-        # eval frame of a parameter version also counts what termination would leave out (DSN_STOP_STATS); from the next frame
-        # on it is used if that is at least _lib.EARLY_STOP_MIN_SKIPPED of the non-transparent samples.  True / False force it.
+        # eval mode: front-to-back slices with ray termination (DSN_EARLY_STOP; pixel error <= (S + 1) eps(S, c) x colour = 5e-5 absolute
+        # for colours up to the scale c).  "auto": the first eval frame of a parameter version also counts what termination would
+        # leave out (DSN_STOP_STATS) and how large its colours are; from the next frame on it is used if it leaves out at least
+        # _lib.EARLY_STOP_MIN_SKIPPED of the non-transparent samples, with c = 2 x the largest colour seen (every
+        # SCREEN_AUDIT_EVERY-th sliced frame is looked at again, without a wait: larger colours raise c, with a warning).
+        # True forces it from the first frame (c = 1 until a frame has been looked at), False switches it off.
         self.early_stop = "auto"
         self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
+        self._colour_probe = None         # (packed generation, count words, event) of a sliced frame whose colour maximum is still to be read
+        self._stop_frames = 0
         # render_view / render_views: torch's intra-op pool is capped at this many threads while a frame is staged, enqueued and
         # awaited (_HostPoolGuard; None = leave the pool alone); and for good at the cgroup's CPU quota (_lib.fit_host_pool: a pool
         # larger than the quota gets the whole process frozen by the kernel's bandwidth control whenever the caller runs a torch op)
         self.host_pool_limit = 8
-        self.host_pool = _lib.fit_host_pool()
+        if host_pool not in ("fit", "keep"):
+            raise ValueError('host_pool must be "fit" or "keep"')
+        self.host_pool = _lib.fit_host_pool(keep=(host_pool == "keep"))
 
     # ---- mode switches (reference :26-38) ----
     def train(self):
@@ -481,6 +496,7 @@ class Renderer:
         packed = self.net.packed(self.device)
         stop, stats = False, False
         if skip and noise is None:
+            self._read_colour_probe()
             if self.early_stop == "auto":
                 if packed.early_stop is None:
                     if self._stop_probe is None:
@@ -516,10 +532,14 @@ class Renderer:
         plan = self._eval_plan(noise, screen) if plan is None else plan
         # what this frame ran with (early stop is the one default-on feature whose output is error-bounded, not
         # bit-identical - a caller can see per frame whether it was in use and with which threshold)
+        cs = packed.colour_scale
         self.last_frame_info = {"density_screen": bool(plan["screen"]), "screen_audit": bool(plan["audit"]),
                                 "early_stop": bool(plan["early_stop"]),
-                                "early_stop_eps": _lib.early_stop_eps(S) if plan["early_stop"] else None,
-                                "early_stop_bound_x_max_colour": (S + 1) * _lib.early_stop_eps(S) if plan["early_stop"] else 0.0}
+                                "early_stop_eps": _lib.early_stop_eps(S, cs) if plan["early_stop"] else None,
+                                "early_stop_colour_scale": cs if plan["early_stop"] else None,
+                                "early_stop_bound_x_max_colour": (S + 1) * _lib.early_stop_eps(S, cs) if plan["early_stop"] else 0.0,
+                                # (absolute, for colours up to the scale)
+                                "early_stop_bound_abs": (S + 1) * _lib.early_stop_eps(S, cs) * cs if plan["early_stop"] else 0.0}
         out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out,
                                share_cus=getattr(self, "_frames_overlap", False), **plan)
         if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
@@ -527,6 +547,14 @@ class Renderer:
             ev = torch.cuda.Event()
             ev.record()
             self._stop_probe = (packed.generation, snap, ev)
+        if plan["early_stop"] and (phases == 0 or phases & _lib.PHASE_SHADE):
+            # the colours of sliced frames are watched: every SCREEN_AUDIT_EVERY-th one leaves its largest weighed colour for a later look
+            if self._colour_probe is None and self._stop_frames % SCREEN_AUDIT_EVERY == 0:
+                snap = ws.buf[:256].clone()
+                ev = torch.cuda.Event()
+                ev.record()
+                self._colour_probe = (packed.generation, snap, ev)
+            self._stop_frames += 1
         if plan["audit"] and self.screen_audit == "auto" and (phases == 0 or phases & _lib.PHASE_SHADE):
             snap = ws.buf[:256].clone()
             ev = torch.cuda.Event()
@@ -570,7 +598,43 @@ class Renderer:
             return
         st = _lib.read_stop_stats(snap)
         frac = st["would_skip"] / max(st["active"], 1)
-        packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED}
+        self._note_colour_max(packed, st["colour_max"], first=True)
+        packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
+                             "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
+
+    def _note_colour_max(self, packed, cmax, first=False):
+        """the early-stop threshold's colour scale follows the largest colour seen: scale = 2 x that (never below 1, never lowered)"""
+        if not (cmax == cmax) or cmax == float("inf"):
+            # a NaN / inf colour reached a pixel: nothing sensible to scale with - termination off for these parameters
+            if packed.early_stop is not None:
+                packed.early_stop["usable"] = False
+            warnings.warn("dsnerf_amd: a frame weighed a non-finite colour: early stop stays off for these parameters")
+            return
+        want = _lib.EARLY_STOP_COLOUR_HEADROOM * cmax
+        if first:
+            if want > packed.colour_scale:
+                packed.set_early_stop_colour_scale(want)
+        elif cmax > packed.colour_scale:
+            warnings.warn("dsnerf_amd: a sliced frame weighed colours up to %.3g, above the scale %.3g of the early-stop threshold: "
+                          "frames since the last look may be off by up to %.2g instead of 5e-5; scale raised to %.3g"
+                          % (cmax, packed.colour_scale, 5e-5 * cmax / packed.colour_scale, want))
+            packed.set_early_stop_colour_scale(want)
+            if packed.early_stop is not None:
+                packed.early_stop["colour_scale"] = packed.colour_scale
+
+    def _read_colour_probe(self, wait=False):
+        if self._colour_probe is None:
+            return
+        gen, snap, ev = self._colour_probe
+        if not wait and not ev.query():
+            return
+        ev.synchronize()
+        self._colour_probe = None
+        packed = self.net.packed(self.device)
+        if packed.generation != gen:
+            return
+        c = snap.view(torch.int32).cpu()
+        self._note_colour_max(packed, float(c[_lib.CNT_COLOUR_MAX:_lib.CNT_COLOUR_MAX + 1].view(torch.float32)[0]))
 
     def last_screen_audit(self, ws=None):
         """what the audit of the last audited eval frame found - synchronises.  dict(audited, violations, max_sigma): `violations`

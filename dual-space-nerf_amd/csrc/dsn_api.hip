@@ -47,6 +47,7 @@ int dsn_pack_params(const float* const* params33_host, void* packed, void* strea
     for (int i = 0; i < DSN_NUM_PARAMS; ++i) DSN_REQUIRE(params33_host[i], "dsn_pack_params: null parameter pointer");
     dsn_launch_pack_params(params33_host, (float*)packed, (hipStream_t)stream);
     dsn_launch_set_screen_margin((float*)packed, DSN_SCREEN_MARGIN_DEFAULT, (hipStream_t)stream);   // until dsn_calibrate_screen has run
+    dsn_launch_set_packed_scalar((float*)packed, 6, 1.0f, (hipStream_t)stream);      // colour scale of the early-stop threshold until measured
     return dsn_check_launch("dsn_pack_params");
 }
 
@@ -55,6 +56,7 @@ int dsn_pack_params_host_image(const float* const* params33_host, float* packed_
     DSN_REQUIRE(params33_host && packed_host, "dsn_pack_params_host_image: null argument");
     dsn_pack_params_host(params33_host, packed_host);
     packed_host[OFF_SCAL + 5] = DSN_SCREEN_MARGIN_DEFAULT;
+    packed_host[OFF_SCAL + 6] = 1.0f;
     return 0;
 }
 
@@ -244,6 +246,13 @@ int dsn_set_screen_margin(void* packed, float margin, void* stream) {
     return dsn_check_launch("dsn_set_screen_margin");
 }
 
+int dsn_set_early_stop_colour_scale(void* packed, float colour_scale, void* stream) {
+    DSN_REQUIRE(packed, "dsn_set_early_stop_colour_scale: null argument");
+    DSN_REQUIRE(colour_scale == colour_scale, "dsn_set_early_stop_colour_scale: NaN scale");
+    dsn_launch_set_packed_scalar((float*)packed, 6, colour_scale, (hipStream_t)stream);
+    return dsn_check_launch("dsn_set_early_stop_colour_scale");
+}
+
 int dsn_shade(const void* scene, int V, int F, const void* packed, const float* x_c, const float* grad, const float* x_w,
               const float* ray_d, const float* essence, int64_t N, int S, const int32_t* active_list,
               const int32_t* active_count, int32_t* face_idx_canon, float* n_w, float* colour, int flags, void* stream) {
@@ -408,7 +417,7 @@ struct DsnWorkspace {
     int32_t* keep;        // [N]   samples the density screen could not rule out
     int32_t* audit;       // [audit_cap] samples declared empty that DSN_SCREEN_AUDIT sends through the accurate pass anyway
     int audit_cap;
-    float* T;             // [R]   DSN_EARLY_STOP: transmittance of every ray after the slices evaluated so far
+    void* T;              // [R] x 8 B  DSN_EARLY_STOP: (transmittance, slices it covers) of every ray (k_slice_alive)
     int32_t* slices;      // [R (S + 64)] the active list split by slice (slice k at k * R * L); later the shading list
     int32_t* alive;       // [N]   the current slice's samples on rays that are not finished
     size_t bytes;
@@ -429,14 +438,9 @@ struct DsnWorkspace {
 #define DSN_CNT_ALIVE 12      //                 [13] reverse-pass slots, [14] shaded samples
 #define DSN_CNT_SEL 13
 #define DSN_CNT_LIT 14
-#define DSN_CNT_STOP 56       // [56] samples left out by ray termination, [57] samples not shaded (weight < eps), [58] DSN_STOP_STATS
-// DSN_EARLY_STOP threshold: the frame moves by at most (S + 1) eps x max|colour| (S unshaded samples of weight < eps each + a
-// terminated tail of total weight < eps), so eps shrinks with S: half of the 1e-4 parity bar for colours <= 1
-static inline float dsn_stop_eps(int S) {
-    const float cap = 9.5367431640625e-07f;      // 2^-20
-    const float e = 1e-4f / (2.0f * (float)(S + 1));
-    return e < cap ? e : cap;
-}
+#define DSN_CNT_STOP 56       // [56] samples left out by ray termination, [57] samples not shaded (weight < eps), [58] DSN_STOP_STATS,
+                              // [59] largest |colour| the compositor weighed (float bits; eval frames) - the scale of the early-stop bound
+// (the DSN_EARLY_STOP threshold: dsn_stop_eps_scaled, dsn_common.h - it follows S and the colour scale kept in `packed`)
 // samples per slice: 4 on big frames (finer termination: the converged set's 512 x 512 x 64 frame 10.32 -> 9.99 ms, w3 12.52 -> 12.22 with
 // two frames in flight; profiles/r03_stop_slice_sweep.txt), 8 where the three launches per slice weigh more than the samples they save
 static inline int dsn_slice_len(int R, int S) {
@@ -479,14 +483,15 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
     w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
     w.audit = (int32_t*)p;        p += dsn_align256(4 * (size_t)w.audit_cap);
-    w.T = (float*)p;              p += dsn_align256(4 * (size_t)R);
+    w.T = (void*)p;               p += dsn_align256(8 * (size_t)R);
     w.slices = (int32_t*)p;       p += dsn_align256(4 * dsn_slice_entries((size_t)R, S));
     w.alive = (int32_t*)p;        p += dsn_align256(4 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
 
-float dsn_early_stop_eps(int S) { return dsn_stop_eps(S > 0 ? S : 1); }
+float dsn_early_stop_eps(int S) { return dsn_stop_eps_scaled(S > 0 ? S : 1, 1.0f); }
+float dsn_early_stop_eps_scaled(int S, float colour_scale) { return dsn_stop_eps_scaled(S > 0 ? S : 1, colour_scale); }
 
 size_t dsn_render_workspace_bytes(int R, int S) {
     if (R <= 0 || S <= 0) return 0;
@@ -587,7 +592,8 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
         int32_t* pcnt = w.count + DSN_CNT_POS;
         dsn_launch_slice_bucket(w.active, w.count + DSN_CNT_ACTIVE, N, S, L, K, cap, w.slices, w.count + DSN_CNT_SLICE, st);
-        dsn_launch_fill_f32(w.T, R, 1.0f, st);
+        dsn_launch_slice_T_init(w.T, R, st);
+        const float* scal = (const float*)packed + OFF_SCAL;
         for (int k = 0; k < K; ++k) {
             const int s0 = k * L, s1 = (k + 1) * L < S ? (k + 1) * L : S;
             const int64_t Nk = (int64_t)R * (s1 - s0);
@@ -595,7 +601,8 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             const int32_t* sc = w.count + DSN_CNT_SLICE + k;
             if (k > 0) {
                 int32_t* acnt = w.count + DSN_CNT_ALIVE_K + k;
-                dsn_launch_slice_alive(sl, sc, Nk, S, w.T, dsn_stop_eps(S), w.alive, acnt, w.count + DSN_CNT_STOP, st);
+                // (advances the rays' transmittance over slice k - 1 on the way: no k_advance_T launch between the slices)
+                dsn_launch_slice_alive(sl, sc, Nk, S, L, k, w.T, w.sigma, w.transparent, z, ray_d, scal, w.alive, acnt, w.count + DSN_CNT_STOP, st);
                 sl = w.alive;
                 sc = acnt;
             }
@@ -609,15 +616,15 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
             // (the sigma > 0 list and its relu records keep growing from slice to slice)
             dsn_launch_field16_fwd((const float*)packed, s.frame, w.x_c, Nk, sl, sc, w.sigma, w.essence, w.masks, w.pos, pcnt, st,
                                    w.rec_cap, fcnt);
-            if (k + 1 < K) dsn_launch_advance_T(w.sigma, w.transparent, z, ray_d, R, S, s0, s1, w.T, st);
+            (void)s0;
         }
         // shading list: weights from the densities alone (the compositor without a colour and without per-ray outputs; flagged
         // densities are still NaN and keep their rays' samples); scratch = the normal buffer
         float* wq = w.n_w;
         dsn_launch_composite(nullptr, w.sigma, w.transparent, z, ray_d, nullptr, R, S, nullptr, nullptr, nullptr, wq, nullptr, st);
-        int32_t* sel = w.active;            // (both lists are dead by now)
+        int32_t* sel = w.alive;             // (dead by now; the list of non-transparent samples stays intact: dsn_calibrate_screen_frame)
         int32_t* lit = w.slices;
-        dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, dsn_stop_eps(S), sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
+        dsn_launch_cull_lit(w.pos, pcnt, N, w.rec_cap, wq, w.sigma, S, scal, sel, w.count + DSN_CNT_SEL, lit, w.count + DSN_CNT_LIT,
                             w.count + DSN_CNT_STOP + 1, w.colour, st);
         dsn_launch_field16_bwd((const float*)packed, s.frame, w.x_c, N, w.pos, pcnt, w.grad, w.masks, st, w.sigma, w.rec_cap, sel,
                                w.count + DSN_CNT_SEL, fcnt);
@@ -672,9 +679,10 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
     else
         dsn_launch_light16((const float*)packed, s.frame, w.n_w, nullptr, ray_o, ray_d, z, w.essence, N, S, list, cnt, w.colour, st);
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
-                         out_weights, out_depth, st, skip);
+                         out_weights, out_depth, st, skip, skip ? w.count + DSN_CNT_STOP + 3 : nullptr);
     if ((flags & DSN_STOP_STATS) && skip)
-        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(R, S), dsn_stop_eps(S), w.count + DSN_CNT_STOP + 2, st);
+        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(R, S), (const float*)packed + OFF_SCAL,
+                              w.count + DSN_CNT_STOP + 2, st);
     }       // shading phase
     return dsn_check_launch("dsn_render_rays");
 }

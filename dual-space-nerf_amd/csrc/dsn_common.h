@@ -213,6 +213,7 @@ enum {
     OFF_WLT2 = OFF_BLT1 + 128,             // lights_encoding.4 weight in C-layout order : 128
     OFF_SCAL = OFF_WLT2 + 128,             // [0]=density bias, [1..3]=rgb3 bias, [4]=lights_encoding.4 bias,
                                            // [5]=margin of the density screen (default / dsn_calibrate_screen, k_screen16)
+                                           // [6]=colour scale of the early-stop threshold (1 / dsn_set_early_stop_colour_scale)
     // raw (unpacked) copies used by the per-frame setup kernel
     OFF_RAW_W0 = OFF_SCAL + 64,            // stage1.0.weight [256,87]
     OFF_RAW_B0 = OFF_RAW_W0 + 256 * 87,    // stage1.0.bias [256]
@@ -238,6 +239,16 @@ enum {
 __host__ __device__ inline size_t dsn_stream16_index(int gb, int hw) {
     if (gb >= DSN_STREAM_BLOCKS) return (size_t)gb * 2048 + hw;
     return (size_t)(gb >> 3) * 16384 + (size_t)(hw >> 9) * 4096 + (size_t)(gb & 7) * 512 + (hw & 511);
+}
+// DSN_EARLY_STOP threshold: the frame moves by at most (S + 1) eps x max|colour| (S unshaded samples of weight < eps each + a
+// terminated tail of total weight < eps), so eps shrinks with S AND with the colour scale c of the loaded parameters
+// (packed[OFF_SCAL + 6], dsn_set_early_stop_colour_scale; 1 until measured): eps = min(2^-20, 1e-4 / (2 (S + 1) max(1, c))) - half of
+// the 1e-4 parity bar, absolute, as long as the colours stay below c (colour = (ELU + 1) x essence is unbounded)
+__host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) {
+    const float cap = 9.5367431640625e-07f;      // 2^-20
+    const float c = colour_scale > 1.0f ? colour_scale : 1.0f;
+    const float e = 1e-4f / (2.0f * (float)(S + 1) * c);
+    return e < cap ? e : cap;
 }
 #define DSN_SCREEN_MARGIN_DEFAULT 0.01f          // conservative margin of the density screen until it has been calibrated
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end

@@ -1842,6 +1842,7 @@ __global__ void __launch_bounds__(256) k_calib_points(const float4* __restrict__
 // geometry phase of dsn_render_rays leaves them), every point taken as it is for the first half of the set and moved by a hash
 // offset of up to +-halo per axis for the second half (the neighbourhood other rays / poses of the sequence will visit); a frame
 // without non-transparent samples falls back to the centroid cube
+#define DSN_CALIB_MIN_FRAME_LIST 65536      // (dsnerf.h: fewer non-transparent samples than this say nothing about the frame)
 __global__ void __launch_bounds__(256) k_calib_points_frame(const float* __restrict__ x_c, const int32_t* __restrict__ list,
                                                              const int32_t* __restrict__ count, const float4* __restrict__ cent, int F,
                                                              int64_t n, float halo, float box, float* __restrict__ x) {
@@ -1854,7 +1855,7 @@ __global__ void __launch_bounds__(256) k_calib_points_frame(const float* __restr
         h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
         o[k] = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
     }
-    if (cnt <= 0) {
+    if (cnt < DSN_CALIB_MIN_FRAME_LIST) {
         const float4 c = cent[(int)(i % F)];
         x[3 * i] = c.x + o[0] * box; x[3 * i + 1] = c.y + o[1] * box; x[3 * i + 2] = c.z + o[2] * box;
         return;
@@ -1935,6 +1936,9 @@ void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n
 __global__ void k_set_scalar(float* p, float v) { *p = v; }
 void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st) {
     hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, packed + OFF_SCAL + 5, margin);
+}
+void dsn_launch_set_packed_scalar(float* packed, int word, float v, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, packed + OFF_SCAL + word, v);
 }
 
 // ---------------------------------------------------------------------------------------------

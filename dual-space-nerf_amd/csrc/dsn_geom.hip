@@ -221,8 +221,12 @@ __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far,
     const int total = rays_here * S;
     const int total_up = cls.gf ? (total + 63) & ~63 : total;      // (classification uses wave-wide ballots: whole waves iterate)
     for (int e = tid; e < total_up; e += GG_THREADS) {
-        if (e >= total) { dsn_nns_classify_one(cls.gf, -1, false, 0.f, 0.f, 0.f, 0, cls.cell_of, cls.counts, cls.outside); continue; }
-        int lr = e / S, i = e - lr * S;
+        // ONE convergent call of the classification per iteration: its run detection uses wave-wide shuffles / ballots, so
+        // the tail lanes of a partial wave (e >= total) go through the same call site with valid = false instead of a call of their own
+        // under a partial exec mask
+        const bool valid = e < total;
+        const int ec = valid ? e : total - 1;
+        int lr = ec / S, i = ec - lr * S;
         float nn = s_near[lr], ff = s_far[lr];
         float ti = t_vals[i];
         float z = nn * (1.0f - ti) + ff * ti;
@@ -233,14 +237,14 @@ __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far,
             if (i < S - 1) { float tn = t_vals[i + 1]; upper = 0.5f * ((nn * (1.0f - tn) + ff * tn) + z); }
             z = lower + (upper - lower) * jitter[g];
         }
-        z_vals[g] = z;
+        if (valid) z_vals[g] = z;
         if (pts || cls.gf) {
             int rr = blockIdx.x * GG_THREADS + lr;
             const float px = ray_o[3 * rr + 0] + ray_d[3 * rr + 0] * z;      // (the expression of k_warp / nns_point: same point, bit for bit)
             const float py = ray_o[3 * rr + 1] + ray_d[3 * rr + 1] * z;
             const float pz = ray_o[3 * rr + 2] + ray_d[3 * rr + 2] * z;
-            if (pts) { pts[3 * g + 0] = px; pts[3 * g + 1] = py; pts[3 * g + 2] = pz; }
-            if (cls.gf) dsn_nns_classify_one(cls.gf, g, true, px, py, pz, 0, cls.cell_of, cls.counts, cls.outside);
+            if (pts && valid) { pts[3 * g + 0] = px; pts[3 * g + 1] = py; pts[3 * g + 2] = pz; }
+            if (cls.gf) dsn_nns_classify_one(cls.gf, valid ? g : (int64_t)-1, valid, px, py, pz, 0, cls.cell_of, cls.counts, cls.outside);
         }
     }
 }
@@ -688,7 +692,8 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
                                                     const float* __restrict__ noise, int R, int S,
                                                     float* __restrict__ rgb_map, float* __restrict__ disp_map,
                                                     float* __restrict__ acc_map, float* __restrict__ weights,
-                                                    float* __restrict__ depth_map, int lazy_colour) {
+                                                    float* __restrict__ depth_map, int lazy_colour,
+                                                    int32_t* __restrict__ colour_max) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;   // wave-uniform
@@ -732,6 +737,13 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
         sb += dsn_wave_sum(w * cb);
         sdep += dsn_wave_sum(w * z);
         sacc += dsn_wave_sum(w);
+        if (colour_max) {      // largest |colour| the frame weighs (float bits of a value >= 0 order like ints): what DSN_EARLY_STOP's bound scales with
+            float m = fmaxf(fabsf(cr), fmaxf(fabsf(cg), fabsf(cb)));
+            m = m == m ? m : INFINITY;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if (lane == 0 && __float_as_int(m) > *colour_max) atomicMax(colour_max, __float_as_int(m));
+        }
     }
     if (lane == 0 && rgb_map) {
         rgb_map[3 * r] = sr; rgb_map[3 * r + 1] = sg; rgb_map[3 * r + 2] = sb;
@@ -746,9 +758,9 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
 
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
-                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour) {
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour, int32_t* colour_max) {
     hipLaunchKernelGGL(k_composite, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
-                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0);
+                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0, colour ? colour_max : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,12 +807,38 @@ __global__ void __launch_bounds__(256) k_slice_bucket(const int32_t* __restrict_
         __syncthreads();
     }
 }
-// the samples of a slice whose ray is still alive (T >= eps); stopped[0] += the others
-__global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__ list, const int32_t* __restrict__ count, int S,
-                                                      const float* __restrict__ T, float eps, int32_t* __restrict__ out,
-                                                      int32_t* __restrict__ out_count, int32_t* __restrict__ stopped) {
+// The samples of slice k (k >= 1) whose ray is still alive (T >= eps); stopped[0] += the others.  The transmittance is advanced HERE
+// (round 4: k_advance_T's 15 launches per frame are gone): Tk[r] = (T of ray r, number of slices it covers).  An entry whose ray's
+// pair covers fewer than k slices multiplies the missing slices' factors in - k_composite's alpha: transparent samples and densities
+// <= 0 give alpha = 0, a flagged density (NaN until the fp32 fallback has run) counts as 0, so T is then an upper bound - in sample
+// order, and publishes (T', k) with ONE 8-byte store.  Entries of the same ray in other waves may read the old or the new pair: both
+// lead to the same T' (same factors, same order), so the lists do not depend on the race.  A ray without samples in a stretch of
+// slices simply catches up at its next entry.  eps comes from the packed scalars (dsn_stop_eps_scaled: S and the colour scale).
+__device__ __forceinline__ float dsn_slice_factor(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+                                                  const float* __restrict__ z_vals, float dn, int64_t g0, int S, int s0, int s1) {
+    float P = 1.0f;
+    float z = z_vals[g0 + s0];
+    for (int i = s0; i < s1; ++i) {
+        const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
+        const float dist = ((i + 1 < S) ? (zn - z) : 1e10f) * dn;
+        float sg = sigma[g0 + i];
+        if (transparent[g0 + i]) sg = 0.f;
+        sg = sg > 0.f ? sg : 0.f;
+        const float alpha = 1.0f - expf(-sg * dist);
+        P *= (1.0f - alpha) + 1e-10f;
+        z = zn;
+    }
+    return P;
+}
+__global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__ list, const int32_t* __restrict__ count, int S, int L, int k,
+                                                      unsigned long long* __restrict__ Tk, const float* __restrict__ sigma,
+                                                      const uint8_t* __restrict__ transparent, const float* __restrict__ z_vals,
+                                                      const float* __restrict__ ray_d, const float* __restrict__ scal,
+                                                      int32_t* __restrict__ out, int32_t* __restrict__ out_count,
+                                                      int32_t* __restrict__ stopped) {
     __shared__ int s_cnt[2], s_base;
     const int n = *count;
+    const float eps = dsn_stop_eps_scaled(S, scal[6]);
     for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -812,7 +850,20 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
             off[j] = -1;
             if (i < n) {
                 idx[j] = list[i];
-                if (!(T[idx[j] / S] < eps)) off[j] = atomicAdd(&s_cnt[0], 1);
+                const int r = idx[j] / S;
+                const unsigned long long pr = __atomic_load_n(Tk + r, __ATOMIC_RELAXED);
+                float T = __uint_as_float((uint32_t)pr);
+                int kd = (int)(pr >> 32);
+                if (kd < k) {
+                    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+                    const float dn = dsn_norm3(d);
+                    for (; kd < k; ++kd) {
+                        const int s0 = kd * L, s1 = (kd + 1) * L < S ? (kd + 1) * L : S;
+                        T = T * dsn_slice_factor(sigma, transparent, z_vals, dn, (int64_t)r * S, S, s0, s1);
+                    }
+                    __atomic_store_n(Tk + r, ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)__float_as_uint(T), __ATOMIC_RELAXED);
+                }
+                if (!(T < eps)) off[j] = atomicAdd(&s_cnt[0], 1);
                 else atomicAdd(&s_cnt[1], 1);
             }
         }
@@ -828,34 +879,9 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
         __syncthreads();
     }
 }
-// T[r] *= prod over the samples s0 <= i < s1 of (1 - alpha_i + 1e-10): k_composite's alpha (transparent samples and densities <= 0
-// give alpha = 0; NaN = flagged density counts as 0)
-// One lane per (ray, sample of the slice): groups of G = 2^g >= s1 - s0 lanes share a ray (consecutive samples: coalesced reads),
-// the factors are multiplied by a butterfly inside the group.
-template <int G>
-__global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
-                                                    const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
-                                                    int s0, int s1, float* __restrict__ T) {
-    const int64_t gl = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t r = gl / G;
-    const int j = (int)(gl % G), i = s0 + j;
-    const bool in = r < R && i < s1;
-    float fac = 1.0f;
-    if (in) {
-        const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
-        const float dn = dsn_norm3(d);
-        const int64_t g = r * S + i;
-        const float z = z_vals[g];
-        const float dist = ((i + 1 < S) ? (z_vals[g + 1] - z) : 1e10f) * dn;
-        float s = sigma[g];
-        if (transparent && transparent[g]) s = 0.f;
-        s = s > 0.f ? s : 0.f;
-        const float alpha = 1.0f - expf(-s * dist);
-        fac = (1.0f - alpha) + 1e-10f;
-    }
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) fac *= __shfl_xor(fac, o);
-    if (r < R && j == 0) T[r] *= fac;
+__global__ void __launch_bounds__(256) k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsigned long long v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, int64_t n, float v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -867,11 +893,12 @@ __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, int64_t
 // below rec_cap, the rest takes the single-launch overflow pass), lit = their sample indices (normals, lighting).  A NaN weight
 // keeps the sample.
 __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_count, int64_t rec_cap,
-                                                   const float* __restrict__ weight, const float* __restrict__ sigma, float eps,
-                                                   int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int32_t* __restrict__ lit,
+                                                   const float* __restrict__ weight, const float* __restrict__ sigma, int S,
+                                                   const float* __restrict__ scal, int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int32_t* __restrict__ lit,
                                                    int32_t* __restrict__ lit_count, int32_t* __restrict__ culled, float* __restrict__ colour) {
     __shared__ int s_cnt[3], s_base[2];
     const int n = *pos_count;
+    const float eps = dsn_stop_eps_scaled(S, scal[6]);
     for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
         if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -915,8 +942,9 @@ __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ po
 // that lie in a slice whose ray had T < eps when the slice began - what DSN_EARLY_STOP would have left out
 __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                      const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
-                                                     int L, float eps, int32_t* __restrict__ out) {
+                                                     int L, const float* __restrict__ scal, int32_t* __restrict__ out) {
     const int r = blockIdx.x * 256 + threadIdx.x;
+    const float eps = dsn_stop_eps_scaled(S, scal[6]);
     int skipped = 0;
     if (r < R) {
         float t = 1.0f;
@@ -946,46 +974,31 @@ void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count,
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
     hipLaunchKernelGGL(k_slice_bucket, dim3((unsigned)blocks), dim3(256), 0, st, active, active_count, S, L, K, cap, lists, counts);
 }
-void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, const float* T, float eps, int32_t* out,
+void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, int L, int k, void* Tk, const float* sigma,
+                            const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
                             int32_t* out_count, int32_t* stopped, hipStream_t st) {
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
-    hipLaunchKernelGGL(k_slice_alive, dim3((unsigned)blocks), dim3(256), 0, st, list, count, S, T, eps, out, out_count, stopped);
+    hipLaunchKernelGGL(k_slice_alive, dim3((unsigned)blocks), dim3(256), 0, st, list, count, S, L, k, (unsigned long long*)Tk, sigma,
+                       transparent, z_vals, ray_d, packed_scal, out, out_count, stopped);
 }
-void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
-                          int s1, float* T, hipStream_t st) {
-    const int n = s1 - s0;
-#define DSN_ADV(G)                                                                                                              \
-    hipLaunchKernelGGL(k_advance_T<G>, dim3((unsigned)(((int64_t)R * G + 255) / 256)), dim3(256), 0, st, sigma, transparent, z_vals, \
-                       ray_d, R, S, s0, s1, T)
-    if (n <= 1) DSN_ADV(1);
-    else if (n <= 2) DSN_ADV(2);
-    else if (n <= 4) DSN_ADV(4);
-    else if (n <= 8) DSN_ADV(8);
-    else if (n <= 16) DSN_ADV(16);
-    else if (n <= 32) DSN_ADV(32);
-    else if (n <= 64) DSN_ADV(64);
-    else {      // longer slices (S > 2048): 64 samples at a time
-        for (int q = s0; q < s1; q += 64) {
-            const int e = q + 64 < s1 ? q + 64 : s1;
-            hipLaunchKernelGGL(k_advance_T<64>, dim3((unsigned)(((int64_t)R * 64 + 255) / 256)), dim3(256), 0, st, sigma, transparent, z_vals,
-                               ray_d, R, S, q, e, T);
-        }
-    }
-#undef DSN_ADV
+// Tk[r] = (T = 1, covers 0 slices)
+void dsn_launch_slice_T_init(void* Tk, int R, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, (unsigned long long*)Tk, (int64_t)R,
+                       (unsigned long long)0x3f800000ull);
 }
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
 }
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
-                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled,
-                         float* colour, hipStream_t st) {
+                         const float* sigma, int S, const float* packed_scal, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count,
+                         int32_t* culled, float* colour, hipStream_t st) {
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
-    hipLaunchKernelGGL(k_cull_lit, dim3((unsigned)blocks), dim3(256), 0, st, pos, pos_count, rec_cap, weight, sigma, eps, sel, sel_count, lit,
+    hipLaunchKernelGGL(k_cull_lit, dim3((unsigned)blocks), dim3(256), 0, st, pos, pos_count, rec_cap, weight, sigma, S, packed_scal, sel, sel_count, lit,
                        lit_count, culled, colour);
 }
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           float eps, int32_t* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, eps, out);
+                           const float* packed_scal, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -60,7 +60,8 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
                          bool fine_only = false, bool dense_fine = false);
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
-                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false);
+                          float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false,
+                          int32_t* colour_max = nullptr);
 void dsn_launch_field16_fwd(const float* packed, const DsnFrameState* fs, const float* x_c, int64_t N,
                             const int32_t* active_list, const int32_t* active_count, float* sigma, float* essence,
                             void* masks, int32_t* pos_list, int32_t* pos_count, hipStream_t st, int64_t rec_cap,
@@ -83,6 +84,7 @@ void dsn_launch_calibrate_screen(const DsnSceneView& s, float* packed, int64_t n
                                  const float* frame_x_c = nullptr, const int32_t* frame_list = nullptr,
                                  const int32_t* frame_count = nullptr);
 void dsn_launch_set_screen_margin(float* packed, float margin, hipStream_t st);
+void dsn_launch_set_packed_scalar(float* packed, int word, float v, hipStream_t st);      // packed[OFF_SCAL + word] = v
 void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const float* n_w, const float* x_w,
                         const float* ray_o, const float* ray_d, const float* z_vals, const float* essence, int64_t N,
                         int S, const int32_t* active_list, const int32_t* active_count, float* colour, hipStream_t st,
@@ -146,13 +148,15 @@ void dsn_launch_image_psnr(const float* img_rgb, const double* gt64, const float
 // front-to-back slices with exact ray termination (dsn_geom.hip; DSN_EARLY_STOP in dsn_render_rays)
 void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int L, int K, int64_t cap,
                              int32_t* lists, int32_t* counts, hipStream_t st);
-void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, const float* T, float eps, int32_t* out,
+// slice k >= 1: advances the rays' transmittance over the slices their pair does not cover yet and keeps the samples of live rays
+// (Tk: [R] x 8 bytes, dsn_launch_slice_T_init; packed_scal = packed + OFF_SCAL: the threshold's colour scale lives there)
+void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, int L, int k, void* Tk, const float* sigma,
+                            const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
                             int32_t* out_count, int32_t* stopped, hipStream_t st);
-void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
-                          int s1, float* T, hipStream_t st);
+void dsn_launch_slice_T_init(void* Tk, int R, hipStream_t st);
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
-                         const float* sigma, float eps, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count, int32_t* culled,
-                         float* colour, hipStream_t st);
+                         const float* sigma, int S, const float* packed_scal, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count,
+                         int32_t* culled, float* colour, hipStream_t st);
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           float eps, int32_t* out, hipStream_t st);
+                           const float* packed_scal, int32_t* out, hipStream_t st);

@@ -17,6 +17,39 @@ class RayParallel:
         self.enabled = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        # per (R, tile, world, device): the permutation that un-deals gathered slabs into ray order, this rank's tile indices on the
+        # device, the slab size - built once, on the host, uploaded once (they were re-created and re-uploaded per
+        # rank on every call: 8 synchronous host-to-device copies per frame at 8 ranks)
+        self._plans = {}
+        self.plan_builds = 0           # how many plans were built (tests: a second call must not build - or upload - anything)
+
+    def _group_device(self):
+        """the device collectives of this group run on: the CPU for gloo, the current CUDA device for nccl (= RCCL)"""
+        if self.enabled and dist.get_backend(self.group) == "gloo":
+            return torch.device("cpu")
+        if torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def tile_plan(self, R: int, tile: int = 3072, device=None, world: int = None):
+        """Cached partition of R rays into round-robin tiles for a group of `world` ranks (default: this group): dict(slab = rows of
+        the equal slabs the ranks exchange, mine = this rank's ray indices on `device`, src = for every ray of the frame its row in the
+        gathered [world * slab, C] tensor, so that un-dealing is ONE index_select)."""
+        world = self.world if world is None else int(world)
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        key = (int(R), int(tile), world, str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            self.plan_builds += 1
+            idx = [self.tile_indices(R, tile, r, world) for r in range(world)]
+            slab = max(i.numel() for i in idx)
+            src = torch.empty(R, dtype=torch.int64)
+            for r, ir in enumerate(idx):
+                src[ir] = r * slab + torch.arange(ir.numel())
+            plan = {"slab": slab, "mine": idx[self.rank if self.rank < world else 0].to(device), "src": src.to(device),
+                    "counts": [i.numel() for i in idx]}
+            self._plans[key] = plan
+        return plan
 
     def block(self, R: int) -> int:
         return (R + self.world - 1) // self.world
@@ -49,29 +82,34 @@ class RayParallel:
         rank = self.rank if rank is None else rank
         world = self.world if world is None else int(world)
         ntiles = (R + tile - 1) // tile
-        mine = torch.arange(rank, ntiles, world)
+        mine = torch.arange(rank, max(ntiles, rank), world)      # (a rank beyond the last tile owns nothing)
         idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
         return idx[idx < R]
 
     def tile_slab(self, R: int, tile: int = 3072) -> int:
         """rows of the equal slabs the ranks exchange (= the largest share; rank 0 owns the most)"""
-        return max(self.tile_indices(R, tile, r).numel() for r in range(self.world))
+        ntiles = (R + tile - 1) // tile
+        n0 = (ntiles + self.world - 1) // self.world          # tiles of rank 0
+        last = R - (ntiles - 1) * tile                         # rays of the frame's last tile
+        return n0 * tile - ((tile - last) if (ntiles - 1) % self.world == 0 else 0)
 
-    def undeal_tiles(self, gathered: torch.Tensor, R: int, tile: int = 3072, out: torch.Tensor = None) -> torch.Tensor:
-        """gathered [world * slab, C] (rank-major slabs as all_gather_into_tensor leaves them) -> [R, C] in ray order"""
-        slab = gathered.shape[0] // self.world
-        full = out if out is not None else torch.empty(R, gathered.shape[1], dtype=gathered.dtype, device=gathered.device)
-        for r in range(self.world):
-            ir = self.tile_indices(R, tile, r).to(gathered.device)
-            full[ir] = gathered[r * slab: r * slab + ir.numel()]
-        return full
+    def undeal_tiles(self, gathered: torch.Tensor, R: int, tile: int = 3072, out: torch.Tensor = None, world: int = None) -> torch.Tensor:
+        """gathered [world * slab, C] (rank-major slabs as all_gather_into_tensor leaves them) -> [R, C] in ray order: ONE gather
+        kernel through the cached permutation (no per-rank loop, no upload after the first call)"""
+        plan = self.tile_plan(R, tile, gathered.device, world)
+        assert gathered.shape[0] == (self.world if world is None else world) * plan["slab"]
+        if out is None:
+            return gathered.index_select(0, plan["src"])
+        torch.index_select(gathered, 0, plan["src"], out=out)
+        return out
 
     def render_tiled(self, render_fn, ray_o, ray_d, near, far, tile: int = 3072):
         """like render(), with the round-robin tile partition.  NOTE: the geometry-guided sampler takes the FIRST ray's
         origin for the whole batch (utils/pts_utils.py:31), so this is meant for rays of one camera."""
         R = ray_o.shape[0]
         dev = ray_o.device
-        idx = self.tile_indices(R, tile).to(dev)
+        plan = self.tile_plan(R, tile, dev)
+        idx = plan["mine"]
         if idx.numel():
             loc = render_fn(ray_o[idx].contiguous(), ray_d[idx].contiguous(), near[idx].contiguous(), far[idx].contiguous())
             packed = torch.cat([loc["color"], loc["disp_map"][:, None], loc["acc_map"][:, None], loc["depth_map"][:, None]], dim=1)
@@ -80,7 +118,7 @@ class RayParallel:
         if self.world == 1:
             full = packed
         else:
-            slab = self.tile_slab(R, tile)
+            slab = plan["slab"]
             pad = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
             pad[: packed.shape[0]] = packed
             allp = torch.empty(self.world * slab, 6, dtype=torch.float32, device=dev)
@@ -94,14 +132,15 @@ class RayParallel:
         rank = self.rank if rank is None else rank
         return list(range(rank, n_frames, self.world))
 
-    def render_frames(self, render_frame_fn, n_frames: int, pixels: int, channels: int = 6, device=None):
+    def render_frames(self, render_frame_fn, n_frames: int, pixels: int, channels: int = 6, device=None, dtype=torch.float32):
         """Every rank renders its frames of a sequence (render_frame_fn(f) -> [pixels, channels] device tensor, e.g. the packed
         rgb / disp / acc / depth image of Renderer.render_view(device_output=True)); after each round of `world` frames ONE
         all_gather_into_tensor brings that round's images to every rank - issued asynchronously, so the exchange of round k
         overlaps the rendering of round k + 1.  Returns the list of n_frames images in sequence order on every rank.
-        Fewer frames than ranks is fine: a rank without a frame in a round joins that round's collective with zeros (its
-        buffer lives on `device`, default: the current CUDA device, or the CPU when there is none) - every rank takes the same
-        path through the collectives whatever n_frames is, so no rank can raise while the others wait."""
+        Fewer frames than ranks is fine: a rank without a frame in a round joins that round's collective with zeros of `dtype` on
+        `device` (default: the device the GROUP's backend runs on - the CPU for gloo, the current CUDA device for nccl - so a
+        frameless rank of a gloo group on a CUDA host does not bring a CUDA tensor to a CPU collective) - every rank
+        takes the same path through the collectives whatever n_frames is, so no rank can raise while the others wait."""
         if n_frames <= 0:
             return []
         rounds = (n_frames + self.world - 1) // self.world
@@ -111,10 +150,9 @@ class RayParallel:
             f = r * self.world + self.rank
             img = render_frame_fn(f) if f < n_frames else None
             if dev is None:
-                dev = img.device if img is not None else (
-                    torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+                dev = img.device if img is not None else self._group_device()
             if img is None:
-                img = torch.zeros(pixels, channels, dtype=torch.float32, device=dev)
+                img = torch.zeros(pixels, channels, dtype=dtype, device=dev)
             img = img.reshape(pixels, channels).contiguous()
             if self.world == 1:
                 outs.append(img[None])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 4
+#define DSN_ABI_VERSION 5
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -209,8 +209,11 @@ DSN_EXPORT size_t dsn_calibrate_workspace_bytes(int64_t n_points);
  * half of the set, moved by up to +-2 cm per axis for the second half.  The cube around the canonical centroids that
  * dsn_calibrate_screen draws from (+-0.15 m) reaches far outside the |h| <= 0.1 m shell a non-transparent sample can lie in
  * (utils/render_utils.py:103-109) and - for a trained field - outside everything the training ever saw; what is never rendered
- * should not set the margin, what is rendered must.  Same `out`, same workspace size; a frame without non-transparent samples falls
- * back to the cube.  Declared behind dsn_render_rays' flags. */
+ * should not set the margin, what is rendered must.  Same `out`, same workspace size.  A frame with fewer than 65 536 non-transparent
+ * samples (a small ray batch, the first chunk of a chunked frame: a million points drawn from a handful of samples say nothing -
+ * ADVICE r03) falls back to the cube; callers fold the cube's statistic in through out[7] in any case (the host mirror does).  The
+ * frame's list of non-transparent samples (workspace words / `active`) survives a whole frame, DSN_EARLY_STOP included.  Declared
+ * behind dsn_render_rays' flags. */
 DSN_EXPORT int dsn_calibrate_screen(const void* scene, int V, int F, void* packed, int64_t n_points, void* workspace, float* out4,
                          void* stream);
 DSN_EXPORT int dsn_set_screen_margin(void* packed, float margin, void* stream);
@@ -288,13 +291,20 @@ DSN_EXPORT int dsn_module_grad(const void* scene, int V, int F, const void* pack
  * (S / 32 beyond 256 samples); after each slice T of every ray is advanced with the densities just computed, the next slice
  * leaves out the finished rays (their remaining samples keep density 0), and d sigma/dx, normals and lighting are computed only
  * for samples whose own weight is >= eps.  Worst case against the dense evaluation: the S samples not shaded add up to S eps and
- * the terminated tail to eps, i.e. (S + 1) eps x the largest colour component, so eps follows S (dsn_early_stop_eps):
- * eps(S) = min(2^-20, 1e-4 / (2 (S + 1))) keeps the worst case at half of the 1e-4 bar for colours <= 1 at any S (1e-6 typical);
- * when no ray saturates, weights / acc / depth keep their bits and only the colour moves (< eps per unshaded sample).
+ * the terminated tail to eps, i.e. (S + 1) eps x the largest colour component c, so eps follows S AND c:
+ * eps(S, c) = min(2^-20, 1e-4 / (2 (S + 1) max(1, c))) keeps the worst case at half of the 1e-4 bar - ABSOLUTE - at any S for colours
+ * up to c (1e-6 typical).  colour = (ELU + 1) x essence is unbounded (model/spacenet.py:174-188): c is a property of the loaded
+ * parameters, kept in `packed` (1 after dsn_pack_params; dsn_set_early_stop_colour_scale sets it - the host mirror measures it: every
+ * eval frame leaves the largest |colour| its compositor weighed in word 59 of `workspace`, float bits).  When no ray saturates,
+ * weights / acc / depth keep their bits and only the colour moves (< eps x colour per unshaded sample).
  * int32 words 56 / 57 of `workspace`: samples left out by termination / samples not shaded. */
 #define DSN_EARLY_STOP 64
-/* the termination / shading threshold DSN_EARLY_STOP and DSN_STOP_STATS use for rays of S samples (host function, no device work) */
+/* the termination / shading threshold DSN_EARLY_STOP and DSN_STOP_STATS use for rays of S samples (host functions, no device work):
+ * dsn_early_stop_eps(S) = dsn_early_stop_eps_scaled(S, 1) */
 DSN_EXPORT float dsn_early_stop_eps(int S);
+DSN_EXPORT float dsn_early_stop_eps_scaled(int S, float colour_scale);
+/* colour scale c of the early-stop threshold for THESE parameters (stream-ordered write into `packed`; values < 1 count as 1) */
+DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale, void* stream);
 /* statistics for the caller's decision whether DSN_EARLY_STOP pays (a frame rendered WITHOUT it): word 58 of `workspace` =
  * non-transparent samples that lie in a slice whose ray had T < eps when the slice began (what DSN_EARLY_STOP would leave out;
  * compare with word 0, the non-transparent samples).  Slicing costs a few launches per slice, ~0.5 ms on a 512 x 512 x 64 frame. */

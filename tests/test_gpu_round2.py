@@ -784,6 +784,7 @@ def _stop_pair(sd, hw=160, S=64, screen=True, **kw):
         torch.cuda.synchronize()
         return out, _lib.read_stop_stats(ws), ws
 
+    run.renderer = r
     return run
 
 
@@ -901,7 +902,7 @@ def test_renderer_decides_early_stop_from_the_first_frame():
         # with termination in use the screen's dropped share counts among the samples still evaluated: w3's 34 % of all points is
         # 68 % of what is left once the dense interior is gone, so the screen comes on although its calibration alone said no
         pk = r.net.packed(r.device)
-        assert r._screen_usable() and pk.screen["points_from"] == "frame"      # (calibrated by the first frame, on its own points)
+        assert r._screen_usable() and pk.screen["points_from"].startswith("frame")      # (calibrated by the first frame, on its own points + the cube)
         b = r.render_view(batch, device_output=True)
         torch.cuda.synchronize()
         st = _lib.read_stop_stats(r._ws)

@@ -147,6 +147,22 @@ def _frames_worker(rank, world, port, n_frames, q):
     dist.all_gather_into_tensor(allp, pad)
     full = rp.undeal_tiles(allp, R, tile)
     ok = ok and torch.equal(full[:, 0], torch.arange(R, dtype=torch.float32)) and torch.equal(full[:, 1], 10.0 * torch.arange(R, dtype=torch.float32))
+    # the index tensors of a partition are built (and uploaded) ONCE per (R, tile, world, device) - a second
+    # frame of the same shape enumerates nothing: neither tile_indices nor the plan builder run again
+    builds = rp.plan_builds
+    calls = {"n": 0}
+    orig = rp.tile_indices
+    rp.tile_indices = lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), orig(*a, **k))[1]
+    o = torch.arange(R, dtype=torch.float32)[:, None].expand(R, 3)
+    fake = lambda o_, d_, n_, f_: {"color": o_ * 2.0, "disp_map": o_[:, 0] + 1, "acc_map": o_[:, 0] + 2, "depth_map": o_[:, 0] + 3}
+    first = rp.render_tiled(fake, o, o, o[:, 0], o[:, 0], tile=tile)
+    b1, c1 = rp.plan_builds, calls["n"]
+    second = rp.render_tiled(fake, o, o, o[:, 0], o[:, 0], tile=tile)
+    full2 = rp.undeal_tiles(allp, R, tile)
+    ok = ok and rp.plan_builds == b1 == builds and calls["n"] == c1 == 0      # (the plan of this R / tile exists since undeal_tiles above)
+    ok = ok and torch.equal(first["color"], o * 2.0) and torch.equal(second["depth_map"], o[:, 0] + 3) and torch.equal(full2, full)
+    # a rank without a frame joins the collective with a buffer on the GROUP's device (gloo: the CPU, whatever CUDA says)
+    ok = ok and rp._group_device() == torch.device("cpu")
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
