@@ -204,7 +204,7 @@ def test_screen_calibration_bounds_the_frame(wname):
                      r._dev(cal["far"][0]).clone(), S, r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
     info = packed.calibrate_screen(r.scene, frame=(cws, 256 * 256, S))
     r._set_frame(batch)
-    assert info["points_from"] == "frame"
+    assert info["points_from"].startswith("frame")
     if wname == "_w4":
         # The CONVERGED set defeats the plain-fp16 trunk where it matters: around sigma = 0 the fp16 evaluation is off by 4-5 % of the
         # magnitude of the summed terms (the hash-initialised sets: 0.02-0.06 %), so a factor 10 of headroom would need a margin of

@@ -111,7 +111,7 @@ def test_converged_checkpoint_on_the_bench_frame():
     _lib.render_rays(r.scene, r.net.packed(r.device), cws, o, d, r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone(), S,
                      r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
     info = r.net.packed(r.device).calibrate_screen(r.scene, frame=(cws, o.shape[0], S))      # on the frame's own points, as Renderer does
-    assert not info["safe"] and info["points_from"] == "frame", info      # (2-5 % deviation around sigma = 0: a margin of 0.2-0.5, beyond the cap of 0.15 - screen off)
+    assert not info["safe"] and info["points_from"].startswith("frame"), info      # (2-5 % deviation around sigma = 0: a margin of 0.2-0.5, beyond the cap of 0.15 - screen off)
 
     def run(**kw):
         n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()

@@ -100,6 +100,7 @@ def test_frame_calibration_needs_a_list_and_folds_the_cube_in():
     o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
     n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
     cube = dict(pk.calibrate_screen(r.scene))
+    cube_own = dict(pk.calibrate_screen(r.scene, n_points=(1 << 20) // 4, other_frames=()))      # what a frame calibration folds in
     # (1) a 256-ray batch: ~6 k listed samples - the "frame" calibration must equal the cube's (same points, same statistic)
     ws_small = _lib.RenderWorkspace(r.device)
     _lib.render_rays(r.scene, pk, ws_small, o[:256].contiguous(), d[:256].contiguous(), n[:256].clone(), f[:256].clone(), S, r._t_vals(S),
@@ -112,7 +113,7 @@ def test_frame_calibration_needs_a_list_and_folds_the_cube_in():
     ws = _lib.RenderWorkspace(r.device)
     _lib.render_rays(r.scene, pk, ws, o, d, n.clone(), f.clone(), S, r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
     frame = dict(pk.calibrate_screen(r.scene, frame=(ws, o.shape[0], S)))
-    assert frame["margin_statistic"] >= cube["margin_statistic"] * (1 - 1e-6) and frame["points_from"] == "frame + centroid cube"
+    assert frame["margin_statistic"] >= cube_own["margin_statistic"] * (1 - 1e-6) and frame["points_from"] == "frame + centroid cube"
     # (3) after a whole sliced frame the active list is still the geometry phase's
     before = ws.buf.clone()
     cnt = int(before[:4].view(torch.int32)[0])
