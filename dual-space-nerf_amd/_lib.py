@@ -39,7 +39,7 @@ EXPORTS = [
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
-    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale",
+    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -299,6 +299,45 @@ class Scene:
         _check(lib().dsn_set_body(_ptr(self.buf), _ptr(canon), _ptr(f), self.V, self.F, _stream()), "dsn_set_body")
         self._keep = (canon, f)
         self.frame_key = None
+        # Nearest-face list levels that do not fit their (fixed) capacity are switched off by the build and every query falls through to
+        # the next level / the exhaustive sweep - same index, 10-50x slower (silently).  The canonical mesh's levels are
+        # built once: looked at here (one synchronisation at set-up); the posed mesh's are rebuilt per frame: their headers are copied
+        # out asynchronously every NN_WATCH_EVERY-th frame and looked at when the next frame is set (nn_watch()).
+        off = (C.c_size_t * 4)()
+        _check(lib().dsn_nn_header_offsets(self.V, self.F, off), "dsn_nn_header_offsets")
+        self._nn_off = [int(o) for o in off]
+        self._nn_probe = None
+        self._nn_frames = 0
+        self.nn_overflow = {}          # level name -> (entries needed, capacity) of every overflow seen
+        st = nn_stats(self)
+        for name in ("canon_fine", "canon_coarse"):
+            self._judge_level(name, st[name])
+
+    NN_WATCH_EVERY = 16
+    _NN_NAMES = ("world_fine", "world_coarse", "canon_fine", "canon_coarse")
+
+    def _judge_level(self, name, rec):
+        ncell, ok, total, cap = rec
+        if total > cap and name not in self.nn_overflow:
+            import warnings
+            warnings.warn(f"dsnerf_amd: the {name.replace('_', ' ')} nearest-face level of this mesh needs {total} list entries, its capacity is "
+                          f"{cap}: the level is switched off and its queries take the next level / the exhaustive sweep over all {self.F} "
+                          "centroids - same results, but the nearest-face search of every frame is several times slower "
+                          "(Scene.nn_overflow; a mesh far denser than SMPL's 13 776 faces per body needs larger DSN capacities)")
+        if total > cap:
+            self.nn_overflow[name] = (int(total), int(cap))
+
+    def nn_watch(self, wait=False):
+        """look at the posed mesh's level headers an earlier frame left (no wait unless asked); returns the overflow record"""
+        if self._nn_probe is not None:
+            snap, ev = self._nn_probe
+            if wait or ev.query():
+                ev.synchronize()
+                self._nn_probe = None
+                w = snap.view(torch.int32)
+                for i, name in enumerate(self._NN_NAMES[:2]):
+                    self._judge_level(name, tuple(int(w[16 * i + k]) for k in (8, 9, 10, 11)))
+        return self.nn_overflow
 
     def set_frame(self, packed: PackedParams, xyz, poses, frame_idx: int, zero_code: bool = False,
                   light_shift=None, rot=None, rot_center=None, reuse: bool = False, fine_only: bool = False):
@@ -324,6 +363,15 @@ class Scene:
                                       FRAME_FINE_ONLY if fine_only else 0, _stream()), "dsn_set_frame")
         self._keep_frame = (xyz, poses, ls, r, rc)
         self._pose_args = (poses, int(frame_idx), bool(zero_code), ls, r, rc)
+        self.nn_watch()
+        if self._nn_probe is None and self._nn_frames % self.NN_WATCH_EVERY == 0:
+            host = torch.empty(128, dtype=torch.uint8).pin_memory()
+            for i in range(2):      # world fine / coarse headers, 64 bytes each
+                host[64 * i:64 * i + 64].copy_(self.buf[self._nn_off[i]:self._nn_off[i] + 64], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._nn_probe = (host, ev)
+        self._nn_frames += 1
         return self
 
 

@@ -384,6 +384,16 @@ int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, voi
     return 0;
 }
 
+// where the four 64-byte level headers live inside a scene blob (host function): lets a caller copy them out asynchronously and
+// watch for a level that did not fit its list capacity without the synchronisation dsn_debug_nn_stats implies
+int dsn_nn_header_offsets(int V, int F, size_t* out4_host) {
+    DSN_REQUIRE(out4_host && V > 0 && F > 0, "dsn_nn_header_offsets: bad argument");
+    DsnSceneView s = dsn_scene_view(nullptr, V, F);
+    const DsnGrid* gs[4] = {s.nn_world.fine.g, s.nn_world.coarse.g, s.nn_canon.fine.g, s.nn_canon.coarse.g};
+    for (int i = 0; i < 4; ++i) out4_host[i] = (size_t)((const char*)gs[i] - (const char*)nullptr);
+    return 0;
+}
+
 // utils/rays_utils.py:16-30 get_rays + :63-97 get_near_far, whole-image path (:176-184)
 int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, const double* bounds2x3, int H, int W,
                     int convention, float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box, void* stream) {

@@ -272,7 +272,11 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
     // holds - shorter lists per query; the posed mesh's lists are rebuilt per frame and stay at 3 F cells
     const int t_fine = dense_fine ? dsn_clampi(5 * F, 512, 62000) : dsn_clampi(3 * F, 512, 44000);
     const int t_coarse = dsn_clampi(F / 3, 64, 5000);
-    dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, dsn_nn_fine_cap(F), true, st);
+    // DSN_NN_FINE_CAP (tests): a smaller LOGICAL capacity of the fine level - provokes the overflow path (level unusable, queries fall
+    // through to the coarse level / the sweep, the host mirror warns) on a mesh that fits the real one
+    const char* ce = getenv("DSN_NN_FINE_CAP");
+    const int fine_cap = ce && atoll(ce) > 0 && atoll(ce) < dsn_nn_fine_cap(F) ? (int)atoll(ce) : dsn_nn_fine_cap(F);
+    dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, fine_cap, true, st);
     if (fine_only) hipLaunchKernelGGL(k_grid_disable, dim3(1), dim3(1), 0, st, nn.coarse.g);
     else dsn_build_level(cent, F, nn.coarse, pad_coarse, t_coarse, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), false, st);
 }

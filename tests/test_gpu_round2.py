@@ -27,9 +27,9 @@ def T(a, dev=DEV):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def full_frame(hw=512, seed=3, pose_seed=5):
+def full_frame(hw=512, seed=3, pose_seed=5, nonuniform=False):
     from dsnerf_amd import synth
-    canon, faces = synth.make_body()
+    canon, faces = synth.make_body(nonuniform=nonuniform)
     xyz = synth.pose_body(canon, seed=seed)
     rays = synth.make_rays(hw, hw, xyz, fit_box=True)
     batch = {"ray_o": torch.from_numpy(rays["ray_o"])[None], "ray_d": torch.from_numpy(rays["ray_d"])[None],

