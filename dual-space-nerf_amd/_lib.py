@@ -46,7 +46,7 @@ SKIP_TRANSPARENT = 1
 NN_EXHAUSTIVE = 2
 FIELD_FP32 = 4
 SAMPLE_UNIFORM = 8
-NO_SCREEN = 16
+DENSITY_SCREEN = 16           # opt-in since ABI 5 (was NO_SCREEN with the opposite meaning)
 SCREEN_AUDIT = 32
 EARLY_STOP, STOP_STATS = 64, 128
 PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
@@ -593,12 +593,13 @@ class RenderWorkspace:
 
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
-                fp32=False, uniform=False, screen=True, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0,
+                fp32=False, uniform=False, screen=False, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0,
                 share_cus=False):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors.
     phases: 0 = the whole frame; PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE = only those parts, on the current stream (the caller
     orders the three calls of a frame with its own events and passes the same `out` / workspace to all of them: PhasePipeline).
-    early_stop: DSN_EARLY_STOP (eval mode: front-to-back slices, rays end once their transmittance is below 2^-20).
+    screen: DSN_DENSITY_SCREEN (opt-in: the plain-fp16 density screen in front of the accurate pass, margin as calibrated).
+    early_stop: DSN_EARLY_STOP (eval mode: front-to-back slices, rays end once their transmittance is below eps(S, colour scale)).
     stop_stats: DSN_STOP_STATS (count what early stop would leave out; read ws word CNT_STOP + 2)."""
     R = ray_o.shape[0]
     dev = scene.device
@@ -619,10 +620,10 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
         flags |= FIELD_FP32
     if uniform:
         flags |= SAMPLE_UNIFORM
-    if not screen:
-        flags |= NO_SCREEN
-    elif audit:
-        flags |= SCREEN_AUDIT
+    if screen:
+        flags |= DENSITY_SCREEN
+        if audit:
+            flags |= SCREEN_AUDIT
     if early_stop and (flags & SKIP_TRANSPARENT) and not fp32:
         flags |= EARLY_STOP
     if stop_stats:

@@ -176,7 +176,11 @@ class Renderer:
         self._frame_src = None
         self._slots = []
         self.skip_transparent = True      # eval mode: networks only on non-transparent samples (exact)
-        self.density_screen = True        # eval mode: plain-fp16 screen in front of the accurate pass (exact by its margin)
+        # eval mode: plain-fp16 density screen in front of the accurate pass.  OPT-IN since round 4: its margin is
+        # calibrated for the loaded parameters and audited while it runs - frames are bit-identical with it on or off on everything
+        # tested - but that is statistical safety, not a proof, and the one converged checkpoint (w4) calibrates it off anyway.
+        # density_screen = True: it runs when its calibration says it is safe and pays (-29 % frame time on an untrained fog).
+        self.density_screen = False
         # eval mode: re-check 1/128 of the screened-out samples.  True: every frame (read with last_screen_audit()); "auto" (default):
         # the first frame after a calibration and every SCREEN_AUDIT_EVERY-th one after it, read back WITHOUT a wait at the start
         # of a later frame - a violation (a dropped sample whose accurate density is positive) switches the screen off with a

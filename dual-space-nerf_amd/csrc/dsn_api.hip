@@ -598,7 +598,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         // eval mode, front to back: slices of L samples along the rays; a ray whose transmittance has fallen below eps is finished
         const int L = dsn_slice_len(R, S), K = (S + L - 1) / L;
         const int64_t cap = (int64_t)R * L;
-        const bool screen = !(flags & DSN_NO_SCREEN);
+        const bool screen = (flags & DSN_DENSITY_SCREEN) != 0;
         const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
         int32_t* pcnt = w.count + DSN_CNT_POS;
         dsn_launch_slice_bucket(w.active, w.count + DSN_CNT_ACTIVE, N, S, L, K, cap, w.slices, w.count + DSN_CNT_SLICE, st);
@@ -648,7 +648,7 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
         // eval mode: forward for every non-transparent sample, then d sigma/dx, normals and lighting only where sigma > 0
         // (elsewhere alpha = 0 exactly and the colour is never used); count[16] = number of such samples
         int32_t* pcnt = w.count + DSN_CNT_POS;
-        const bool screen = !(flags & DSN_NO_SCREEN);
+        const bool screen = (flags & DSN_DENSITY_SCREEN) != 0;
         const bool audit = screen && (flags & DSN_SCREEN_AUDIT);
         if (screen) {
             // plain-fp16 screen: samples whose fp16 density is negative by the safety margin keep that (negative) density and leave the

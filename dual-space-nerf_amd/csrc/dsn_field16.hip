@@ -1225,7 +1225,7 @@ void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, con
 //     sigma~ < -(F16_SCREEN_REL * S1 + F16_SCREEN_ABS),
 // a margin 36x the largest fp16-vs-fp32 deviation measured on the benchmark frame relative to S1 (2.75e-4 S1)
 // (tests/test_gpu_render.py::test_density_screen_margin); every other sample goes to the accurate pass.  An empty
-// sample keeps sigma~ (< 0) as its density, so the compositor sees the same exact zero.  DSN_NO_SCREEN turns it off.
+// sample keeps sigma~ (< 0) as its density, so the compositor sees the same exact zero.  off unless DSN_DENSITY_SCREEN is given.
 // ---------------------------------------------------------------------------------------------
 #ifndef F16_SCREEN_SGB
 #define F16_SCREEN_SGB 0      // n > 0: pin 1 MFMA : n VALU inside every block of the screen kernel

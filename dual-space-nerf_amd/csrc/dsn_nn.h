@@ -37,8 +37,13 @@ struct DsnGrid {            // device-resident descriptor (64 B)
 #define DSN_NN_FINE_MAXCELL 65536
 #define DSN_NN_COARSE_MAXCELL 16384
 
-__host__ __device__ inline int dsn_nn_fine_cap(int F) { long long c = 1600LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
-__host__ __device__ inline int dsn_nn_coarse_cap(int F) { long long c = 1000LL * F; return (int)(c < (1 << 20) ? (1 << 20) : c); }
+// List capacities (entries per level).  Measured needs at F = 13 776 (dsn_debug_nn_stats; tests/test_gpu_round4.py): the uniform
+// lattice body 970 F (fine, posed) / 820 F (coarse); the SMPL-like body of synth.make_body(nonuniform=True) - half of the vertices in
+// dense caps at head / hands / feet - 1260 F / 1060 F: round 3's 1600 F / 1000 F left the latter's COARSE level switched off (every
+// far query on the exhaustive sweep, silently).  2000 F / 2000 F now; a level that still does not fit is reported by the host mirror
+// (Scene.nn_overflow, a warning) instead of failing silently.
+__host__ __device__ inline int dsn_nn_fine_cap(int F) { long long c = 2000LL * F; return (int)(c < (1 << 20) ? (1 << 20) : (c > 0x7fffff00LL ? 0x7fffff00LL : c)); }
+__host__ __device__ inline int dsn_nn_coarse_cap(int F) { long long c = 2000LL * F; return (int)(c < (1 << 20) ? (1 << 20) : (c > 0x7fffff00LL ? 0x7fffff00LL : c)); }
 
 #define DSN_SUPER 4                 // build acceleration: super-cells of 4 x 4 x 4 cells ...
 #define DSN_SUPER_CAP 4096          // ... each with a candidate superset of at most this many faces

@@ -275,10 +275,14 @@ DSN_EXPORT int dsn_module_grad(const void* scene, int V, int F, const void* pack
 /* cfg.MODEL.sample_points_mode == "uniform" (can_render.py:42-51): plain uniform_sampling between the given near/far
  * instead of the geometry-guided interval.  Valid for dsn_render_rays. */
 #define DSN_SAMPLE_UNIFORM 8
-/* eval-mode density screen off: by default dsn_render_rays (with DSN_SKIP_TRANSPARENT, split-fp16 field) first runs a
- * plain-fp16 pass of the trunk and sends only the samples whose fp16 density is not negative by a safety margin - sigma~ >= -(1 % of the
- * magnitude of its terms + 0.01) - through the accurate pass; the others contribute exactly zero either way. */
-#define DSN_NO_SCREEN 16
+/* eval-mode density screen, OPT-IN since ABI 5 (rounds 1-3: on unless DSN_NO_SCREEN = 16 was given - the bit now means the opposite):
+ * with DSN_SKIP_TRANSPARENT and the split-fp16 field, dsn_render_rays first runs a plain-fp16 pass of the trunk and sends only the
+ * samples whose fp16 density is not negative by a safety margin - sigma~ >= -margin (magnitude of its terms + 1) - through the
+ * accurate pass; the others contribute exactly zero either way.  The margin is MEASURED for the parameters (dsn_calibrate_screen*:
+ * a factor 10 of headroom on a million points; 0.01 until then) and can be audited per frame (DSN_SCREEN_AUDIT): frames come out
+ * bit-identical with the screen on or off on everything tested, but that is a statistical statement about the calibration set, not
+ * a bound - hence not the default under a "results identical" contract. */
+#define DSN_DENSITY_SCREEN 16
 /* audit of the density screen: a pseudo-random 1/128 of the samples it declares empty go through the accurate pass anyway
  * (the frame stays exact); afterwards int32 word 40 of `workspace` holds how many were audited, word 44 how many of those have
  * an accurate density > 0 (must be 0: such a sample would have been dropped wrongly) and word 45 the largest such density

@@ -51,7 +51,7 @@ for step in "$@"; do
     trainpmc) D=gpurun_out/pmct_$TAG; rm -rf $D; C="python bench.py --train --steps 3 --warmup 2 $args"
          pmcpass $D fetch "$C" FETCH_SIZE; pmcpass $D write "$C" WRITE_SIZE
          pmcpass $D sq "$C" SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES; pmcpass $D grbm "$C" GRBM_GUI_ACTIVE
-         python scripts/pmc_summary.py $D ${O}_train_pmc.json | cut -c1-300 | head -12; rm -rf $D;;
+         python scripts/pmc_summary.py $D ${O}_train_pmc.json 5 | cut -c1-300 | head -12; rm -rf $D;;
     strong) timeout 600 python bench.py --strong --no-cpu-baseline $args 2>/dev/null | tail -1 > ${O}_strong.json; summ ${O}_strong.json;;
     strong8) timeout 900 python bench.py --strong --emulate-world 8 --steps 5 --warmup 2 $args 2>/dev/null | tail -1 > ${O}_strong_emulated8.json; summ ${O}_strong_emulated8.json;;
     weak8) timeout 900 python bench.py --emulate-world 8 --steps 8 --warmup 3 $args 2>/dev/null | tail -1 > ${O}_weak_emulated8.json; summ ${O}_weak_emulated8.json;;

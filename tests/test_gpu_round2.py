@@ -40,12 +40,15 @@ def full_frame(hw=512, seed=3, pose_seed=5, nonuniform=False):
     return canon, faces, batch
 
 
-def renderer_with(sd, canon, faces, S=64):
+def renderer_with(sd, canon, faces, S=64, density_screen=True):
+    """(density_screen: see test_gpu_render.make_renderer - the suite opts into the screen, the product default is off)"""
     import dsnerf_amd
     net = dsnerf_amd.DualSpaceNeRF(make_cfg(S))
     net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
     net.cuda()
-    return dsnerf_amd.Renderer(net, None, make_cfg(S), torch.from_numpy(canon), body_data={"f": faces})
+    r = dsnerf_amd.Renderer(net, None, make_cfg(S), torch.from_numpy(canon), body_data={"f": faces})
+    r.density_screen = bool(density_screen)
+    return r
 
 
 # ------------------------------------------------------------------------------------------------------------------------

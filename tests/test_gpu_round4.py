@@ -274,3 +274,28 @@ def test_list_capacity_overflow_warns_and_stays_exact(monkeypatch):
     for k in ("face_idx", "x_c", "transparent"):
         assert torch.equal(got[k], want[k]), k
     assert np.array_equal(got["face_idx"].cpu().numpy(), g["idx_world"].reshape(-1))
+
+
+def test_density_screen_is_opt_in():
+    """the plain-fp16 density screen is statistically safe (calibrated margin + audit), not proven exact - so it is off
+    unless asked for: a new Renderer renders default-parameter frames without it (every non-transparent sample takes the accurate
+    pass), dsn_render_rays without DSN_DENSITY_SCREEN likewise; opted in, it runs and the frame keeps its bits."""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)
+    r = renderer_with(state(), canon, faces, density_screen=False)
+    r.eval()
+    assert r.density_screen is False
+    a = r.render_view(batch, device_output=True)
+    torch.cuda.synchronize()
+    assert r.last_frame_info["density_screen"] is False and r.screen_info is None
+    c = r._ws.buf[:256].view(torch.int32).cpu()
+    assert int(c[_lib.CNT_KEEP]) == 0 and int(c[_lib.CNT_ACTIVE]) > 0           # no screen ran
+    r2 = renderer_with(state(), canon, faces, density_screen=True)
+    r2.eval()
+    b = r2.render_view(batch, device_output=True)
+    torch.cuda.synchronize()
+    assert r2.last_frame_info["density_screen"] is True and r2.screen_info["usable"]
+    c2 = r2._ws.buf[:256].view(torch.int32).cpu()
+    assert 0 < int(c2[_lib.CNT_KEEP]) < int(c2[_lib.CNT_ACTIVE])
+    for k in a:
+        assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
