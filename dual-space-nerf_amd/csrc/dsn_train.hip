@@ -834,6 +834,9 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
 // splits 0.44 -> LDS-DMA staging 0.345 -> convert-once 0.33 -> one workgroup per CU (256 instead of 512 groups) 0.28.  (Storing
 // per-workgroup tiles and reducing them in a second kernel instead of the atomicAdd epilogue measured the same: 0.24 + 0.04.)
 #define W16S_STAGES 4
+#ifndef W16D_VALU
+#define W16D_VALU 5           // k_t_wgrad16d: VALU instructions the scheduler places behind each MFMA of a pipelined step
+#endif
 __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
@@ -1000,6 +1003,219 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
         publish(v);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         multiply();
+    }
+    const float back = sy * sx;
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b) {
+            const int j = (wi * IT + b) * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (wo * OT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dW + (int64_t)i * ldw + j, acc[a][b][r] * back);
+            }
+        }
+    if (dbias) atomicAdd(dbias + tid, bsum);
+}
+
+// Round 4: the same product, SOFTWARE-PIPELINED.  In k_t_wgrad16c a step runs in phases - wait for the DMA, barrier, read the ring and
+// split (VALU + LDS), barrier, 48 MFMAs - and a wave issues in order: while it is feeding its 48 MFMAs into the matrix pipe (~1500
+// cycles) it converts nothing, and while it converts the pipe idles (MFMA busy 24 %, a step takes 2.0-2.7 us against 0.7 us of MFMA
+// issue).  Here the operands live in TWO buffers: the conversion of step t + 1 (ring -> split halves -> operand buffer (t + 1) & 1) is
+// written BETWEEN the MFMAs of step t in program order (sched_group_barrier: one MFMA, then a handful of VALU / LDS instructions),
+// the wait for the DMA of step t + 2 moves to the end of the step, and ONE barrier per step certifies all three hand-overs (operands
+// of t + 1 published, ring slot t + 1 consumed, step t + 2 landed).  LDS: 3 ring stages (96 KB) + 2 operand buffers (64 KB) = the same
+// 160 KB.  Same products in the same order per accumulator: the same partial sums as k_t_wgrad16c (DSN_WGRAD16=c keeps that kernel).
+#define W16D_STAGES 3
+__global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
+                                                     const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
+                                                     int rows_per_wg, float* __restrict__ dW, int ldw,
+                                                     float* __restrict__ dbias, Rows rw) {
+    constexpr int OT = 4, IT = 4, WI = 2;
+    __shared__ __attribute__((aligned(16))) float ring[W16D_STAGES][2][16][256];
+    __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][2][256];      // [buffer][operand][hi | lo][8-sample group][feature]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / WI, wi = wave % WI;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t NL = rows_n(rw, N);
+    if (rw.cnt) rows_per_wg = (int)rows_share(NL, 16, 64);     // (the launch was sized for N rows: share what is listed)
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t n1 = n0 + rows_per_wg;
+    if (n1 > NL) n1 = NL;
+    if (n0 >= n1) return;                                // workgroup-uniform
+    const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
+    const bool tail = n0 + 16 * (int64_t)full < n1;
+    float bsum = 0.0f;                                   // column sum of dY feature tid (bias gradient)
+    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    t_f32x16 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ring[0][0][0][0];
+    t_i32x4 ids = {0, 0, 0, 0};                          // listed rows: the wave's four row numbers of the next step to be staged
+    auto fetch_ids = [&](int t) {
+        if (!rw.list) return;
+        ids = *reinterpret_cast<t_cptr4>((uintptr_t)(rw.list + (n0 + 16 * (int64_t)t + 4 * wave)));
+    };
+    // DMA of step t into ring slot t % 3: exactly 8 instructions per wave in every form (the vmcnt waits below count on it)
+    auto stage = [&](int t) {
+        const int slot = t % W16D_STAGES;
+        const int64_t row = n0 + 16 * (int64_t)t + 4 * wave;
+        const unsigned da = ring_off + (unsigned)(((slot * 2 + 0) * 16 + 4 * wave) * 1024);
+        const unsigned db = ring_off + (unsigned)(((slot * 2 + 1) * 16 + 4 * wave) * 1024);
+        int64_t r0 = row;
+        if (rw.list) {
+            if (ids[3] - ids[0] != 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* ga = reinterpret_cast<const char*>(dY + (int64_t)ids[j] * 256) + lane * 16;
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* gb = reinterpret_cast<const char*>(X + (int64_t)ids[j] * 256) + lane * 16;
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db + 1024u * j) : "memory", "m0");
+                }
+                return;
+            }
+            r0 = (int64_t)ids[0];                        // a run of four consecutive rows: the one-address form
+        }
+        const char* ga = reinterpret_cast<const char*>(dY + r0 * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(X + r0 * 256) + lane * 16;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(ga), "s"(da) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     : : "v"(gb), "s"(db) : "memory", "m0");
+    };
+    auto ring_read = [&](int slot, float (&v)[2][16]) {
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[op][j] = ring[slot][op][j][tid];
+    };
+    // split the 16 values v[op][row] of feature tid and publish them in operand buffer `buf`
+    auto publish = [&](const float (&v)[2][16], int buf) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bsum += v[0][j];
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const float inv = op == 0 ? iy : ix;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                t_half8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = v[op][8 * g + j] * inv;
+                    const _Float16 h = (_Float16)x;
+                    hi[j] = h;
+                    lo[j] = (_Float16)(x - (float)h);
+                }
+                opbuf[buf][op][0][g][tid] = hi;
+                opbuf[buf][op][1][g][tid] = lo;
+            }
+        }
+    };
+    auto operands = [&](int buf, t_half8 (&ah)[OT], t_half8 (&al)[OT], t_half8 (&bh)[IT], t_half8 (&bl)[IT]) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+            ah[a] = opbuf[buf][0][0][half][(wo * OT + a) * 32 + col];
+            al[a] = opbuf[buf][0][1][half][(wo * OT + a) * 32 + col];
+        }
+#pragma unroll
+        for (int b = 0; b < IT; ++b) {
+            bh[b] = opbuf[buf][1][0][half][(wi * IT + b) * 32 + col];
+            bl[b] = opbuf[buf][1][1][half][(wi * IT + b) * 32 + col];
+        }
+    };
+    auto mfmas = [&](const t_half8 (&ah)[OT], const t_half8 (&al)[OT], const t_half8 (&bh)[IT], const t_half8 (&bl)[IT]) {
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int b = 0; b < IT; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+    if (full > 0) {
+        const int pre = full < W16D_STAGES ? full : W16D_STAGES;
+        for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
+        if (pre < full) fetch_ids(pre);
+        // step 0 has landed (steps 1, 2 may fly) -> its operands into buffer 0; then step 1 has landed too
+        if (pre == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (pre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            float v[2][16];
+            ring_read(0, v);
+            publish(v, 0);
+        }
+        if (pre == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int t = 0; t + 1 < full; ++t) {
+            // here: operands of step t published in buffer t & 1, step t + 1 landed (slot (t + 1) % 3), step t + 2 in flight, slot t % 3 free
+            if (t + W16D_STAGES < full) {
+                stage(t + W16D_STAGES);
+                if (t + W16D_STAGES + 1 < full) fetch_ids(t + W16D_STAGES + 1);
+            }
+            {
+                t_half8 ah[OT], al[OT], bh[IT], bl[IT];
+                float v[2][16];
+                operands(t & 1, ah, al, bh, bl);
+                ring_read((t + 1) % W16D_STAGES, v);
+                mfmas(ah, al, bh, bl);
+                publish(v, (t + 1) & 1);
+#if !defined(W16D_NO_SGB)
+                // program order for the in-order issue: operand + ring reads first, then one MFMA : a few VALU, the LDS writes behind
+#pragma unroll
+                for (int i = 0; i < 48; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, W16D_VALU, 0);
+                    if ((i % 6) == 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+#endif
+            }
+            // step t + 2 has landed (step t + 3, just issued, may fly)
+            if (t + 2 < full) {
+                if (t + W16D_STAGES < full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        {   // the last full step: nothing behind it to convert
+            t_half8 ah[OT], al[OT], bh[IT], bl[IT];
+            operands((full - 1) & 1, ah, al, bh, bl);
+            mfmas(ah, al, bh, bl);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    if (tail) {
+        float v[2][16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t lrow = n0 + 16 * (int64_t)full + j;
+            const bool ok = lrow < n1;
+            const int64_t row = ok ? rows_at(rw, lrow) : 0;
+            v[0][j] = ok ? dY[row * 256 + tid] : 0.0f;
+            v[1][j] = ok ? X[row * 256 + tid] : 0.0f;
+        }
+        publish(v, full & 1);                                                   // (that buffer's readers are behind the loop's last barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        t_half8 ah[OT], al[OT], bh[IT], bl[IT];
+        operands(full & 1, ah, al, bh, bl);
+        mfmas(ah, al, bh, bl);
     }
     const float back = sy * sx;
 #pragma unroll
@@ -1207,7 +1423,9 @@ void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, c
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
+    static const bool old_kernel = [] { const char* e = getenv("DSN_WGRAD16"); return e && e[0] == 'c'; }();
+    if (old_kernel) hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
+    else hipLaunchKernelGGL(k_t_wgrad16d, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
 }
 
 
