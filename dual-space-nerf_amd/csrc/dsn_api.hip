@@ -460,17 +460,22 @@ static inline int dsn_slice_len(int R, int S) {
     if (L > 64) L = 64;
     return (S + L - 1) / L <= DSN_STOP_MAX_SLICES ? L : (S + DSN_STOP_MAX_SLICES - 1) / DSN_STOP_MAX_SLICES;
 }
-// entries of the per-slice lists: K slices of R * L each, K * L < S + L whatever the slice length (above)
-static inline size_t dsn_slice_entries(size_t R, int S) { return R * ((size_t)S + (size_t)std::max(64, S / DSN_STOP_MAX_SLICES + 1)); }
+// entries of the per-slice lists: K slices of R * L each (K L < S + L) for the slice length in use - round 3 reserved R (S + 64) for any
+// length (8 bytes per sample at S = 64; now 4).  DSN_STOP_SLICE (experiments) changes L: set it before the workspace is sized.
+static inline size_t dsn_slice_entries(size_t R, int S) {
+    const int L = dsn_slice_len((int)std::min<size_t>(R, 0x7fffffff), S), K = (S + L - 1) / L;
+    return R * (size_t)K * (size_t)L;
+}
 // Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
-// pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for half of the samples of a
-// big frame (the bench frame puts 11.6 % of its samples there, a solid trained network 39 %); samples beyond the capacity
-// take the single-launch forward + reverse pass instead (dsn_launch_field16_from): same values, no records.
-// DSN_RECORD_CAP (tests) overrides the capacity.
+// pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for A QUARTER of the samples of a
+// big frame (round 3: half - 1.9 of the 3.4 GB of a 512 x 512 x 64 frame).  The bench frame puts 11.6 % (hash-random parameters) /
+// 8 % (converged parameters, front-to-back slices) of its samples there, a briefly trained solid 39 %; samples beyond the capacity
+// take the single-launch forward + reverse pass instead (dsn_launch_field16_from): same values, no records, ~10 % more time for them.
+// DSN_RECORD_CAP (tests, or a caller who wants the records of every sample) overrides the capacity.
 static int64_t dsn_record_cap(int64_t N) {
     const char* e = getenv("DSN_RECORD_CAP");
     if (e) { const long long v = atoll(e); return v < 1 ? 1 : (v > N ? N : v); }
-    return N <= ((int64_t)1 << 21) ? N : (N / 2 > ((int64_t)1 << 21) ? N / 2 : ((int64_t)1 << 21));
+    return N <= ((int64_t)1 << 21) ? N : (N / 4 > ((int64_t)1 << 21) ? N / 4 : ((int64_t)1 << 21));
 }
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
     DsnWorkspace w;
@@ -490,7 +495,9 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.rec_cap = dsn_record_cap((int64_t)N);
     w.masks = (void*)p;           p += dsn_align256(224 * (size_t)w.rec_cap);
     w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
-    w.keep = (int32_t*)p;         p += dsn_align256(4 * N);
+    // the density screen's keep list lives from the screen to the forward launch of a slice / frame: inside the field phase, where the
+    // normal buffer is free (the geometry phase's sort is done with it, the early-stop shading weights and the normals come later)
+    w.keep = (int32_t*)w.n_w;
     w.audit_cap = (int)(N / 32 + 1024);                                      // 1/128 of the empty samples are audited
     w.audit = (int32_t*)p;        p += dsn_align256(4 * (size_t)w.audit_cap);
     w.T = (void*)p;               p += dsn_align256(8 * (size_t)R);

@@ -29,7 +29,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-// build-time variant switches (A/B-ed with scripts/variants.sh + scripts/gpu_variants.sh; defaults = best measured)
+// build-time variant switches (A/B-ed with scripts/variants.sh + scripts/gpu_variants.sh; defaults = best measured).
+// Every switch below keeps the results.  The timing ablations that do NOT (F16_ABL, F16_SABL: kernels with pieces cut out, WRONG
+// results by design) and the in-kernel cycle counters (F16_TIMING) exist only in builds made with -DDSN_EXPERIMENTS
+// (scripts/variants.sh passes it): the product build (dual-space-nerf_amd/build.py) cannot switch them on.
+#if !defined(DSN_EXPERIMENTS) && (defined(F16_ABL) || defined(F16_SABL) || defined(F16_TIMING))
+#error "F16_ABL / F16_SABL / F16_TIMING are experiment switches (wrong results / debug counters): build with -DDSN_EXPERIMENTS"
+#endif
 #ifndef F16_SINCOS_OCML
 #define F16_SINCOS_OCML 0     // 1: ocml sincosf (divergent large-argument path), 0: branch-free dsn_sincos
 #endif
