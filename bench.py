@@ -364,6 +364,9 @@ def main():
             torch.cuda.synchronize()
             st = _lib.read_stop_stats(ws)
             frac = st["would_skip"] / max(st["active"], 1)
+            # (like Renderer: the probe frame sizes the relu-record array for these parameters - a dense field gets more than the default
+            #  quarter of the samples instead of the overflow pass on every frame; every slot's workspace grows at its next get())
+            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S))
             cmax = st["colour_max"]
             finite = cmax == cmax and cmax != float("inf")
             scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0

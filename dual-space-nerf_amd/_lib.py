@@ -39,7 +39,7 @@ EXPORTS = [
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
-    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets",
+    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_record_capacity_fraction",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -76,6 +76,7 @@ def lib():
         L.dsn_last_error.restype = C.c_char_p
         L.dsn_early_stop_eps.restype = C.c_float
         L.dsn_early_stop_eps_scaled.restype = C.c_float
+        L.dsn_record_capacity_fraction.restype = C.c_float
         for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
@@ -575,6 +576,20 @@ def composite(colour, sigma, transparent, z_vals, ray_d, noise=None):
                                _ptr(transparent), _ptr(z_vals, torch.float32), _ptr(ray_d, torch.float32), _ptr(noise),
                                R, S, _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(w), _ptr(dep), _stream()), "dsn_composite")
     return rgb, disp, acc, w, dep
+
+
+def record_capacity_fraction(at_least: float = 0.0) -> float:
+    """share of a big frame's samples the relu-record array of the render workspace is sized for (dsn_record_capacity_fraction:
+    process-wide, only grows).  RenderWorkspace.get() picks a raised value up at its next call."""
+    return float(lib().dsn_record_capacity_fraction(C.c_float(at_least)))
+
+
+def fit_record_capacity(positive_fraction: float) -> float:
+    """a frame put this share of its samples on the sigma > 0 list: make the record capacity cover 1.25 x that (samples beyond the
+    capacity have their forward pass evaluated twice; Renderer / bench.py call this with their probe frame's count)"""
+    if positive_fraction > 0.8 * record_capacity_fraction():
+        return record_capacity_fraction(min(1.0, 1.25 * float(positive_fraction)))
+    return record_capacity_fraction()
 
 
 class RenderWorkspace:

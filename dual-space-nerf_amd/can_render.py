@@ -547,6 +547,7 @@ class Renderer:
         out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=phases, out=out,
                                share_cus=getattr(self, "_frames_overlap", False), **plan)
         if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
+            self._probe_samples = int(o.shape[0]) * int(S)
             snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
             ev = torch.cuda.Event()
             ev.record()
@@ -602,6 +603,11 @@ class Renderer:
             return
         st = _lib.read_stop_stats(snap)
         frac = st["would_skip"] / max(st["active"], 1)
+        # (the probe frame also says how many relu records frames of these parameters need: a dense field gets a larger record array
+        #  before its second frame instead of the overflow pass on every frame)
+        n_pos = int(snap.view(torch.int32)[_lib.CNT_POS])
+        if getattr(self, "_probe_samples", 0) > 0:
+            _lib.fit_record_capacity(n_pos / float(self._probe_samples))
         self._note_colour_max(packed, st["colour_max"], first=True)
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}

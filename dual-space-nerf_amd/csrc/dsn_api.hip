@@ -4,6 +4,7 @@
 #include "../../include/dsnerf.h"
 #include "dsn_common.h"
 #include "dsn_kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 #include <stdio.h>
@@ -23,6 +24,7 @@ static int dsn_check_launch(const char* what) {
 #define DSN_REQUIRE(cond, msg) do { if (!(cond)) return dsn_fail("%s", msg); } while (0)
 
 thread_local int g_dsn_persistent_override = 0;
+static std::atomic<float> g_record_fraction{0.25f};      // dsn_record_capacity_fraction
 namespace {
 struct DsnShareCus {      // DSN_SHARE_CUS for the duration of one dsn_render_rays call
     explicit DsnShareCus(bool on) {
@@ -475,7 +477,11 @@ static inline size_t dsn_slice_entries(size_t R, int S) {
 static int64_t dsn_record_cap(int64_t N) {
     const char* e = getenv("DSN_RECORD_CAP");
     if (e) { const long long v = atoll(e); return v < 1 ? 1 : (v > N ? N : v); }
-    return N <= ((int64_t)1 << 21) ? N : (N / 4 > ((int64_t)1 << 21) ? N / 4 : ((int64_t)1 << 21));
+    const int64_t floor_ = (int64_t)1 << 21;
+    if (N <= floor_) return N;
+    int64_t c = (int64_t)((double)N * (double)g_record_fraction.load());
+    c = (c + 255) & ~(int64_t)255;
+    return c < floor_ ? floor_ : (c > N ? N : c);
 }
 static DsnWorkspace dsn_carve(void* base, int R, int S) {
     DsnWorkspace w;
@@ -505,6 +511,16 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.alive = (int32_t*)p;        p += dsn_align256(4 * N);
     w.bytes = (size_t)(p - (char*)base);
     return w;
+}
+
+// share of a big frame's samples the relu-record array is sized for (process-wide, only ever grows; see dsnerf.h)
+float dsn_record_capacity_fraction(float at_least) {
+    if (at_least == at_least && at_least > 0.0f) {
+        const float want = at_least > 1.0f ? 1.0f : at_least;
+        float cur = g_record_fraction.load();
+        while (want > cur && !g_record_fraction.compare_exchange_weak(cur, want)) {}
+    }
+    return g_record_fraction.load();
 }
 
 float dsn_early_stop_eps(int S) { return dsn_stop_eps_scaled(S > 0 ? S : 1, 1.0f); }

@@ -430,11 +430,21 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
     }
 }
 // the same store for a whole block (non-pipelined epilogues)
+#ifndef F16_NT_STORE
+#define F16_NT_STORE 0        // training stores (activations written once, read much later by the weight-gradient kernels) with the nt hint
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float* st, const f32x16& v, float stscale) {
     if (!st) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+#if F16_NT_STORE
+        const f32x4 x = {v[4 * q] * stscale, v[4 * q + 1] * stscale, v[4 * q + 2] * stscale, v[4 * q + 3] * stscale};
+        __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(st + 8 * q));
+#else
         *reinterpret_cast<float4*>(st + 8 * q) = make_float4(v[4 * q] * stscale, v[4 * q + 1] * stscale, v[4 * q + 2] * stscale, v[4 * q + 3] * stscale);
+#endif
+    }
 }
 
 // 256 -> 256 forward layer (software-pipelined epilogues: the epilogue of output block m-1 issues under the MFMAs of block m)
