@@ -33,7 +33,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // Every switch below keeps the results.  The timing ablations that do NOT (F16_ABL, F16_SABL: kernels with pieces cut out, WRONG
 // results by design) and the in-kernel cycle counters (F16_TIMING) exist only in builds made with -DDSN_EXPERIMENTS
 // (scripts/variants.sh passes it): the product build (dual-space-nerf_amd/build.py) cannot switch them on.
-#if !defined(DSN_EXPERIMENTS) && (defined(F16_ABL) || defined(F16_SABL) || defined(F16_TIMING))
+#if !defined(DSN_EXPERIMENTS) && (defined(F16_ABL) || defined(F16_SABL) || defined(F16_TIMING) || defined(F16_TRAIN_ABL))
 #error "F16_ABL / F16_SABL / F16_TIMING are experiment switches (wrong results / debug counters): build with -DDSN_EXPERIMENTS"
 #endif
 #ifndef F16_SINCOS_OCML
@@ -435,6 +435,24 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(float* st, const f32x16& v, float stscale) {
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 4)
+    // timing emulation (WRONG data, right access pattern) of quad-transposed stores: instruction j writes, for the four points of a
+    // lane quad in turn, point j's row - lane i of the quad its 16-byte piece i of a 64-byte segment (lower / upper half-wave: first /
+    // second segment of the 128-byte line) - instead of every lane 16 bytes of its own row
+    {
+        const int lane = threadIdx.x & 63, hf = lane >> 5, i = lane & 3;
+        const unsigned long long me = (unsigned long long)(uintptr_t)st;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int src = (lane & ~3) | j;
+            const unsigned lo = __shfl((unsigned)me, src), hi = __shfl((unsigned)(me >> 32), src);
+            float* pj = reinterpret_cast<float*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+            if (pj) *reinterpret_cast<float4*>(pj - 4 * hf + 16 * hf + 4 * i) =
+                make_float4(v[4 * j] * stscale, v[4 * j + 1] * stscale, v[4 * j + 2] * stscale, v[4 * j + 3] * stscale);
+        }
+        return;
+    }
+#endif
     if (!st) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -625,8 +643,13 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     uint4* mrec = masks ? masks + ((size_t)(MODE == F16_BWD ? lslot : pt) * 2 + half) * 7 : nullptr;
     // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
     const int64_t tr_ls = N * 256;
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL)      // timing ablation (WRONG results): 1 = no h_l stores, 2 = no a_l stores
+    float* const th = ST && valid && !(F16_TRAIN_ABL & 1) ? tr_h + pt * 256 + 4 * half : nullptr;
+    float* const ta = ST && valid && !(F16_TRAIN_ABL & 2) ? tr_a + pt * 256 + 4 * half : nullptr;
+#else
     float* const th = ST && valid ? tr_h + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : h_l
     float* const ta = ST && valid ? tr_a + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : masked sigma-adjoint of layer l
+#endif
 
   if (MODE != F16_BWD) {
     // positional encoding (fp32, accurate sincos) -> split k-steps; same slot map as k_field

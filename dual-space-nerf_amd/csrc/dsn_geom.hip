@@ -211,11 +211,11 @@ __device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_be
 // cls (fused path): the first step of the cell-major nearest-face search rides along - the sample's fine cell goes to cls.cell_of and
 // the cell's counter is bumped once per run of equal cells in the wave (dsn_nn.hip, k_nns_classify: the same code on the z just
 // computed instead of a second pass that reads it back)
-struct GgClassify { const DsnGrid* gf; int32_t* cell_of; int32_t* counts; int32_t* outside; };
+struct GgClassify { const DsnGrid* gf; int32_t* cell_of; int32_t* counts; int32_t* outside; int32_t* rank_of; };
 __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far, const float* __restrict__ ray_o,
                                         const float* __restrict__ ray_d, int R, int S, const float* __restrict__ t_vals,
                                         const float* __restrict__ jitter, float* __restrict__ z_vals, float* __restrict__ pts,
-                                        const GgClassify cls = GgClassify{nullptr, nullptr, nullptr, nullptr}) {
+                                        const GgClassify cls = GgClassify{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int tid = threadIdx.x;
     const int rays_here = min(GG_THREADS, R - blockIdx.x * GG_THREADS);
     const int total = rays_here * S;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far,
             const float py = ray_o[3 * rr + 1] + ray_d[3 * rr + 1] * z;
             const float pz = ray_o[3 * rr + 2] + ray_d[3 * rr + 2] * z;
             if (pts && valid) { pts[3 * g + 0] = px; pts[3 * g + 1] = py; pts[3 * g + 2] = pz; }
-            if (cls.gf) dsn_nns_classify_one(cls.gf, valid ? g : (int64_t)-1, valid, px, py, pz, 0, cls.cell_of, cls.counts, cls.outside);
+            if (cls.gf) dsn_nns_classify_one(cls.gf, valid ? g : (int64_t)-1, valid, px, py, pz, cls.rank_of, cls.cell_of, cls.counts, cls.outside);
         }
     }
 }
@@ -327,8 +327,9 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg_finish(const float* __
 
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
-                          hipStream_t st, const DsnGrid* cls_grid, int32_t* cls_cell_of, int32_t* cls_counts, int32_t* cls_outside) {
-    const GgClassify cls = {cls_grid, cls_cell_of, cls_counts, cls_outside};
+                          hipStream_t st, const DsnGrid* cls_grid, int32_t* cls_cell_of, int32_t* cls_counts, int32_t* cls_outside,
+                          int32_t* cls_rank_of) {
+    const GgClassify cls = {cls_grid, cls_cell_of, cls_counts, cls_outside, cls_rank_of};
     const int blocks = (R + GG_THREADS - 1) / GG_THREADS;
     int slices = blocks > 0 ? 1024 / blocks : 1;           // aim at ~4 workgroups per CU
     if (slices > V / 256) slices = V / 256;                // at least 256 vertices per slice
@@ -830,6 +831,10 @@ __device__ __forceinline__ float dsn_slice_factor(const float* __restrict__ sigm
     }
     return P;
 }
+// LC > 0: the slice length at compile time - the factor of slice k - 1 (the one nearly every entry needs) is straight-line code, so the
+// loads of a thread's eight entries are issued together instead of one dependent chain per entry inside a branch (the first fused
+// version took 53 us per slice against 25 us for the two kernels it replaced; the catch-up over older slices stays a rare branch)
+template <int LC>
 __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__ list, const int32_t* __restrict__ count, int S, int L, int k,
                                                       unsigned long long* __restrict__ Tk, const float* __restrict__ sigma,
                                                       const uint8_t* __restrict__ transparent, const float* __restrict__ z_vals,
@@ -839,29 +844,71 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
     __shared__ int s_cnt[2], s_base;
     const int n = *count;
     const float eps = dsn_stop_eps_scaled(S, scal[6]);
+    if (LC > 0) L = LC;
+    const int p0 = (k - 1) * L, p1 = k * L < S ? k * L : S;          // slice k - 1
     for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         int32_t idx[DSN_AGG_PER_THREAD];
         int off[DSN_AGG_PER_THREAD];
+        float Tn[DSN_AGG_PER_THREAD], P[DSN_AGG_PER_THREAD], dn[DSN_AGG_PER_THREAD];
+        int kd[DSN_AGG_PER_THREAD];
+        bool ok[DSN_AGG_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
             const int64_t i = base + j * 256 + threadIdx.x;
-            off[j] = -1;
-            if (i < n) {
-                idx[j] = list[i];
-                const int r = idx[j] / S;
-                const unsigned long long pr = __atomic_load_n(Tk + r, __ATOMIC_RELAXED);
-                float T = __uint_as_float((uint32_t)pr);
-                int kd = (int)(pr >> 32);
-                if (kd < k) {
-                    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
-                    const float dn = dsn_norm3(d);
-                    for (; kd < k; ++kd) {
-                        const int s0 = kd * L, s1 = (kd + 1) * L < S ? (kd + 1) * L : S;
-                        T = T * dsn_slice_factor(sigma, transparent, z_vals, dn, (int64_t)r * S, S, s0, s1);
+            ok[j] = i < n;
+            idx[j] = list[ok[j] ? i : (int64_t)n - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            const int r = idx[j] / S;
+            // (single-copy-atomic 8-byte access at WORKGROUP scope = a plain global_load_dwordx2: a stale pair is harmless - the entry
+            //  recomputes the same value - and the system scope an unqualified atomic gets bypasses the caches: 2x the kernel time)
+            const unsigned long long pr = __hip_atomic_load(Tk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            Tn[j] = __uint_as_float((uint32_t)pr);
+            kd[j] = (int)(pr >> 32);
+            const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+            dn[j] = dsn_norm3(d);
+            if (LC > 0) {
+                // slice k - 1 of this ray, unrolled: k_composite's alpha (see dsn_slice_factor: the same factors in the same order)
+                const int64_t g0 = (int64_t)r * S;
+                constexpr int LA = LC > 0 ? LC : 1;      // (LC = 0 never gets here)
+                float z[LA + 1], sg[LA];
+                uint8_t tr[LA];
+#pragma unroll
+                for (int q = 0; q <= LC; ++q) z[q] = p0 + q < S ? z_vals[g0 + p0 + q] : 0.f;
+#pragma unroll
+                for (int q = 0; q < LC; ++q) { const bool in = p0 + q < p1; sg[q] = in ? sigma[g0 + p0 + q] : 0.f; tr[q] = in ? transparent[g0 + p0 + q] : (uint8_t)1; }
+                float pp = 1.0f;
+#pragma unroll
+                for (int q = 0; q < LC; ++q) {
+                    if (p0 + q < p1) {
+                        const float dist = ((p0 + q + 1 < S) ? (z[q + 1] - z[q]) : 1e10f) * dn[j];
+                        float sv = tr[q] ? 0.f : sg[q];
+                        sv = sv > 0.f ? sv : 0.f;
+                        const float alpha = 1.0f - expf(-sv * dist);
+                        pp *= (1.0f - alpha) + 1e-10f;
                     }
-                    __atomic_store_n(Tk + r, ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)__float_as_uint(T), __ATOMIC_RELAXED);
+                }
+                P[j] = pp;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DSN_AGG_PER_THREAD; ++j) {
+            off[j] = -1;
+            if (ok[j]) {
+                const int r = idx[j] / S;
+                float T = Tn[j];
+                int kq = kd[j];
+                if (kq < k) {
+                    for (; kq < (LC > 0 ? k - 1 : k); ++kq) {       // (LC > 0: only the slices before k - 1 - a ray that had no entry for a while)
+                        const int s0 = kq * L, s1 = (kq + 1) * L < S ? (kq + 1) * L : S;
+                        T = T * dsn_slice_factor(sigma, transparent, z_vals, dn[j], (int64_t)r * S, S, s0, s1);
+                    }
+                    if (LC > 0) T = T * P[j];
+                    __hip_atomic_store(Tk + r, ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)__float_as_uint(T), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (!(T < eps)) off[j] = atomicAdd(&s_cnt[0], 1);
                 else atomicAdd(&s_cnt[1], 1);
@@ -878,6 +925,54 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
             if (off[j] >= 0) out[s_base + off[j]] = idx[j];
         __syncthreads();
     }
+}
+// The per-ray alternative (DSN_STOP_ADVANCE=ray): one lane per (ray, sample of slice k - 1), groups of G lanes share a ray (consecutive
+// samples: coalesced reads), the factors multiplied in sample order by the group's first lane - the same product, bit for bit, as an
+// entry of k_slice_alive computes - and (T', k) published for EVERY ray; the list filter behind it then finds every pair up to date.
+template <int G>
+__global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+                                                    const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
+                                                    int L, int k, unsigned long long* __restrict__ Tk) {
+    const int64_t gl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gl / G;
+    const int j = (int)(gl % G);
+    if (r >= R) return;
+    const unsigned long long pr = Tk[r];
+    const int kd = (int)(pr >> 32);
+    float T = __uint_as_float((uint32_t)pr);
+    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    // (rays the filter has kept current are one slice behind; a ray is never further behind here, every ray is advanced every slice)
+    const int s0 = (k - 1) * L, s1 = k * L < S ? k * L : S;
+    const int i = s0 + j;
+    float fac = 1.0f;
+    if (i < s1) {
+        const int64_t g = r * S + i;
+        const float z = z_vals[g];
+        const float dist = ((i + 1 < S) ? (z_vals[g + 1] - z) : 1e10f) * dn;
+        float sv = sigma[g];
+        if (transparent[g]) sv = 0.f;
+        sv = sv > 0.f ? sv : 0.f;
+        fac = (1.0f - (1.0f - expf(-sv * dist))) + 1e-10f;
+    }
+    // sample order: P = ((f0 f1) f2) f3 ..., as dsn_slice_factor multiplies (P starts at 1)
+    float P = 1.0f;
+#pragma unroll
+    for (int q = 0; q < G; ++q) P *= __shfl(fac, (int)((threadIdx.x & 63) - j + q));
+    if (j == 0 && kd < k) Tk[r] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)__float_as_uint(T * P);
+}
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
+                          int k, void* Tk, hipStream_t st) {
+#define DSN_ADV(G) hipLaunchKernelGGL(k_advance_T<G>, dim3((unsigned)(((int64_t)R * G + 255) / 256)), dim3(256), 0, st, sigma, transparent, \
+                                      z_vals, ray_d, R, S, L, k, (unsigned long long*)Tk)
+    if (L <= 1) DSN_ADV(1);
+    else if (L <= 2) DSN_ADV(2);
+    else if (L <= 4) DSN_ADV(4);
+    else if (L <= 8) DSN_ADV(8);
+    else if (L <= 16) DSN_ADV(16);
+    else if (L <= 32) DSN_ADV(32);
+    else DSN_ADV(64);
+#undef DSN_ADV
 }
 __global__ void __launch_bounds__(256) k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsigned long long v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -976,10 +1071,15 @@ void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count,
 }
 void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, int L, int k, void* Tk, const float* sigma,
                             const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
-                            int32_t* out_count, int32_t* stopped, hipStream_t st) {
+                            int32_t* out_count, int32_t* stopped, hipStream_t st, bool pairs_current) {
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
-    hipLaunchKernelGGL(k_slice_alive, dim3((unsigned)blocks), dim3(256), 0, st, list, count, S, L, k, (unsigned long long*)Tk, sigma,
-                       transparent, z_vals, ray_d, packed_scal, out, out_count, stopped);
+#define DSN_ALIVE(LC) hipLaunchKernelGGL(k_slice_alive<LC>, dim3((unsigned)blocks), dim3(256), 0, st, list, count, S, L, k, (unsigned long long*)Tk, \
+                                         sigma, transparent, z_vals, ray_d, packed_scal, out, out_count, stopped)
+    if (pairs_current) DSN_ALIVE(0);      // (every pair was advanced by k_advance_T: nothing to compute, the generic form only filters)
+    else if (L == 4) DSN_ALIVE(4);
+    else if (L == 8) DSN_ALIVE(8);
+    else DSN_ALIVE(0);
+#undef DSN_ALIVE
 }
 // Tk[r] = (T = 1, covers 0 slices)
 void dsn_launch_slice_T_init(void* Tk, int R, hipStream_t st) {

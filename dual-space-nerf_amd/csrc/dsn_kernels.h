@@ -28,7 +28,7 @@ void dsn_launch_pose_setup(const float* packed, const float* poses, int frame_id
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
                           int R, int S, const float* t_vals, const float* jitter, float* z_vals, float* pts,
                           hipStream_t st, const DsnGrid* cls_grid = nullptr, int32_t* cls_cell_of = nullptr,
-                          int32_t* cls_counts = nullptr, int32_t* cls_outside = nullptr);
+                          int32_t* cls_counts = nullptr, int32_t* cls_outside = nullptr, int32_t* cls_rank_of = nullptr);
 // scratch of the cell-major search that the sampler fills when it classifies on the way (cleared here): per-cell counters and
 // the counter of samples outside the fine grid
 void dsn_nn_cellmajor_begin(void* small, int32_t** counts, int32_t** outside, hipStream_t st);
@@ -152,7 +152,10 @@ void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count,
 // (Tk: [R] x 8 bytes, dsn_launch_slice_T_init; packed_scal = packed + OFF_SCAL: the threshold's colour scale lives there)
 void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, int L, int k, void* Tk, const float* sigma,
                             const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
-                            int32_t* out_count, int32_t* stopped, hipStream_t st);
+                            int32_t* out_count, int32_t* stopped, hipStream_t st, bool pairs_current = false);
+// the per-ray form of the advance (one coalesced pass over slice k - 1 of every ray; dsn_launch_slice_alive(..., pairs_current = true) behind it)
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
+                          int k, void* Tk, hipStream_t st);
 void dsn_launch_slice_T_init(void* Tk, int R, hipStream_t st);
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,

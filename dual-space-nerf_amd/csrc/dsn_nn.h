@@ -205,9 +205,11 @@ __device__ __forceinline__ NnsRun nns_run(int c, int lane) {
 // one sample's step of the cell-major classification, called by every lane of a wave (wave-wide ballots inside): its fine cell
 // -> cell_of[i], the cell's counter bumped once per run, samples outside the fine grid counted in *outside (optional).  Shared by
 // k_nns_classify (dsn_nn.hip) and the sampler's emit loop (dsn_geom.hip: the fused path classifies while it writes z).
+// rank_of (optional, round 4): the atomic's return value is the run's offset inside its cell - kept per sample, it is the sample's place
+// in the cell-major order, and the counting sort's scatter needs no second round of atomics (k_nns_scatter_ranked).
 __device__ __forceinline__ int dsn_nns_classify_one(const DsnGrid* __restrict__ gf, int64_t i, bool valid, float px, float py, float pz,
-                                                    int, int32_t* __restrict__ cell_of, int32_t* __restrict__ counts,
-                                                    int32_t* __restrict__ outside) {
+                                                    int32_t* __restrict__ rank_of, int32_t* __restrict__ cell_of,
+                                                    int32_t* __restrict__ counts, int32_t* __restrict__ outside) {
     const int lane = threadIdx.x & 63;
     int c = -1;
     if (valid) {
@@ -215,7 +217,12 @@ __device__ __forceinline__ int dsn_nns_classify_one(const DsnGrid* __restrict__ 
         cell_of[i] = c;
     }
     const NnsRun r = nns_run(c, lane);
-    if (r.head && c >= 0) atomicAdd(counts + c, r.len);
+    int base = 0;
+    if (r.head && c >= 0) base = atomicAdd(counts + c, r.len);
+    if (rank_of) {
+        base = __shfl(base, r.head_lane);
+        if (valid && c >= 0) rank_of[i] = base + r.rank;
+    }
     // samples outside the fine grid (none for rays clipped to the body's bounds): counted, the fused search + warp leaves them to
     // a second pass (k_warp on the samples with cell_of < 0)
     if (outside) {

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
     float p[3] = {0.f, 0.f, 0.f};
     if (i < N) nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
-    const int c = dsn_nns_classify_one(gf, i, i < N, p[0], p[1], p[2], 0, cell_of, counts, outside);
+    const int c = dsn_nns_classify_one(gf, i, i < N, p[0], p[1], p[2], nullptr, cell_of, counts, outside);
     if (i < N && c < 0 && nn) nn[i] = -1;
 }
 
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
 // cleared for their second life as scatter cursors.  Single workgroup, LDS-staged tiles (see k_grid_scan).
 __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
-                                                    int32_t* __restrict__ totals) {
+                                                    int32_t* __restrict__ totals, int keep_counts) {
     __shared__ int s_n[1024 * SCAN_PER];
     __shared__ int s_w[16];
     const int ncell = gf->ok ? gf->ncell : 0;
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
         for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += (v[k] + NNS_PER - 1) / NNS_PER; }
         __syncthreads();
         for (int i = t; i < 1024 * SCAN_PER; i += 1024)
-            if (base + i < ncell) { wave_offs[base + i] = s_n[i]; counts[base + i] = 0; }
+            if (base + i < ncell) { wave_offs[base + i] = s_n[i]; if (!keep_counts) counts[base + i] = 0; }
         carry_a += tot_a; carry_b += tot_b;
         __syncthreads();
     }
@@ -379,6 +379,21 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter(const int32_t* __re
         nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
         sorted[base + r.rank] = make_float4(p[0], p[1], p[2], __int_as_float((int)i));
     }
+}
+
+// the same scatter from the ranks the classification kept (dsn_nns_classify_one, rank_of): position = cell offset + rank, no atomics
+// (k_nns_scatter spent its 0.29 ms per 16.8 M samples on them), the per-cell counts stay what the classification counted
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter_ranked(const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
+                                                                    const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                    const float* __restrict__ z_vals, int64_t N, int S,
+                                                                    const int32_t* __restrict__ offs, float4* __restrict__ sorted) {
+    const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    if (i >= N) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    float p[3];
+    nns_point(nullptr, ray_o, ray_d, z_vals, i, S, p);
+    sorted[offs[c] + rank_of[i]] = make_float4(p[0], p[1], p[2], __int_as_float((int)i));
 }
 
 // WARP = true (round 3): the rest of the warp stage (can_render.py:333-379: projection onto the nearest posed face, transparency,
@@ -590,9 +605,14 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
         hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, cell_of, (int32_t*)nullptr,
                            counts, totals + 2);
     }
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
+    // classified by the sampler: it also kept every sample's rank inside its cell (cell_of + N) - the scatter places by rank
+    const bool ranked = classified && !getenv("DSN_NN_ATOMIC_SCATTER");      // (A/B switch: round 3's scatter with atomic cursors)
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, ranked ? 1 : 0);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
-    hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
+    if (ranked)
+        hipLaunchKernelGGL(k_nns_scatter_ranked, gN, b, 0, st, cell_of, cell_of + N, ray_o, ray_d, z_vals, N, S, offs, (float4*)sorted);
+    else
+        hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
     hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
@@ -626,7 +646,7 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, pts, ray_o, ray_d, z_vals, N, S, cell_of, nn, counts, (int32_t*)nullptr);
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, 0);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
@@ -666,7 +686,7 @@ void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, cons
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_COARSE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify_coarse, gN, b, 0, st, v.fine.g, v.coarse.g, pts, live, N, cell_of, nn, counts);
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 0);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,
                        offs, counts, (float4*)sorted);
