@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--early-stop", default="auto", choices=["auto", "on", "off"],
                     help="front-to-back slices with ray termination (DSN_EARLY_STOP): auto = like Renderer, from the statistics of one "
                          "probe frame at set-up (used when it would leave out >= 4 %% of the non-transparent samples)")
+    ap.add_argument("--stop-schedule", default="auto", choices=["auto", "uniform"],
+                    help="slices of the front-to-back evaluation: auto = lengths chosen from the probe frame's statistics (longer slices where "
+                         "few rays end: fewer launches for a few more samples, same error bound; Renderer.stop_schedule), uniform = 4 / 8 samples")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="frames in flight (own scene / workspace each); 1 = strictly serial.  How they overlap: --overlap.  Measured "
                          "(profiles/r03_frames_in_flight.txt): 3 against 2 is -1.5 %% on the default frame, -2.6 %% on the converged set, 4 is no better")
@@ -371,7 +374,14 @@ def main():
             finite = cmax == cmax and cmax != float("inf")
             scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
             eps = _lib.early_stop_eps(S, scale)
+            schedule = None
+            if args.stop_schedule == "auto":
+                hist, L_uni = _lib.read_stop_hist(ws, R, S)
+                lens, ev, un = _lib.choose_stop_schedule(hist, L_uni, S)
+                if len(lens) < hist.shape[1]:
+                    schedule = lens
             stop_info = {"enabled": finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED),
+                         "slice_lengths": schedule if schedule is not None else f"uniform ({_lib.stop_slice_len(R, S)} samples)",
                          "probe_frame_would_skip_fraction_of_non_transparent": frac, "probe_frame_largest_colour": cmax,
                          "colour_scale": scale, "eps": eps, "bound_abs_for_colours_up_to_the_scale": (S + 1) * eps * scale,
                          "bound": "(S + 1) eps(S, c) x max|colour|: <= 5e-5 absolute while colours stay below the scale c = 2 x the probe "
@@ -381,9 +391,11 @@ def main():
             pk.early_stop = {"skipped_fraction": stop_info.get("probe_frame_would_skip_fraction_of_non_transparent", 0.0), "usable": True}
             no_screen = not pk.screen_pays(True)
         torch.cuda.synchronize()
-        return {"packed": pk, "no_screen": no_screen, "early": stop_info["enabled"], "screen_info": screen_info, "stop_info": stop_info}
+        return {"packed": pk, "no_screen": no_screen, "early": stop_info["enabled"], "screen_info": screen_info, "stop_info": stop_info,
+                "schedule": stop_info.get("slice_lengths") if isinstance(stop_info.get("slice_lengths"), list) else None}
 
     cur = prepare(sd)
+    headline_schedule = cur.get("schedule")
     packed, screen_info, stop_info, early = cur["packed"], cur["screen_info"], cur["stop_info"], cur["early"]
     args.no_screen = cur["no_screen"]      # (what the roofline pass below looks at)
     k_step = 0
@@ -402,7 +414,7 @@ def main():
         outs[j] = _lib.render_rays(scenes[j], cur["packed"], wss[j], ray_o, ray_d, nears[j], fars[j], S, t_vals, None, None,
                                    skip_transparent=not args.dense, want_weights=False, out=outs[j], fp32=args.fp32,
                                    screen=not cur["no_screen"], early_stop=cur["early"], phases=phases,
-                                   audit=audit_of.get(j, False), share_cus=share_cus[0])
+                                   audit=audit_of.get(j, False), share_cus=share_cus[0], stop_schedule=cur.get("schedule"))
 
     def exchange(j):
         if use_dist:
@@ -577,7 +589,7 @@ def main():
                                                "plain-fp16 screen (statistically safe: calibrated margin + audit), where its calibration lets it run")
     if rank == 0 and world == 1 and not args.no_roofline:
         scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)      # (the frame state of THESE parameters: by_weights has used the scene)
-        result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, early=early)
+        result["roofline"] = roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, early=early, schedule=headline_schedule)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(synth, canon, faces, xyz, poses, sd, rays, S, args)
     if rank == 0 and world == 1 and not args.no_extras and not (args.dense or args.fp32):
@@ -1165,7 +1177,7 @@ def eager_baseline(args, _lib, synth, dev, chunks=5, train=True):
     return res
 
 
-def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, early=False):
+def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, early=False, schedule=None):
     """Stage-by-stage pass over the same frame; the field kernels are timed with HIP events on the launch stream
     (torch's current stream IS the stream every dsn_* call is enqueued on).  The dominant kernel of the frame is
     k_field16<forward> (all non-transparent samples); k_field16<reverse> runs on the sigma > 0 subset."""
@@ -1283,11 +1295,12 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, ea
         # sum of samples x 0.918 MFLOP / sum of launch times = what the sliced forward achieves, launch tails included.
         ws2 = _lib.RenderWorkspace(dev)
         n2, f2 = near0.clone(), far0.clone()
-        _lib.render_rays(scene, packed, ws2, ray_o, ray_d, n2, f2, S, t_vals, None, None, want_weights=False, screen=screen, early_stop=True)
+        _lib.render_rays(scene, packed, ws2, ray_o, ray_d, n2, f2, S, t_vals, None, None, want_weights=False, screen=screen, early_stop=True,
+                         stop_schedule=schedule)
         torch.cuda.synchronize()
         cw = ws2.buf[:1024].view(torch.int32).cpu()
-        L_slice = 4 if N >= (1 << 22) else 8
-        K = (S + L_slice - 1) // L_slice
+        L_slice = _lib.stop_slice_len(R, S)
+        K = len(schedule) if schedule is not None else (S + L_slice - 1) // L_slice
         base = 128 if screen else 96                       # (DSN_CNT_KEEP_K / DSN_CNT_ALIVE_K: what the forward launch of slice k ran on)
         sizes = [int(cw[base + k]) if (k > 0 or screen) else int(cw[64]) for k in range(K)]
         del ws2
@@ -1315,7 +1328,7 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, ea
         traffic, traffic_src = measured_traffic("k_field16<forward>", args)
         out.update({"kernel": "k_field16<forward>, one launch per front-to-back slice (DSN_EARLY_STOP): per-launch averages of a frame",
                     "achieved": ach_sl, "frac": ach_sl / peak, "kernel_ms": ms_sl / K, "samples_per_launch": sum(sizes) / K,
-                    "launches_per_frame": K, "samples_per_slice": sizes, "samples_per_frame": sum(sizes), "sum_kernel_ms_per_frame": ms_sl,
+                    "launches_per_frame": K, "slice_lengths": schedule if schedule is not None else [L_slice] * K, "samples_per_slice": sizes, "samples_per_frame": sum(sizes), "sum_kernel_ms_per_frame": ms_sl,
                     "evaluated_fraction_of_non_transparent": sum(sizes) / max(1, n_all), "x_fp32_matrix_peak": ach_sl / PEAK_F32_MATRIX_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "single_launch_on_all_non_transparent_samples": single})
         out.pop("rocprof_kernel_ms", None); out.pop("rocprof_source", None); out.pop("frac_at_rocprof_kernel_ms", None)

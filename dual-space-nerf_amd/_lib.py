@@ -40,6 +40,7 @@ EXPORTS = [
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
     "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_record_capacity_fraction",
+    "dsn_render_rays_ex",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -52,6 +53,8 @@ EARLY_STOP, STOP_STATS = 64, 128
 PHASE_GEOMETRY, PHASE_FIELD, PHASE_SHADE = 256, 512, 1024      # dsn_render_rays: enqueue only these parts of the frame (0 = all)
 SHARE_CUS = 2048              # frames in flight: the persistent field kernels take 7/8 of the compute units (dsnerf.h)
 CNT_STOP = 56                 # [56] samples left out by ray termination, [57] samples not shaded, [58] STOP_STATS: what early stop would leave out
+CNT_BYTES = 8192              # bytes of the workspace's count area (256 diagnostic words + the slice histogram of STOP_STATS from word 256)
+CNT_HIST = 256
 CNT_COLOUR_MAX = 59           # largest |colour| the compositor of an eval frame weighed (float bits): the scale of the early-stop bound
 EARLY_STOP_COLOUR_HEADROOM = 2.0   # the colour scale handed to the library = this x the largest colour seen so far (Renderer / bench.py)
 EARLY_STOP_MIN_SKIPPED = 0.04  # Renderer / bench.py: share of the non-transparent samples early stop must leave out before the slicing pays (it costs ~0.5 ms = 3 % of a 512 x 512 x 64 frame when it leaves out nothing)
@@ -609,7 +612,7 @@ class RenderWorkspace:
 def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, ray_d, near, far, S, t_vals,
                 jitter=None, noise=None, skip_transparent=True, want_weights=True, out=None, exhaustive=False,
                 fp32=False, uniform=False, screen=False, train_cache=None, audit=False, early_stop=False, stop_stats=False, phases=0,
-                share_cus=False):
+                share_cus=False, stop_schedule=None):
     """Whole hot path on R rays (can_render.py:137-168).  Returns dict of device tensors.
     phases: 0 = the whole frame; PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE = only those parts, on the current stream (the caller
     orders the three calls of a frame with its own events and passes the same `out` / workspace to all of them: PhasePipeline).
@@ -657,11 +660,16 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                            _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _ptr(gbuf), _stream()),
                "dsn_render_rays_train")
         return out
-    _check(lib().dsn_render_rays(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
-                                 _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
-                                 _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
-                                 _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
-                                 _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _stream()),
+    # stop_schedule (early_stop only): slice lengths chosen from a probe frame's statistics (choose_stop_schedule); None = uniform slices
+    sched, n_sched = None, 0
+    if stop_schedule is not None and (flags & EARLY_STOP):
+        n_sched = len(stop_schedule)
+        sched = (C.c_int32 * n_sched)(*[int(x) for x in stop_schedule])
+    _check(lib().dsn_render_rays_ex(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
+                                    _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
+                                    _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
+                                    _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
+                                    _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), sched, n_sched, _stream()),
            "dsn_render_rays")
     return out
 
@@ -726,6 +734,57 @@ def early_stop_eps(S: int, colour_scale: float = 1.0) -> float:
     min(2^-20, 1e-4 / (2 (S + 1) max(1, colour_scale))) - the frame stays within (S + 1) eps x the largest colour of the one-pass
     frame (include/dsnerf.h), i.e. within 5e-5 absolute while the colours stay below the scale"""
     return float(lib().dsn_early_stop_eps_scaled(int(S), C.c_float(colour_scale)))
+
+
+def stop_slice_len(R: int, S: int) -> int:
+    """samples per uniform slice of DSN_EARLY_STOP (= dsn_slice_len of csrc/dsn_api.hip without its experiment override)"""
+    L = 4 if R * S >= (1 << 22) else 8
+    return L if (S + L - 1) // L <= 32 else (S + 31) // 32
+
+
+def read_stop_hist(ws, R: int, S: int):
+    """(synchronises) the slice histogram a DSN_STOP_STATS frame left: numpy int64 [K + 1, K], hist[g][k] = non-transparent samples of
+    uniform slice k on rays whose first slice with T < eps at its start is g (g = K: never)"""
+    import numpy as np
+    buf = ws if isinstance(ws, torch.Tensor) else ws.buf
+    L = stop_slice_len(R, S)
+    K = (S + L - 1) // L
+    c = buf[4 * CNT_HIST:4 * CNT_HIST + 4 * (K + 1) * K].view(torch.int32).cpu().numpy().astype(np.int64)
+    return c.reshape(K + 1, K), L
+
+
+def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 32768, launch_rounds: float = 0.9):
+    """Slice lengths for dsn_render_rays_ex from a probe frame's histogram (read_stop_hist).  A slice that starts at uniform slice a
+    and covers slices a .. b evaluates sum_k M[a][k], M[a][k] = samples of slice k on rays still alive at the start of a (sum over
+    g > a of hist[g][k]); every slice also costs about `launch_rounds` of a round of the chip (the half-empty last round of its forward
+    launch, the list filter and transmittance launches in front of it; a round = round_samples samples: 128 per workgroup).  Dynamic
+    programming over the slice borders minimises samples + launch_rounds x round_samples x slices; slices stay within 64 samples.
+    Returns (list of lengths in samples, evaluated samples it predicts, evaluated samples of the uniform schedule)."""
+    import numpy as np
+    hist = np.asarray(hist, np.int64)
+    K = hist.shape[1]
+    M = np.zeros((K, K), np.int64)                       # M[a][k]: alive at the start of slice a
+    for a in range(K):
+        M[a] = hist[a + 1:].sum(0)
+    ov = float(launch_rounds) * float(round_samples)
+    best = [0.0] + [float("inf")] * K
+    prev = [0] * (K + 1)
+    for b in range(1, K + 1):
+        for a in range(max(0, b - 64 // max(L, 1)), b):
+            if (min(b * L, S) - a * L) > 64:
+                continue
+            c = best[a] + ov + float(M[a][a:b].sum())
+            if c < best[b]:
+                best[b], prev[b] = c, a
+    cuts, b = [], K
+    while b > 0:
+        cuts.append((prev[b], b))
+        b = prev[b]
+    cuts.reverse()
+    lens = [min(b * L, S) - a * L for a, b in cuts]
+    evaluated = int(sum(M[a][a:b].sum() for a, b in cuts))
+    uniform = int(sum(M[k][k] for k in range(K)))
+    return lens, evaluated, uniform
 
 
 def read_stop_stats(ws):

@@ -198,6 +198,9 @@ class Renderer:
         self.early_stop = "auto"
         self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
         self._colour_probe = None         # (packed generation, count words, event) of a sliced frame whose colour maximum is still to be read
+        # "auto": the slice lengths of sliced frames follow the probe frame's statistics (longer slices where few rays end: fewer
+        # launches, a few more samples, the same error bound - dsn_render_rays_ex); None: uniform slices of 4 / 8 samples
+        self.stop_schedule = "auto"
         self._stop_frames = 0
         # render_view / render_views: torch's intra-op pool is capped at this many threads while a frame is staged, enqueued and
         # awaited (_HostPoolGuard; None = leave the pool alone); and for good at the cgroup's CPU quota (_lib.fit_host_pool: a pool
@@ -518,8 +521,11 @@ class Renderer:
                 self._audit_frames += 1
             else:
                 audit = bool(self.screen_audit)
+        sched = packed.early_stop.get("schedule") if (stop and packed.early_stop and self.stop_schedule == "auto") else None
+        if sched is not None and sum(sched) != int(self.cfg.MODEL.COARSE_RAY_SAMPLING):
+            sched = None
         return {"skip_transparent": skip, "uniform": (self.sample_points_mode == "uniform"), "screen": screen,
-                "audit": audit, "early_stop": stop, "stop_stats": stats}
+                "audit": audit, "early_stop": stop, "stop_stats": stats, "stop_schedule": sched}
 
     def _render_eval(self, scene, ws, o, d, near, far, S, jitter, noise, screen=None, plan=None, phases=0, out=None):
         packed = self.net.packed(self.device)
@@ -528,7 +534,7 @@ class Renderer:
             # First eval frame of a parameter version: its geometry phase first (sampler, warp: the canonical points of its
             # non-transparent samples), the density screen's margin calibrated on THOSE points, then the rest of the frame.
             geo = {"skip_transparent": True, "uniform": (self.sample_points_mode == "uniform"), "screen": True, "audit": False,
-                   "early_stop": False, "stop_stats": False}
+                   "early_stop": False, "stop_stats": False, "stop_schedule": None}
             out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, self._t_vals(S), jitter, noise, phases=_lib.PHASE_GEOMETRY,
                                    out=out, **geo)
             self._screen_usable(frame=(scene, ws, o.shape[0], S))
@@ -538,7 +544,7 @@ class Renderer:
         # bit-identical - a caller can see per frame whether it was in use and with which threshold)
         cs = packed.colour_scale
         self.last_frame_info = {"density_screen": bool(plan["screen"]), "screen_audit": bool(plan["audit"]),
-                                "early_stop": bool(plan["early_stop"]),
+                                "early_stop": bool(plan["early_stop"]), "early_stop_schedule": plan.get("stop_schedule"),
                                 "early_stop_eps": _lib.early_stop_eps(S, cs) if plan["early_stop"] else None,
                                 "early_stop_colour_scale": cs if plan["early_stop"] else None,
                                 "early_stop_bound_x_max_colour": (S + 1) * _lib.early_stop_eps(S, cs) if plan["early_stop"] else 0.0,
@@ -548,7 +554,8 @@ class Renderer:
                                share_cus=getattr(self, "_frames_overlap", False), **plan)
         if plan["stop_stats"] and (phases == 0 or phases & _lib.PHASE_SHADE):
             self._probe_samples = int(o.shape[0]) * int(S)
-            snap = ws.buf[:256].clone()      # (stream-ordered: the next frame on this workspace clears the words)
+            self._probe_shape = (int(o.shape[0]), int(S))
+            snap = ws.buf[:_lib.CNT_BYTES].clone()      # (stream-ordered: the next frame on this workspace clears the words)
             ev = torch.cuda.Event()
             ev.record()
             self._stop_probe = (packed.generation, snap, ev)
@@ -611,6 +618,13 @@ class Renderer:
         self._note_colour_max(packed, st["colour_max"], first=True)
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
+        # the slice schedule of the frames to come (longer slices where few rays end: dsn_render_rays_ex), from the probe frame's histogram
+        R_, S_ = getattr(self, "_probe_shape", (0, 0))
+        if self.stop_schedule == "auto" and R_ > 0 and snap.numel() >= _lib.CNT_BYTES:
+            hist, L = _lib.read_stop_hist(snap, R_, S_)
+            lens, ev, un = _lib.choose_stop_schedule(hist, L, S_)
+            if len(lens) < hist.shape[1]:
+                packed.early_stop.update({"schedule": lens, "schedule_evaluates": ev, "uniform_evaluates": un})
 
     def _note_colour_max(self, packed, cmax, first=False):
         """the early-stop threshold's colour scale follows the largest colour seen: scale = 2 x that (never below 1, never lowered)"""

@@ -778,12 +778,22 @@ void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t
 // counters costs ~15 ns each: 9 ms for the 8-way split of a 6.6 M-entry list).
 #define DSN_AGG_PER_THREAD 8
 #define DSN_AGG_ITEMS (256 * DSN_AGG_PER_THREAD)
-// the active list split by slice: slice k = samples [k L, (k+1) L) of every ray -> lists + k * cap, counts[k]   (K <= 32)
+// The slices of a frame: slice k = samples [b[k], b[k + 1]) of every ray, K <= 32 slices.  Uniform (b[k] = k L) by default; a caller that
+// has the statistics of a probe frame passes its own lengths (dsn_render_rays_ex: longer slices where few rays end, see dsnerf.h).
+struct DsnSliceBounds { int K; int b[DSN_STOP_MAX_SLICES + 1]; };
+__device__ __forceinline__ int dsn_slice_of(const DsnSliceBounds& sb, int i) {
+    int k = 0;
+#pragma unroll 4
+    for (int q = 1; q < sb.K; ++q) k += i >= sb.b[q] ? 1 : 0;
+    return k;
+}
+// the active list split by slice -> lists + R * b[k] (slice k holds at most R * (b[k + 1] - b[k]) entries), counts[k]
 __global__ void __launch_bounds__(256) k_slice_bucket(const int32_t* __restrict__ active, const int32_t* __restrict__ active_count, int S,
-                                                       int L, int K, int64_t cap, int32_t* __restrict__ lists,
+                                                       DsnSliceBounds sb, int64_t R, int32_t* __restrict__ lists,
                                                        int32_t* __restrict__ counts) {
     __shared__ int s_cnt[32], s_base[32];
     const int n = *active_count;
+    const int K = sb.K;
     for (int64_t base = (int64_t)blockIdx.x * DSN_AGG_ITEMS; base < n; base += (int64_t)gridDim.x * DSN_AGG_ITEMS) {
         if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(256) k_slice_bucket(const int32_t* __restrict_
             kk[j] = -1;
             if (i < n) {
                 idx[j] = active[i];
-                kk[j] = (idx[j] % S) / L;
+                kk[j] = dsn_slice_of(sb, idx[j] % S);
                 off[j] = atomicAdd(&s_cnt[kk[j]], 1);
             }
         }
@@ -804,7 +814,7 @@ __global__ void __launch_bounds__(256) k_slice_bucket(const int32_t* __restrict_
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < DSN_AGG_PER_THREAD; ++j)
-            if (kk[j] >= 0) lists[(int64_t)kk[j] * cap + s_base[kk[j]] + off[j]] = idx[j];
+            if (kk[j] >= 0) lists[R * (int64_t)sb.b[kk[j]] + s_base[kk[j]] + off[j]] = idx[j];
         __syncthreads();
     }
 }
@@ -932,7 +942,7 @@ __global__ void __launch_bounds__(256) k_slice_alive(const int32_t* __restrict__
 template <int G>
 __global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                     const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
-                                                    int L, int k, unsigned long long* __restrict__ Tk) {
+                                                    int s0, int s1, int k, unsigned long long* __restrict__ Tk) {
     const int64_t gl = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gl / G;
     const int j = (int)(gl % G);
@@ -942,8 +952,7 @@ __global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sig
     float T = __uint_as_float((uint32_t)pr);
     const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
     const float dn = dsn_norm3(d);
-    // (rays the filter has kept current are one slice behind; a ray is never further behind here, every ray is advanced every slice)
-    const int s0 = (k - 1) * L, s1 = k * L < S ? k * L : S;
+    // (every ray is advanced every slice: a ray is exactly one slice behind here)
     const int i = s0 + j;
     float fac = 1.0f;
     if (i < s1) {
@@ -961,16 +970,18 @@ __global__ void __launch_bounds__(256) k_advance_T(const float* __restrict__ sig
     for (int q = 0; q < G; ++q) P *= __shfl(fac, (int)((threadIdx.x & 63) - j + q));
     if (j == 0 && kd < k) Tk[r] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)__float_as_uint(T * P);
 }
-void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                          int k, void* Tk, hipStream_t st) {
+// T of every ray over slice k - 1 = samples [s0, s1) (at most 64)
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
+                          int s1, int k, void* Tk, hipStream_t st) {
+    const int n = s1 - s0;
 #define DSN_ADV(G) hipLaunchKernelGGL(k_advance_T<G>, dim3((unsigned)(((int64_t)R * G + 255) / 256)), dim3(256), 0, st, sigma, transparent, \
-                                      z_vals, ray_d, R, S, L, k, (unsigned long long*)Tk)
-    if (L <= 1) DSN_ADV(1);
-    else if (L <= 2) DSN_ADV(2);
-    else if (L <= 4) DSN_ADV(4);
-    else if (L <= 8) DSN_ADV(8);
-    else if (L <= 16) DSN_ADV(16);
-    else if (L <= 32) DSN_ADV(32);
+                                      z_vals, ray_d, R, S, s0, s1, k, (unsigned long long*)Tk)
+    if (n <= 1) DSN_ADV(1);
+    else if (n <= 2) DSN_ADV(2);
+    else if (n <= 4) DSN_ADV(4);
+    else if (n <= 8) DSN_ADV(8);
+    else if (n <= 16) DSN_ADV(16);
+    else if (n <= 32) DSN_ADV(32);
     else DSN_ADV(64);
 #undef DSN_ADV
 }
@@ -1034,10 +1045,21 @@ __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ po
     }
 }
 // statistics for the host's decision (DSN_STOP_STATS, a frame rendered WITHOUT early stop): out[0] += the non-transparent samples
-// that lie in a slice whose ray had T < eps when the slice began - what DSN_EARLY_STOP would have left out
+// that lie in a slice whose ray had T < eps when the slice began - what DSN_EARLY_STOP would have left out with uniform slices of L.
+// hist (optional, [K][K] ints, K = ceil(S / L) <= 32, zeroed by the caller): hist[g][k] += the non-transparent samples of slice k on rays
+// whose first slice with T < eps at its start is g (g = K: never) - from it the host prices ANY grouping of the slices (a group that
+// starts at slice a evaluates slice k >= a on the rays with g > a) and picks the schedule of dsn_render_rays_ex.  Row K is stored as row
+// g = K - 1 + 1 -> the array has K + 1 rows.
 __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                      const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
-                                                     int L, const float* __restrict__ scal, int32_t* __restrict__ out) {
+                                                     int L, const float* __restrict__ scal, int32_t* __restrict__ out,
+                                                     int32_t* __restrict__ hist) {
+    __shared__ int s_h[(DSN_STOP_MAX_SLICES + 1) * DSN_STOP_MAX_SLICES];
+    const int K = (S + L - 1) / L;
+    if (hist) {
+        for (int i = threadIdx.x; i < (K + 1) * K; i += 256) s_h[i] = 0;
+        __syncthreads();
+    }
     const int r = blockIdx.x * 256 + threadIdx.x;
     const float eps = dsn_stop_eps_scaled(S, scal[6]);
     int skipped = 0;
@@ -1048,8 +1070,10 @@ __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ si
         const int64_t g0 = (int64_t)r * S;
         float z = z_vals[g0];
         bool dead = false;
+        int gstar = K;                     // first slice that finds the ray finished at its start
+        unsigned long long nt_lo = 0, nt_hi = 0;      // non-transparent samples per slice, 4 bits each would overflow at L > 15: counted below
         for (int i = 0; i < S; ++i) {
-            if (i % L == 0) dead = t < eps;
+            if (i % L == 0) { dead = t < eps; if (dead && gstar == K) gstar = i / L; }
             const bool tr = transparent && transparent[g0 + i];
             if (dead && !tr) ++skipped;
             const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
@@ -1059,15 +1083,30 @@ __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ si
             t = t * ((1.0f - (1.0f - expf(-s * dist))) + 1e-10f);
             z = zn;
         }
+        (void)nt_lo; (void)nt_hi;
+        if (hist) {
+            for (int k = 0; k < K; ++k) {
+                int c = 0;
+                for (int i = k * L; i < (k + 1) * L && i < S; ++i) c += (transparent && transparent[g0 + i]) ? 0 : 1;
+                if (c) atomicAdd(&s_h[gstar * K + k], c);
+            }
+        }
     }
     for (int off = 32; off >= 1; off >>= 1) skipped += __shfl_xor(skipped, off);
     if ((threadIdx.x & 63) == 0 && skipped) atomicAdd(out, skipped);
+    if (hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (K + 1) * K; i += 256) if (s_h[i]) atomicAdd(hist + i, s_h[i]);
+    }
 }
 
-void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int L, int K, int64_t cap,
+void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int R, const int* bounds, int K,
                              int32_t* lists, int32_t* counts, hipStream_t st) {
+    DsnSliceBounds sb;
+    sb.K = K;
+    for (int k = 0; k <= DSN_STOP_MAX_SLICES; ++k) sb.b[k] = k <= K ? bounds[k] : S;
     const int64_t blocks = std::min<int64_t>((N + DSN_AGG_ITEMS - 1) / DSN_AGG_ITEMS, 2048);
-    hipLaunchKernelGGL(k_slice_bucket, dim3((unsigned)blocks), dim3(256), 0, st, active, active_count, S, L, K, cap, lists, counts);
+    hipLaunchKernelGGL(k_slice_bucket, dim3((unsigned)blocks), dim3(256), 0, st, active, active_count, S, sb, (int64_t)R, lists, counts);
 }
 void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N, int S, int L, int k, void* Tk, const float* sigma,
                             const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
@@ -1097,8 +1136,8 @@ void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N
                        lit_count, culled, colour);
 }
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           const float* packed_scal, int32_t* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out);
+                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist) {
+    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out, hist);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -146,7 +146,9 @@ void dsn_launch_image_scatter(const float* rgb, const float* disp, const float* 
 void dsn_launch_image_psnr(const float* img_rgb, const double* gt64, const float* gt32, const uint8_t* mask, int H, int W,
                            double* out4, void* workspace, hipStream_t st);
 // front-to-back slices with exact ray termination (dsn_geom.hip; DSN_EARLY_STOP in dsn_render_rays)
-void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int L, int K, int64_t cap,
+#define DSN_STOP_MAX_SLICES 32
+// bounds[0 .. K]: slice k = samples [bounds[k], bounds[k + 1]) of every ray; its list starts at lists + R * bounds[k]
+void dsn_launch_slice_bucket(const int32_t* active, const int32_t* active_count, int64_t N, int S, int R, const int* bounds, int K,
                              int32_t* lists, int32_t* counts, hipStream_t st);
 // slice k >= 1: advances the rays' transmittance over the slices their pair does not cover yet and keeps the samples of live rays
 // (Tk: [R] x 8 bytes, dsn_launch_slice_T_init; packed_scal = packed + OFF_SCAL: the threshold's colour scale lives there)
@@ -154,12 +156,12 @@ void dsn_launch_slice_alive(const int32_t* list, const int32_t* count, int64_t N
                             const uint8_t* transparent, const float* z_vals, const float* ray_d, const float* packed_scal, int32_t* out,
                             int32_t* out_count, int32_t* stopped, hipStream_t st, bool pairs_current = false);
 // the per-ray form of the advance (one coalesced pass over slice k - 1 of every ray; dsn_launch_slice_alive(..., pairs_current = true) behind it)
-void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                          int k, void* Tk, hipStream_t st);
+void dsn_launch_advance_T(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int s0,
+                          int s1, int k, void* Tk, hipStream_t st);
 void dsn_launch_slice_T_init(void* Tk, int R, hipStream_t st);
 void dsn_launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N, int64_t rec_cap, const float* weight,
                          const float* sigma, int S, const float* packed_scal, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count,
                          int32_t* culled, float* colour, hipStream_t st);
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           const float* packed_scal, int32_t* out, hipStream_t st);
+                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist = nullptr);

@@ -348,6 +348,19 @@ DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* pack
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
                     float* out_weights, float* out_z, void* workspace, void* stream);
+/* The same with a SCHEDULE for DSN_EARLY_STOP: slice_lengths_host[0 .. n_slices) (host array, 1 .. 64 samples each, at most 32 slices,
+ * adding up to S) instead of uniform slices of 4 / 8 samples.  A slice costs a launch of every field kernel whatever it holds (a
+ * 512 x 512 frame's late slices hold 40-90 k samples, one to three rounds of the chip's 32 k-sample capacity), so where few rays end a
+ * longer slice is cheaper than two short ones; termination is then checked less often there, i.e. MORE samples are evaluated: the
+ * error bound of DSN_EARLY_STOP is unchanged.  The statistics to choose from: a DSN_STOP_STATS frame leaves, from int32 word 256 of
+ * `workspace`, hist[g][k] (g = 0 .. K, k = 0 .. K - 1, K = ceil(S / L) uniform slices) = non-transparent samples of slice k on rays whose
+ * first slice with T < eps at its start is g (g = K: never) - a group of slices that starts at slice a evaluates slice k >= a on the
+ * rays with g > a.  NULL / 0 = uniform slices = dsn_render_rays.  (The host mirror picks the schedule by dynamic programming over
+ * that histogram: _lib.choose_stop_schedule.) */
+DSN_EXPORT int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                       float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
+                       int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
+                       float* out_weights, float* out_z, void* workspace, const int32_t* slice_lengths_host, int n_slices, void* stream);
 
 /* diagnostics, NOT for the hot path (synchronises `stream`): {ncell, ok, total entries, capacity} of the four
  * nearest-face list levels (world fine/coarse, canonical fine/coarse) into a HOST array of 16 int32. */

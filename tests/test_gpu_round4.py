@@ -132,13 +132,13 @@ def test_frame_calibration_needs_a_list_and_folds_the_cube_in():
     _lib.render_rays(w3.scene, pk3, ws3, o, d, n.clone(), f.clone(), S, w3._t_vals(S), phases=_lib.PHASE_GEOMETRY)
     torch.cuda.synchronize()
     N = o.shape[0] * S
-    act0 = ws3.buf[1024:1024 + 4 * N].view(torch.int32).clone()
+    act0 = ws3.buf[_lib.CNT_BYTES:_lib.CNT_BYTES + 4 * N].view(torch.int32).clone()
     c0 = int(ws3.buf[:4].view(torch.int32)[0])
     _lib.render_rays(w3.scene, pk3, ws3, o, d, n.clone(), f.clone(), S, w3._t_vals(S), early_stop=True, screen=False)
     torch.cuda.synchronize()
     assert _lib.read_stop_stats(ws3)["skipped"] > 0
     assert int(ws3.buf[:4].view(torch.int32)[0]) == c0 == cnt      # (same rays, same mesh: the same geometry)
-    act1 = ws3.buf[1024:1024 + 4 * N].view(torch.int32)
+    act1 = ws3.buf[_lib.CNT_BYTES:_lib.CNT_BYTES + 4 * N].view(torch.int32)
     assert torch.equal(torch.sort(act0[:c0]).values, torch.sort(act1[:c0]).values)
 
 
@@ -299,3 +299,51 @@ def test_density_screen_is_opt_in():
     assert 0 < int(c2[_lib.CNT_KEEP]) < int(c2[_lib.CNT_ACTIVE])
     for k in a:
         assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
+
+
+def test_stop_schedule_from_the_probe_frame():
+    """dsn_render_rays_ex: slice lengths chosen from a probe frame's histogram (longer slices where few rays end).  The histogram is
+    consistent with the scalar statistic; the chosen schedule has fewer slices, evaluates what the histogram predicts (within the
+    borderline rays) and a little more than the uniform schedule; the frame stays within the early-stop bound of the one-pass frame;
+    a schedule that does not add up to S is refused."""
+    from dsnerf_amd import _lib
+    S = 64
+    run = _stop_pair(state("x_w4"), hw=256, S=S, screen=False)
+    r = run.renderer
+    ref, st0, ws0 = run(stop_stats=True)
+    R = ref["color"].shape[0]
+    hist, L = _lib.read_stop_hist(ws0, R, S)
+    K = hist.shape[1]
+    assert hist.shape == (K + 1, K) and L == _lib.stop_slice_len(R, S)
+    assert int(hist.sum()) == st0["active"]                               # every non-transparent sample is in exactly one bin
+    dead = sum(int(hist[g][k]) for g in range(K + 1) for k in range(K) if k >= g)
+    assert dead == st0["would_skip"]                                      # samples of slices at / behind the ray's first dead slice
+    lens, ev, un = _lib.choose_stop_schedule(hist, L, S)
+    assert sum(lens) == S and all(1 <= x <= 64 for x in lens) and len(lens) < K
+    assert un == st0["active"] - st0["would_skip"] and un <= ev <= 1.15 * un
+    uni, st_u, _ = run(early_stop=True)
+    got, st_s, ws_s = run(early_stop=True, stop_schedule=lens)
+    evaluated = st_s["active"] - st_s["skipped"]
+    assert abs(evaluated - ev) <= 0.005 * ev + 64, (evaluated, ev)
+    assert st_s["skipped"] <= st_u["skipped"]
+    eps = _lib.early_stop_eps(S, r.net.packed(r.device).colour_scale)
+    cmax = max(1.0, float(ref["color"].abs().max()))
+    for out in (uni, got):
+        assert float((ref["color"] - out["color"]).abs().max()) <= (S + 1) * eps * cmax + 2e-6 * cmax
+        assert float((ref["acc_map"] - out["acc_map"]).abs().max()) <= 2 * eps
+        assert float((ref["weights"] - out["weights"]).abs().max()) <= eps
+    with pytest.raises(RuntimeError, match="add up to S"):
+        run(early_stop=True, stop_schedule=[4] * 15)
+    with pytest.raises(RuntimeError, match="1 to 64"):
+        run(early_stop=True, stop_schedule=[0] + [4] * 16)
+    # the Renderer picks a schedule by itself from its probe frame and reports it
+    canon, faces, batch = full_frame(hw=256)
+    rr = renderer_with(state("x_w4"), canon, faces, density_screen=False)
+    rr.eval()
+    a = rr.render_view(batch, device_output=True)
+    rr._read_stop_probe(wait=True)
+    info = rr.net.packed(rr.device).early_stop
+    assert info["usable"] and sum(info["schedule"]) == S and len(info["schedule"]) < K
+    b = rr.render_view(batch, device_output=True)
+    assert rr.last_frame_info["early_stop"] and rr.last_frame_info["early_stop_schedule"] == info["schedule"]
+    assert float((a["coarse_color"] - b["coarse_color"]).abs().max()) < 1e-4
