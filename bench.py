@@ -534,6 +534,10 @@ def main():
         # The frame time is a property of the CHECKPOINT as much as of the kernels: the same frame, same pipeline,
         # 5 timed frames each, for every parameter set the repo pins with reference-generated goldens.  w4 is the converged one.
         headline = cur
+        # (the headline's own counters, before the other parameter sets reuse the workspaces)
+        headline_cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
+        headline_st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
+        headline_ws_gb = _lib.lib().dsn_render_workspace_bytes(R, S) / 1e9
         by = {}
         share_cus[0] = depth > 1 and os.environ.get("DSN_BENCH_SHARE_CUS", "1") != "0"      # (frames in flight again)
 
@@ -559,8 +563,11 @@ def main():
             else:
                 c = prepare(load_weights(synth, name), want_screen=False)
                 by[name] = {"ms_per_frame": timed_frames(c), "frames": 5}
-            cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
-            st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
+            if name == args.weights:
+                cw, st = headline_cw, headline_st
+            else:
+                cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
+                st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
             by[name].update({
                 "rays_per_s": R / (by[name]["ms_per_frame"] * 1e-3),
                 "density_screen": not c["no_screen"],
@@ -622,6 +629,8 @@ def main():
         # 3072-ray chunks, can_render.py:172-245) needs a quarter of it, for this much time
         chunk = (H * W) // 4
         ex["chunked_frame"] = {"chunk_rays": chunk,
+                               "workspace_gb_whole_frame_headline": headline_ws_gb,      # (at the record fraction the headline's probe frame left)
+                               "record_capacity_fraction_now": _lib.record_capacity_fraction(),      # (process-wide, grown by the densest set of by_weights)
                                "workspace_gb_whole_frame": _lib.lib().dsn_render_workspace_bytes(H * W, S) / 1e9,
                                "workspace_gb_chunked": _lib.lib().dsn_render_workspace_bytes(chunk, S) / 1e9,
                                "host_to_host_ms": host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
@@ -648,6 +657,40 @@ def main():
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps(result), flush=True)      # the LAST line of stdout (RCCL prints its banner at its first collective)
+
+
+def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, screen, reduce_max=None):
+    """Front-to-back slicing for the secondary modes, decided like Renderer / the headline loop do: one probe render (one pass,
+    DSN_STOP_STATS) of these rays says what termination would leave out, how large the colours are (-> the threshold's colour scale)
+    and how the slices should be cut (choose_stop_schedule).  reduce_max(tensor): all-reduce MAX over the ranks of a multi-GPU run, so
+    that every rank takes the same decision and threshold.  Returns (enabled, schedule | None, info dict)."""
+    if args.early_stop == "off" or args.dense or args.fp32:
+        return False, None, {"enabled": False}
+    R = o.shape[0]
+    _lib.render_rays(scene, packed, ws, o, d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False, screen=screen,
+                     stop_stats=True)
+    torch.cuda.synchronize()
+    st = _lib.read_stop_stats(ws)
+    frac = st["would_skip"] / max(st["active"], 1)
+    cmax = st["colour_max"]
+    finite = cmax == cmax and cmax != float("inf")
+    if reduce_max is not None:
+        t_ = torch.tensor([frac, cmax if finite else float("inf")], dtype=torch.float64, device=o.device)
+        reduce_max(t_)
+        frac, cmax = float(t_[0]), float(t_[1])
+        finite = cmax != float("inf")
+    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S))
+    scale = packed.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
+    schedule = None
+    if args.stop_schedule == "auto" and reduce_max is None:      # (a multi-rank run keeps uniform slices: one schedule for all ranks)
+        hist, L_uni = _lib.read_stop_hist(ws, R, S)
+        lens, _, _ = _lib.choose_stop_schedule(hist, L_uni, S)
+        if len(lens) < hist.shape[1]:
+            schedule = lens
+    enabled = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
+    return enabled, (schedule if enabled else None), {
+        "enabled": enabled, "probe_would_skip_fraction_of_non_transparent": frac, "probe_largest_colour": cmax, "colour_scale": scale,
+        "eps": _lib.early_stop_eps(S, scale), "slice_lengths": schedule if schedule is not None else f"uniform ({_lib.stop_slice_len(R, S)} samples)"}
 
 
 def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S, caller_torch_op=False, chunk=None):
@@ -733,24 +776,8 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
     near, far = near0.clone(), far0.clone()
     # front-to-back slices with ray termination: decided like Renderer does, from the statistics of one probe render of this rank's
     # share, which also measures the colour scale of the threshold (set-up, not a step)
-    stop_info = {"enabled": False}
-    if args.early_stop != "off":
-        _lib.render_rays(scene, packed, ws, o, d, near0.clone(), far0.clone(), S, t_vals, None, None, want_weights=False,
-                         screen=info["usable"], stop_stats=True)
-        torch.cuda.synchronize()
-        st = _lib.read_stop_stats(ws)
-        frac = st["would_skip"] / max(st["active"], 1)
-        cmax = st["colour_max"]
-        finite = cmax == cmax and cmax != float("inf")
-        if use_dist:      # one decision and one colour scale for the whole frame: the ranks' shares are dealt from the same image
-            t_ = torch.tensor([frac, cmax if finite else float("inf")], dtype=torch.float64, device=dev)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            frac, cmax = float(t_[0]), float(t_[1])
-            finite = cmax != float("inf")
-        scale = packed.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
-        stop_info = {"enabled": finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED),
-                     "probe_would_skip_fraction_of_non_transparent": frac, "probe_largest_colour": cmax, "colour_scale": scale,
-                     "eps": _lib.early_stop_eps(S, scale)}
+    stop_on, schedule, stop_info = stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, info["usable"],
+                                              reduce_max=(lambda t_: dist.all_reduce(t_, op=dist.ReduceOp.MAX)) if use_dist else None)
     px = torch.zeros(slab, 6, dtype=torch.float32, device=dev)
     allp = torch.empty(world * slab, 6, dtype=torch.float32, device=dev)
     full = torch.empty(R, 6, dtype=torch.float32, device=dev)
@@ -762,7 +789,7 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
         far.copy_(far0)
         scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
         out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
-                               screen=info["usable"], early_stop=stop_info["enabled"])
+                               screen=info["usable"], early_stop=stop_on, stop_schedule=schedule)
         px[:Rl, 0:3] = out["color"]
         px[:Rl, 3] = out["disp_map"]
         px[:Rl, 4] = out["acc_map"]
@@ -845,6 +872,9 @@ def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
             info = packed.calibrate_screen(scenes[0], frame=(wss[0], R, S)) if args.screen else {"usable": False, "note": "density screen not opted in"}
             screen = bool(info["usable"])
         nears, fars, outs = [near0.clone() for _ in range(depth)], [far0.clone() for _ in range(depth)], [None] * depth
+        # (every rank of the real run probes its own frame: early stop, colour scale and slice schedule per emulated rank)
+        scenes[0].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
+        stop_on, schedule, stop_info = stop_setup(_lib, args, scenes[0], packed, wss[0], o, d, near0, far0, S, t_vals, screen)
 
         def step(k):
             j = k % depth
@@ -853,7 +883,7 @@ def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
                 fars[j].copy_(far0)
                 scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
                 outs[j] = _lib.render_rays(scenes[j], packed, wss[j], o, d, nears[j], fars[j], S, t_vals, want_weights=False, out=outs[j],
-                                           screen=screen)
+                                           screen=screen, early_stop=stop_on, stop_schedule=schedule, share_cus=depth > 1)
 
         for k in range(args.warmup):
             step(k)
@@ -865,7 +895,7 @@ def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
         ms = 1e3 * (time.perf_counter() - t0) / args.steps
         cnt = wss[(args.steps - 1) % depth].buf[:256].view(torch.int32).cpu()
         ranks.append({"rank": r_, "ms_per_frame": ms, "non_transparent": int(cnt[_lib.CNT_ACTIVE]), "accurate_pass": int(cnt[_lib.CNT_KEEP]),
-                      "positive_density": int(cnt[_lib.CNT_POS])})
+                      "positive_density": int(cnt[_lib.CNT_POS]), "early_stop": stop_info})
     t = np.array([x["ms_per_frame"] for x in ranks])
     ag_ms = 0.03 + 1e3 * (24.0 * R * (Nw - 1)) / ((Nw - 1) * 153e9)      # every rank receives N - 1 slabs of 24 B x R over its N - 1 links
     res = {"metric": f"weak-scaling load balance: the {Nw} ranks' frames ({H}x{W} x {S} samples/ray) rendered one after the other on ONE GPU",
@@ -911,6 +941,10 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
     scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None)
     # (the centroid cube: the shares are rendered with one margin, whichever rank calibrates)
     info = packed.calibrate_screen(scene) if args.screen else {"usable": False, "note": "density screen not opted in (--screen)"}
+    # (one decision for the frame, as the ranks of the real run agree on by all-reduce: probe on the whole frame; uniform slices)
+    whole = rp.tile_indices(R, tile, 0, 1).numpy()
+    stop_on, _, stop_info = stop_setup(_lib, args, scene, packed, ws, T(rays["ray_o"][whole]), T(rays["ray_d"][whole]), T(rays["near"][whole]),
+                                       T(rays["far"][whole]), S, t_vals, info["usable"], reduce_max=lambda t_: None)
 
     def time_share(idx):
         mine = idx.numpy()
@@ -927,7 +961,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
             far.copy_(far0)
             scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
             out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
-                                   screen=info["usable"])
+                                   screen=info["usable"], early_stop=stop_on)
             px[:, 0:3] = out["color"]
             px[:, 3] = out["disp_map"]
             px[:, 4] = out["acc_map"]
@@ -973,7 +1007,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
                       "all_gather_ms_PRICED_not_measured": ag_ms,
                       "sum_of_shares_over_whole_frame": float(t.sum() / whole_ms),
                       "predicted_strong_scaling_efficiency": whole_ms / (Nw * step_ms),
-                      "predicted_speedup": whole_ms / step_ms,
+                      "predicted_speedup": whole_ms / step_ms, "early_stop": stop_info,
                       "density_screen_calibration": info}}
     _flush_c_stdio()
     print(json.dumps(res), flush=True)
