@@ -367,11 +367,13 @@ def main():
             torch.cuda.synchronize()
             st = _lib.read_stop_stats(ws)
             frac = st["would_skip"] / max(st["active"], 1)
-            # (like Renderer: the probe frame sizes the relu-record array for these parameters - a dense field gets more than the default
-            #  quarter of the samples instead of the overflow pass on every frame; every slot's workspace grows at its next get())
-            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S))
             cmax = st["colour_max"]
             finite = cmax == cmax and cmax != float("inf")
+            will_stop = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
+            # (like Renderer: the probe frame sizes the relu-record array for these parameters - a dense field gets more than the default
+            #  quarter of the samples instead of the overflow pass on every frame; every slot's workspace grows at its next get().  The
+            #  probe is one pass: sliced frames put far fewer samples on the sigma > 0 list, estimated by what termination leaves out)
+            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if will_stop else 1.0))
             scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
             eps = _lib.early_stop_eps(S, scale)
             schedule = None
@@ -545,7 +547,7 @@ def main():
             nonlocal cur, k_step
             cur = c
             k_step = 0
-            for _ in range(2):
+            for _ in range(max(2, depth)):      # (every slot once: a workspace that has just grown pays its first touch here, untimed)
                 step()
             barrier()
             tb = time.perf_counter()
@@ -679,15 +681,17 @@ def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, scre
         reduce_max(t_)
         frac, cmax = float(t_[0]), float(t_[1])
         finite = cmax != float("inf")
-    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S))
+    enabled = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
+    # (relu records: the probe frame is one pass; sliced frames put far fewer samples on the sigma > 0 list - estimated here, and a
+    #  frame that still overflows takes the exact overflow pass)
+    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if enabled else 1.0))
     scale = packed.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
     schedule = None
-    if args.stop_schedule == "auto" and reduce_max is None:      # (a multi-rank run keeps uniform slices: one schedule for all ranks)
+    if args.stop_schedule == "auto":      # (every rank cuts its own rays' slices from its own histogram: no collective needed)
         hist, L_uni = _lib.read_stop_hist(ws, R, S)
         lens, _, _ = _lib.choose_stop_schedule(hist, L_uni, S)
         if len(lens) < hist.shape[1]:
             schedule = lens
-    enabled = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
     return enabled, (schedule if enabled else None), {
         "enabled": enabled, "probe_would_skip_fraction_of_non_transparent": frac, "probe_largest_colour": cmax, "colour_scale": scale,
         "eps": _lib.early_stop_eps(S, scale), "slice_lengths": schedule if schedule is not None else f"uniform ({_lib.stop_slice_len(R, S)} samples)"}
@@ -944,7 +948,8 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
     # (one decision for the frame, as the ranks of the real run agree on by all-reduce: probe on the whole frame; uniform slices)
     whole = rp.tile_indices(R, tile, 0, 1).numpy()
     stop_on, _, stop_info = stop_setup(_lib, args, scene, packed, ws, T(rays["ray_o"][whole]), T(rays["ray_d"][whole]), T(rays["near"][whole]),
-                                       T(rays["far"][whole]), S, t_vals, info["usable"], reduce_max=lambda t_: None)
+                                       T(rays["far"][whole]), S, t_vals, info["usable"])
+    frame_scale = packed.colour_scale
 
     def time_share(idx):
         mine = idx.numpy()
@@ -954,6 +959,12 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
         px = torch.zeros(Rl, 6, dtype=torch.float32, device=dev)
         out = None
         ms = []
+        # (a rank of the real run probes its own share: its own slice schedule; decision and colour scale are the frame's)
+        schedule = None
+        if stop_on:
+            scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
+            _, schedule, _ = stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, info["usable"])
+            packed.set_early_stop_colour_scale(frame_scale)
         for i in range(args.warmup + args.steps):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -961,7 +972,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
             far.copy_(far0)
             scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
             out = _lib.render_rays(scene, packed, ws, o, d, near, far, S, t_vals, None, None, want_weights=False, out=out,
-                                   screen=info["usable"], early_stop=stop_on)
+                                   screen=info["usable"], early_stop=stop_on, stop_schedule=schedule)
             px[:, 0:3] = out["color"]
             px[:, 3] = out["disp_map"]
             px[:, 4] = out["acc_map"]

@@ -562,6 +562,7 @@ class Renderer:
         if plan["early_stop"] and (phases == 0 or phases & _lib.PHASE_SHADE):
             # the colours of sliced frames are watched: every SCREEN_AUDIT_EVERY-th one leaves its largest weighed colour for a later look
             if self._colour_probe is None and self._stop_frames % SCREEN_AUDIT_EVERY == 0:
+                self._watch_samples = int(o.shape[0]) * int(S)
                 snap = ws.buf[:256].clone()
                 ev = torch.cuda.Event()
                 ev.record()
@@ -614,7 +615,10 @@ class Renderer:
         #  before its second frame instead of the overflow pass on every frame)
         n_pos = int(snap.view(torch.int32)[_lib.CNT_POS])
         if getattr(self, "_probe_samples", 0) > 0:
-            _lib.fit_record_capacity(n_pos / float(self._probe_samples))
+            # (the probe frame is one pass; with termination in use the sliced frames list far fewer samples: estimated by what it leaves
+            #  out, corrected by the sliced frames themselves in _read_colour_probe, covered by the exact overflow pass in between)
+            will_stop = frac >= _lib.EARLY_STOP_MIN_SKIPPED if self.early_stop == "auto" else bool(self.early_stop)
+            _lib.fit_record_capacity(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0))
         self._note_colour_max(packed, st["colour_max"], first=True)
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
@@ -659,6 +663,8 @@ class Renderer:
             return
         c = snap.view(torch.int32).cpu()
         self._note_colour_max(packed, float(c[_lib.CNT_COLOUR_MAX:_lib.CNT_COLOUR_MAX + 1].view(torch.float32)[0]))
+        if getattr(self, "_watch_samples", 0) > 0:      # what the sliced frames really put on the sigma > 0 list
+            _lib.fit_record_capacity(int(c[_lib.CNT_POS]) / float(self._watch_samples))
 
     def last_screen_audit(self, ws=None):
         """what the audit of the last audited eval frame found - synchronises.  dict(audited, violations, max_sigma): `violations`
