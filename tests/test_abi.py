@@ -94,6 +94,41 @@ def test_every_entry_point_rejects_null_arguments(lib):
     assert b"frame index" in lib.dsn_last_error()
 
 
+def test_round4_host_functions(lib):
+    """the host-side entry points of ABI 5 need no GPU: threshold of the early stop with a colour scale, the slice-schedule checks of
+    dsn_render_rays_ex, the offsets of the nearest-face level headers, the (process-wide, monotone) relu-record capacity fraction"""
+    lib.dsn_early_stop_eps_scaled.restype = C.c_float
+    lib.dsn_record_capacity_fraction.restype = C.c_float
+    cap = 2.0 ** -20
+    e1 = lib.dsn_early_stop_eps(64)
+    assert e1 == pytest.approx(min(cap, 1e-4 / (2 * 65)), rel=1e-6)
+    assert lib.dsn_early_stop_eps_scaled(64, C.c_float(1.0)) == e1 == lib.dsn_early_stop_eps_scaled(64, C.c_float(0.25))   # scales < 1 count as 1
+    for S, c in ((64, 2.64), (128, 300.0), (16, 4527.0)):
+        e = lib.dsn_early_stop_eps_scaled(S, C.c_float(c))
+        assert e == pytest.approx(min(cap, 1e-4 / (2 * (S + 1) * c)), rel=1e-5)
+        assert (S + 1) * e * c <= 0.5e-4 * (1 + 1e-5)                      # the absolute bound for colours up to the scale
+    assert lib.dsn_set_early_stop_colour_scale(None, C.c_float(2.0), None) != 0 and b"dsn_set_early_stop_colour_scale" in lib.dsn_last_error()
+    # the schedule of dsn_render_rays_ex is checked before anything else is touched
+    one = C.c_void_p(64)
+    args = lambda lens: (one, 1, 1, one, one, one, one, one, 4, 16, one, None, None, 1 | 64, one, one, one, one, None, None, one,
+                         (C.c_int32 * len(lens))(*lens), len(lens), None)
+    for lens, msg in (([4, 4, 4], b"add up to S"), ([0, 8, 8], b"1 to 64"), ([1] * 33, b"32 slices")):
+        assert lib.dsn_render_rays_ex(*args(lens)) != 0 and msg in lib.dsn_last_error(), (lens, lib.dsn_last_error())
+    # level headers: four distinct 64-byte slots inside the scene blob, in the order of dsn_debug_nn_stats
+    off = (C.c_size_t * 4)()
+    assert lib.dsn_nn_header_offsets(6890, 13776, off) == 0
+    offs = [int(o) for o in off]
+    assert offs == sorted(offs) and len(set(offs)) == 4 and offs[0] > 256 and offs[-1] + 64 <= lib.dsn_scene_bytes(6890, 13776)
+    assert all(o % 256 == 0 for o in offs)
+    assert lib.dsn_nn_header_offsets(0, 0, off) != 0
+    # record capacity: reading does not change it, it only grows, and the workspace follows it
+    f0 = lib.dsn_record_capacity_fraction(C.c_float(0.0))
+    assert 0.25 <= f0 <= 1.0 and lib.dsn_record_capacity_fraction(C.c_float(float("nan"))) == f0
+    assert lib.dsn_record_capacity_fraction(C.c_float(0.1)) == f0
+    # (not raised here: the setting is process-wide and other tests size their workspaces with it)
+    assert lib.dsn_render_workspace_bytes(512 * 512, 64) >= 2.3e9
+
+
 def test_no_fallback_without_gpu():
     import torch
     import dsnerf_amd
