@@ -149,15 +149,20 @@ class Ranks:
             self.dev = torch.device("cpu")
         else:
             assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists for the product path)"
-            assert self.local < torch.cuda.device_count(), (f"rank {self.rank}: local rank {self.local} has no GPU "
-                                                            f"({torch.cuda.device_count()} visible)")
-            self.dev = torch.device("cuda", self.local)
+            # DSN_BENCH_ONE_GPU=1 (debug, with DSN_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): every rank uses GPU 0, so
+            # that the REAL code paths of a multi-rank run - partition, per-step collectives, barriers, the max over ranks - can be run
+            # end to end on a one-GPU box.  A control-flow check: the ranks share the GPU, the times mean nothing.
+            self.one_gpu = os.environ.get("DSN_BENCH_ONE_GPU") == "1"
+            idx = 0 if self.one_gpu else self.local
+            assert idx < torch.cuda.device_count(), (f"rank {self.rank}: local rank {self.local} has no GPU "
+                                                     f"({torch.cuda.device_count()} visible)")
+            self.dev = torch.device("cuda", idx)
             torch.cuda.set_device(self.dev)
         if self.on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            self.backend = "gloo" if self.dry else "nccl"
-            if self.dry:
+            self.backend = "gloo" if self.dry else os.environ.get("DSN_BENCH_BACKEND", "nccl")
+            if self.backend == "gloo":
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world)
@@ -198,7 +203,9 @@ class Ranks:
             except Exception:
                 ver = None
         return {"world_size": self.dist.get_world_size() if self.on else 1, "ranks_counted_by_all_reduce": seen,
-                "backend": ({"nccl": "nccl (= RCCL on ROCm)", "gloo": "gloo (dry launch, CPU)"}.get(self.backend)),
+                "backend": ({"nccl": "nccl (= RCCL on ROCm)", "gloo": "gloo (dry launch, CPU)" if self.dry else
+                             "gloo over GPU tensors (DEBUG: control-flow check of the multi-rank paths, not a measurement)"}.get(self.backend)),
+                "ranks_share_one_gpu_DEBUG": bool(getattr(self, "one_gpu", False)),
                 "rccl_version": ver, "launcher": os.environ.get("DSN_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                                                                 else ("none (single process)" if self.world == 1 else "external")),
                 "per_rank_ms_per_step": None if per_rank_s is None else [1e3 * t / steps for t in per_rank_s]}
@@ -214,7 +221,7 @@ def launch_ranks(args):
     driver's own N > 1 invocation does) and hand its exit status on.  The children see WORLD_SIZE and take the normal path."""
     import socket
     import subprocess
-    if not args.dry_launch:
+    if not args.dry_launch and os.environ.get("DSN_BENCH_ONE_GPU") != "1":
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if n_dev < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {n_dev} GPU(s) visible on this node")

@@ -11,6 +11,7 @@
 #   traintrace / trainpmc   the same two for `bench.py --train --steps 5 --warmup 2`
 #   strong / weak8 / strong8    bench.py --strong; --emulate-world 8 in the weak / strong mode
 #   dist1            the RCCL path with ONE rank (DSN_BENCH_FORCE_DIST=1) in weak, --strong and --train mode
+#   world2           TWO ranks sharing this one GPU over gloo (debug): the real multi-rank code paths of all three modes end to end
 #   ab:"A=1 B=2":"C=3"   A/B of environment settings (two interleaved rounds), BENCH_ARGS from the environment
 #   py:SCRIPT[:ARGS] python scripts/SCRIPT ARGS
 TAG=${1:-x}; shift
@@ -58,6 +59,12 @@ for step in "$@"; do
     dist1) DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > ${O}_weak_rccl.json; summ ${O}_weak_rccl.json
            DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --strong --no-cpu-baseline 2>/dev/null | tail -1 > ${O}_strong_rccl.json; summ ${O}_strong_rccl.json
            DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --train --steps 10 --warmup 3 2>/dev/null | tail -1 > ${O}_train_rccl.json; summ ${O}_train_rccl.json;;
+    world2) # the REAL multi-rank code paths with 2 ranks on this one GPU over gloo (RCCL refuses two ranks per device): control flow, collectives and
+            # reassembly of all three modes end to end; the ranks share the GPU, so the times mean nothing
+            for m in "" "--strong --hw 512 --samples 64" "--train"; do
+              n=$(echo "world2$m" | tr -c 'a-zA-Z0-9\n' '_')
+              DSN_BENCH_BACKEND=gloo DSN_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-roofline $m > ${O}_$n.log 2> ${O}_$n.err
+              tail -1 ${O}_$n.log > ${O}_$n.json; summ ${O}_$n.json || tail -5 ${O}_$n.err; done;;
     ab) IFS=':' read -ra CFGS <<< "$arg"
         for rep in 1 2; do for cfg in "${CFGS[@]}"; do
           env $cfg python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extras --no-roofline $BENCH_ARGS 2>/dev/null | python -c "
