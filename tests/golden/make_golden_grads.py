@@ -104,6 +104,14 @@ def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, see
 def main():
     import torch
     torch.set_num_threads(8)
+    if "--nonuniform" in sys.argv:               # the SMPL-like body (synth.make_body(nonuniform=True)): dense caps at head / hands / feet
+        state = synth.make_state_dict()
+        poses = synth.make_poses()
+        canon, faces = synth.make_body(nonuniform=True)
+        xyz = synth.pose_body(canon)
+        rays = synth.make_rays(32, 32, xyz, fit_box=True)
+        case("full_train_grads_nu", canon, faces, xyz, poses, rays, np.arange(0, 1024, 8), 64, state, raw_noise_std=1.0)
+        return
     if "--other-weights" in sys.argv:            # the trained parameter sets: w2 (make_weights_w2.py, default) or `--other-weights w4`
         rest = [a for a in sys.argv[sys.argv.index("--other-weights") + 1:] if not a.startswith("-")]
         tag = rest[0] if rest else "w2"

@@ -12,7 +12,8 @@ from test_gpu_render import make_batch, make_renderer
 pytestmark = pytest.mark.gpu
 
 GRAD_CASES = ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2", "full_train_grads_w2",
-              "small_train_grads_w4", "full_train_grads_w4"]
+              "small_train_grads_w4", "full_train_grads_w4",
+              "full_train_grads_nu"]        # the SMPL-like body (dense caps at head / hands / feet): make_golden_grads.py --nonuniform
 FULL_LIMIT, SAMPLE = 20000, 4096
 
 
@@ -67,7 +68,8 @@ def test_backward_matches_reference_autograd(name):
 @pytest.mark.parametrize("name,nrays,nsamp", [("small_train_grads", None, None), ("full_train_grads", None, None),
                                               ("full_train_grads", 37, None), ("full_train_grads", 37, 21),
                                               ("small_train_grads_w2", None, None), ("full_train_grads_w2", None, None),
-                                              ("small_train_grads_w4", None, None), ("full_train_grads_w4", None, None)])
+                                              ("small_train_grads_w4", None, None), ("full_train_grads_w4", None, None),
+                                              ("full_train_grads_nu", None, None)])
 def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
     """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) == autograd of the
     CPU oracle on the same inputs, full tensors."""
