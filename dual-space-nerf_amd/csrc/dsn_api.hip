@@ -24,7 +24,7 @@ static int dsn_check_launch(const char* what) {
 #define DSN_REQUIRE(cond, msg) do { if (!(cond)) return dsn_fail("%s", msg); } while (0)
 
 thread_local int g_dsn_persistent_override = 0;
-static std::atomic<float> g_record_fraction{0.25f};      // dsn_record_capacity_fraction
+static std::atomic<float> g_record_fraction{0.125f};      // dsn_record_capacity_fraction
 namespace {
 struct DsnShareCus {      // DSN_SHARE_CUS for the duration of one dsn_render_rays call
     explicit DsnShareCus(bool on) {
@@ -418,10 +418,17 @@ struct DsnWorkspace {
     float* z;             // [N] (used when the caller does not want z_vals)
     float* x_c;           // [N,3]
     float* sigma;         // [N]
-    float* essence;       // [N,3]
-    float* grad;          // [N,3]
-    float* n_w;           // [N,3]
-    float* colour;        // [N,3]
+    // Two 12 N-byte regions, adjacent, each used by two arrays IN PLACE (round 4; round 3 kept four arrays = 48 B per sample):
+    //   G: d sigma / dx_c, overwritten sample by sample with the world normal made from it (k_normal reads its sample's gradient, then
+    //      writes its normal); before the field phase the screen's keep list, after the slices the shading weights
+    //   E: essence, overwritten sample by sample with the colour made from it (k_light16 / k_light write a tile's colours after they
+    //      have read its essences; DSN_EARLY_STOP zeroes the "colour" of a sample it does not shade - its essence is dead by then)
+    // and, during the geometry phase, together the 24 N bytes of the cell-major sort: cells (4 N) | ranks (4 N) | sorted records (16 N).
+    float* essence;       // [N,3]  = E
+    float* grad;          // [N,3]  = G
+    float* n_w;           // [N,3]  = G
+    float* colour;        // [N,3]  = E
+    void* sort_scratch;   // 16 N bytes at G + 8 N (the sorted (point, id) records of the nearest-face search)
     int32_t* pos;         // [N]   samples with sigma > 0 (eval-mode split of the field kernel)
     void* masks;          // [rec_cap] x 224 B relu-mask records, indexed by the slot on the sigma > 0 list
     int64_t rec_cap;
@@ -469,9 +476,10 @@ static inline size_t dsn_slice_entries(size_t R, int S) {
     return R * (size_t)K * (size_t)L;
 }
 // Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
-// pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for A QUARTER of the samples of a
-// big frame (round 3: half - 1.9 of the 3.4 GB of a 512 x 512 x 64 frame).  The bench frame puts 11.6 % (hash-random parameters) /
-// 8 % (converged parameters, front-to-back slices) of its samples there, a briefly trained solid 39 %; samples beyond the capacity
+// pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for a FRACTION of the samples of a
+// big frame: an eighth until a caller asks for more (dsn_record_capacity_fraction; round 3: half - 1.9 of the 3.4 GB of a
+// 512 x 512 x 64 frame).  The bench frame puts 11.6 % (hash-random parameters) / 14 % (converged parameters, front-to-back slices)
+// of its samples there, a briefly trained solid 39 %: the host mirror's probe frame sizes it per checkpoint; samples beyond the capacity
 // take the single-launch forward + reverse pass instead (dsn_launch_field16_from): same values, no records, ~10 % more time for them.
 // DSN_RECORD_CAP (tests, or a caller who wants the records of every sample) overrides the capacity.
 static int64_t dsn_record_cap(int64_t N) {
@@ -493,10 +501,9 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.z = (float*)p;              p += dsn_align256(4 * N);
     w.x_c = (float*)p;            p += dsn_align256(12 * N);
     w.sigma = (float*)p;          p += dsn_align256(4 * N);
-    w.essence = (float*)p;        p += dsn_align256(12 * N);
-    w.grad = (float*)p;           p += dsn_align256(12 * N);
-    w.n_w = (float*)p;            p += dsn_align256(12 * N);
-    w.colour = (float*)p;         p += dsn_align256(12 * N);
+    w.grad = w.n_w = (float*)p;          p += 12 * N;                       // G (no padding between G and E: the sort spans both)
+    w.essence = w.colour = (float*)p;    p += dsn_align256(12 * N + 256);   // E
+    w.sort_scratch = (void*)((char*)w.grad + ((8 * N + 15) & ~(size_t)15));      // (16-byte aligned records; E carries 256 bytes of slack)
     w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
     w.rec_cap = dsn_record_cap((int64_t)N);
     w.masks = (void*)p;           p += dsn_align256(224 * (size_t)w.rec_cap);
@@ -620,12 +627,12 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
         // Samples outside the fine grid (none for rays clipped to the body's bounds) are left to a k_warp pass of their own.
         int32_t* g3 = (int32_t*)w.grad;
         if (!fused_nn) {      // (DSN_NN_UNFUSED, cross-check / A-B switch: round 2's form - search writes nn[], k_warp reads it)
-            dsn_launch_nn_cellmajor(s.nn_world, nullptr, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, g3 + N, w.nn_small, st);
+            dsn_launch_nn_cellmajor(s.nn_world, nullptr, ray_o, ray_d, z, N, S, g3, w.sort_scratch, g3 + N, w.nn_small, st);
             dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                             g3 + N, skip);
         } else {
             int32_t* outside = nullptr;
-            dsn_launch_nn_cellmajor_warp(s.nn_world, ray_o, ray_d, z, N, S, g3, (void*)w.n_w, w.nn_small, s.face_world, s.face_canon,
+            dsn_launch_nn_cellmajor_warp(s.nn_world, ray_o, ray_d, z, N, S, g3, w.sort_scratch, w.nn_small, s.face_world, s.face_canon,
                                          w.transparent, w.x_c, list, cnt, skip, &outside, st, true);
             dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                             nullptr, skip, g3, outside);
@@ -791,7 +798,7 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     const int32_t* nn_far = nullptr;
     const char* far_env = getenv("DSN_TRAIN_FAR_SEARCH_MIN");      // test / tuning override (a huge value switches it off)
     if (!exh && N >= (far_env ? atoll(far_env) : (long long)DSN_TRAIN_FAR_SEARCH_MIN)) {
-        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, (void*)w.n_w, w.pos, w.nn_small, st);
+        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, w.sort_scratch, w.pos, w.nn_small, st);
         nn_far = w.pos;
     }
     dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st, nn_far);

@@ -489,9 +489,9 @@ void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const fl
 __global__ void __launch_bounds__(FIELD_THREADS, 2)
 k_light(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
         const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
-        const float* __restrict__ z_vals, const float* __restrict__ essence, int64_t N, int S,
+        const float* __restrict__ z_vals, const float* essence, int64_t N, int S,
         const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-        float* __restrict__ colour) {
+        float* colour) {      // (essence and colour may be the same array: see k_light16)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;

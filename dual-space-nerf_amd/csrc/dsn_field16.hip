@@ -2016,9 +2016,11 @@ __device__ __forceinline__ void light_block(const char* __restrict__ blkp, int l
 __global__ void __launch_bounds__(256, 2)
 k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
           const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
-          const float* __restrict__ z_vals, const float* __restrict__ essence, int64_t N, int S,
+          const float* __restrict__ z_vals, const float* essence, int64_t N, int S,
           const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
-          float* __restrict__ colour, float* __restrict__ tr_hl1, float* __restrict__ tr_hl2, float* __restrict__ tr_pre) {
+          float* colour, float* __restrict__ tr_hl1, float* __restrict__ tr_hl2, float* __restrict__ tr_pre) {
+    // (essence and colour may be the SAME array - the fused path's workspace keeps the colour where the essence was: a tile reads its
+    //  samples' essences at its top and writes their colours at its end; hence no __restrict__ on the two)
     // tr_*: (training forward) the two hidden layers after their ReLU, row-major [N,128], and the pre-activation of the output
     // [N] - what the backward of the lighting MLP needs, so that it does not have to evaluate the MLP again
     __shared__ __attribute__((aligned(16))) char s_w[LIGHT_LDS_BYTES];      // [LT0: 4 x (hi, lo of k-step 0) | LT1: 16 x 4 KB]

@@ -579,11 +579,13 @@ template <bool EXHAUSTIVE>
 __global__ void __launch_bounds__(WARP_THREADS) k_normal(DsnNNArgs nn, const float4* __restrict__ cent_canon,
                                                           const DsnFaceRec* __restrict__ face_world,
                                                           const DsnFaceRec* __restrict__ face_canon, int F,
-                                                          const float* __restrict__ x_c, const float* __restrict__ grad,
+                                                          const float* __restrict__ x_c, const float* grad,
                                                           int64_t N, const int32_t* __restrict__ active_list,
                                                           const int32_t* __restrict__ active_count,
                                                           int32_t* __restrict__ face_idx_canon,
-                                                          float* __restrict__ n_w, const int32_t* __restrict__ nn_far) {
+                                                          float* n_w, const int32_t* __restrict__ nn_far) {
+    // (grad and n_w may be the SAME array - the fused path's workspace keeps the normal where the gradient was: every thread reads its
+    //  sample's gradient before it writes its sample's normal; hence no __restrict__ on the two)
     // nn_far (optional): the answer for points outside the fine grid, where the coarse-level cell-major search has found one
     // (dsn_launch_nn_cellmajor_coarse: training batches); -1 elsewhere
     __shared__ float4 s_tile[EXHAUSTIVE ? NN_TILE : 1];

@@ -334,8 +334,9 @@ DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale,
  *  the workspace is sized and leave them alone while it is in use.) */
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 /* The relu records the eval-mode reverse pass reads (224 B per sample with sigma > 0) are the largest item of the workspace.  Frames
- * of more than 2 M samples reserve them for a FRACTION of the samples - 1/4 by default (a frame of hash-random parameters puts 12 % of
- * its samples there, the converged checkpoint 8 %, a briefly trained solid 39 %); samples beyond the capacity are evaluated by a
+ * of more than 2 M samples reserve them for a FRACTION of the samples - 1/8 until somebody asks for more (a frame of hash-random
+ * parameters puts 12 % of its samples there, the converged checkpoint 14 % with front-to-back slices, a briefly trained solid 39 %:
+ * the host mirror's probe frame asks for what its checkpoint needs); samples beyond the capacity are evaluated by a
  * single-launch forward + reverse pass: same values, but their forward pass runs twice.  dsn_record_capacity_fraction(f) raises the
  * fraction to at least f (process-wide, it never shrinks; f <= 0 or NaN only reads it) and returns the value in force: a caller who
  * has seen word 16 of a frame's workspace come near the capacity calls it and re-sizes its workspaces with dsn_render_workspace_bytes

@@ -40,14 +40,16 @@ def test_version_and_sizes(lib):
     assert n >= 1024 * 64 * (4 + 1 + 4 + 12 * 5 + 4)
     assert lib.dsn_render_workspace_bytes(0, 64) == 0
     # the per-sample workspace of the benchmark frame and of a quarter of its rays (a regression guard.
-    # Round 3: 3.44 GB = 205 B per sample; round 4: relu records for a quarter of the samples instead of half, per-slice lists sized for
-    # the slice length in use, the screen's keep list inside the normal buffer -> 2.37 GB = 141 B per sample, 19 GB for the
-    # 1024 x 1024 x 128 frame of configs[3] on ONE GPU.  The arrays stay indexed by sample: Renderer.render_view(batch, chunk=65536)
-    # trades a quarter of it for +5-10 % time)
+    # Round 3: 3.44 GB = 205 B per sample; round 4: 1.50 GB = 89 B per sample - relu records for an eighth of the samples until a probe
+    # frame asks for more (dsn_record_capacity_fraction), the normal kept where the gradient was and the colour where the essence was,
+    # per-slice lists sized for the slice length in use, the screen's keep list inside the gradient buffer - and 12 GB for the
+    # 1024 x 1024 x 128 frame of configs[3] on ONE GPU (27.3).  The arrays stay indexed by sample.)
     whole, quarter = lib.dsn_render_workspace_bytes(512 * 512, 64), lib.dsn_render_workspace_bytes(512 * 512 // 4, 64)
-    assert 2.3e9 < whole < 2.4e9 and whole / (512 * 512 * 64) < 142
-    assert 0.24 * whole < quarter < 0.36 * whole              # (at 4 M samples the record array keeps its 2 M-sample floor: half of them)
-    assert lib.dsn_render_workspace_bytes(1024 * 1024, 128) < 19.1e9
+    frac = lib.dsn_record_capacity_fraction(C.c_float(0.0)) if hasattr(lib, "dsn_record_capacity_fraction") else 0.125
+    if frac <= 0.126:      # (the fraction is process-wide and only grows: other tests of this process may have raised it)
+        assert 1.45e9 < whole < 1.6e9 and whole / (512 * 512 * 64) < 90
+        assert lib.dsn_render_workspace_bytes(1024 * 1024, 128) < 13e9
+    assert 0.24 * whole < quarter < 0.50 * whole              # (at 4 M samples the record array keeps its 2 M-sample floor: half of them)
 
 
 def test_errors_are_loud(lib):
@@ -123,10 +125,10 @@ def test_round4_host_functions(lib):
     assert lib.dsn_nn_header_offsets(0, 0, off) != 0
     # record capacity: reading does not change it, it only grows, and the workspace follows it
     f0 = lib.dsn_record_capacity_fraction(C.c_float(0.0))
-    assert 0.25 <= f0 <= 1.0 and lib.dsn_record_capacity_fraction(C.c_float(float("nan"))) == f0
+    assert 0.125 <= f0 <= 1.0 and lib.dsn_record_capacity_fraction(C.c_float(float("nan"))) == f0
     assert lib.dsn_record_capacity_fraction(C.c_float(0.1)) == f0
     # (not raised here: the setting is process-wide and other tests size their workspaces with it)
-    assert lib.dsn_render_workspace_bytes(512 * 512, 64) >= 2.3e9
+    assert lib.dsn_render_workspace_bytes(512 * 512, 64) >= 1.45e9
 
 
 def test_no_fallback_without_gpu():
