@@ -380,7 +380,8 @@ def main():
             # (like Renderer: the probe frame sizes the relu-record array for these parameters - a dense field gets more than the default
             #  quarter of the samples instead of the overflow pass on every frame; every slot's workspace grows at its next get().  The
             #  probe is one pass: sliced frames put far fewer samples on the sigma > 0 list, estimated by what termination leaves out)
-            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if will_stop else 1.0))
+            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if will_stop else 1.0),
+                                     1.6 if will_stop else 1.25)
             scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
             eps = _lib.early_stop_eps(S, scale)
             schedule = None
@@ -691,7 +692,7 @@ def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, scre
     enabled = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
     # (relu records: the probe frame is one pass; sliced frames put far fewer samples on the sigma > 0 list - estimated here, and a
     #  frame that still overflows takes the exact overflow pass)
-    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if enabled else 1.0))
+    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if enabled else 1.0), 1.6 if enabled else 1.25)
     scale = packed.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
     schedule = None
     if args.stop_schedule == "auto":      # (every rank cuts its own rays' slices from its own histogram: no collective needed)

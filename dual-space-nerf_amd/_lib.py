@@ -587,11 +587,12 @@ def record_capacity_fraction(at_least: float = 0.0) -> float:
     return float(lib().dsn_record_capacity_fraction(C.c_float(at_least)))
 
 
-def fit_record_capacity(positive_fraction: float) -> float:
-    """a frame put this share of its samples on the sigma > 0 list: make the record capacity cover 1.25 x that (samples beyond the
-    capacity have their forward pass evaluated twice; Renderer / bench.py call this with their probe frame's count)"""
-    if positive_fraction > 0.8 * record_capacity_fraction():
-        return record_capacity_fraction(min(1.0, 1.25 * float(positive_fraction)))
+def fit_record_capacity(positive_fraction: float, headroom: float = 1.25) -> float:
+    """a frame put this share of its samples on the sigma > 0 list: make the record capacity cover `headroom` x that (samples beyond
+    the capacity have their forward pass evaluated twice; Renderer / bench.py call this with their probe frame's count - with more
+    headroom when the share is an ESTIMATE for sliced frames from a one-pass probe)"""
+    if headroom * positive_fraction > record_capacity_fraction():
+        return record_capacity_fraction(min(1.0, float(headroom) * float(positive_fraction)))
     return record_capacity_fraction()
 
 

@@ -618,7 +618,7 @@ class Renderer:
             # (the probe frame is one pass; with termination in use the sliced frames list far fewer samples: estimated by what it leaves
             #  out, corrected by the sliced frames themselves in _read_colour_probe, covered by the exact overflow pass in between)
             will_stop = frac >= _lib.EARLY_STOP_MIN_SKIPPED if self.early_stop == "auto" else bool(self.early_stop)
-            _lib.fit_record_capacity(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0))
+            _lib.fit_record_capacity(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0), 1.6 if will_stop else 1.25)
         self._note_colour_max(packed, st["colour_max"], first=True)
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
