@@ -77,6 +77,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #endif
 
 #define F16_THREADS 256
+// offset of output block m inside a training activation row ([N,256] row-major: 32 m).  Experiment builds (F16_TRAIN_ABL & 32, timing only,
+// WRONG addresses for the readers) emulate a TILE-major layout instead: [tile of 32 list slots][m][row][32 features] - 4 KB contiguous
+// per wave and output block
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 32)
+#define F16_ST_M(m) (1024 * (m))
+#else
+#define F16_ST_M(m) (32 * (m))
+#endif
 #define F16_CHUNK 8              // blocks per ring barrier; the ring holds two chunks (fixed: the DMA immediates span one chunk)
 #define F16_RING_SLOTS (2 * F16_CHUNK)
 #define F16_NCHUNK (DSN_STREAM_BLOCKS / F16_CHUNK)   // 109
@@ -492,7 +500,7 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
         uint32_t bits = 0;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
         else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) {
-            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr, 1.0f,
+            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + F16_ST_M(m - 1) : nullptr, 1.0f,
                                       HEAD ? wden + 32 * (m - 1) + 4 * half : nullptr, sg); });
         if (EXTRA) {   // encoding operands come back from LDS just for these two blocks
             half8 qh[2][2], ql[2][2];
@@ -507,7 +515,7 @@ __device__ __forceinline__ void layer16_fwd(W16& w, int& blk, int lane, const fl
         uint32_t bits = 0;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
-            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr, 1.0f,
+            epi_slice<true, ST, HEAD>(pM, pC, kb, 0u, bits, yh[7], yl[7], ovf, (ST && st) ? st + F16_ST_M(7) : nullptr, 1.0f,
                                       HEAD ? wden + 32 * 7 + 4 * half : nullptr, sg);
         mk[3] |= dsn_active_word(bits) << 16;
     }
@@ -524,12 +532,12 @@ __device__ __forceinline__ void layer16_bwd(W16& w, int& blk, int lane, const ha
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, true>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + 32 * (m - 1) : nullptr, stscale); });
+        else dense16<8, true>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[m - 1], yl[m - 1], ovf, (ST && st) ? st + F16_ST_M(m - 1) : nullptr, stscale); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ovf, (ST && st) ? st + 32 * 7 : nullptr, stscale);
+    for (int kb = 0; kb < 8; ++kb) epi_slice<false, ST>(pM, pC, kb, mw, dummy, yh[7], yl[7], ovf, (ST && st) ? st + F16_ST_M(7) : nullptr, stscale);
 }
 
 // MODE 0 (FULL): forward + reverse for every listed sample (stage API, train mode).
@@ -643,9 +651,14 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     uint4* mrec = masks ? masks + ((size_t)(MODE == F16_BWD ? lslot : pt) * 2 + half) * 7 : nullptr;
     // training kernel: this lane's row in the row-major [N,256] activation arrays (layer stride N * 256 floats)
     const int64_t tr_ls = N * 256;
-#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL)      // timing ablation (WRONG results): 1 = no h_l stores, 2 = no a_l stores
-    float* const th = ST && valid && !(F16_TRAIN_ABL & 1) ? tr_h + pt * 256 + 4 * half : nullptr;
-    float* const ta = ST && valid && !(F16_TRAIN_ABL & 2) ? tr_a + pt * 256 + 4 * half : nullptr;
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL)      // timing ablation (WRONG results): 1 = no h_l stores, 2 = no a_l stores,
+    // 8 / 16: the same store instructions into a SMALL footprint (rows folded onto 4096 / 256 rows per layer: 57 MB - inside the 256 MB
+    // Infinity Cache - / 3.6 MB - inside one L2): is the cost of the stores the write-back to HBM or their issue?
+    const int64_t pt_st = (F16_TRAIN_ABL & 8) ? (pt & 4095) : ((F16_TRAIN_ABL & 16) ? (pt & 255) : pt);
+    const int64_t sl_st = (tile * 4 + wave) * 32 + (lane & 31);      // (& 32: tile-major emulation, by list slot)
+    const int64_t row_off = (F16_TRAIN_ABL & 32) ? (sl_st >> 5) * 8192 + (sl_st & 31) * 32 : pt_st * 256;
+    float* const th = ST && valid && !(F16_TRAIN_ABL & 1) ? tr_h + row_off + 4 * half : nullptr;
+    float* const ta = ST && valid && !(F16_TRAIN_ABL & 2) ? tr_a + row_off + 4 * half : nullptr;
 #else
     float* const th = ST && valid ? tr_h + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : h_l
     float* const ta = ST && valid ? tr_a + pt * 256 + 4 * half : nullptr;     // + l * tr_ls : masked sigma-adjoint of layer l
@@ -683,7 +696,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        if (ST) store16(th ? th + 0 * tr_ls + 32 * m : nullptr, v, 1.0f);
+        if (ST) store16(th ? th + 0 * tr_ls + F16_ST_M(m) : nullptr, v, 1.0f);
         track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
@@ -716,7 +729,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        if (ST) store16(th ? th + 4 * tr_ls + 32 * m : nullptr, v, 1.0f);
+        if (ST) store16(th ? th + 4 * tr_ls + F16_ST_M(m) : nullptr, v, 1.0f);
         track16(ovf, v);
         split16<false>(v, ah[m], al[m]);
     }
@@ -730,7 +743,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         f32x16 v = unscale16(aM, aC);
         const uint32_t bits = relu_bits16(v);
         if (m & 1) mk[m >> 1] |= bits << 16; else mk[m >> 1] = bits;
-        if (ST) store16(th ? th + 6 * tr_ls + 32 * m : nullptr, v, 1.0f);
+        if (ST) store16(th ? th + 6 * tr_ls + F16_ST_M(m) : nullptr, v, 1.0f);
         const f32x16 wd = rows16(v_wden, m, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg_part = fmaf(wd[r], v[r], sg_part);
@@ -836,7 +849,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] *= F16_GSCALE;
         mask16(g, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
-        if (ST) store16(ta ? ta + 6 * tr_ls + 32 * m : nullptr, g, F16_GUNSCALE);
+        if (ST) store16(ta ? ta + 6 * tr_ls + F16_ST_M(m) : nullptr, g, F16_GUNSCALE);
         split16<true>(g, ah[m], al[m]);
     }
     MK_LOAD(5, mk) layer16_bwd<ST>(w, blk, lane, ah, al, bh, bl, mk, ovf, ta ? ta + 5 * tr_ls : nullptr);
@@ -851,7 +864,7 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
         dense16<8, true>(w, blk, lane, ah, al, aM, aC);
         f32x16 v = fold16(aM, aC);
         mask16(v, (mk[m >> 1] >> (16 * (m & 1))) & 0xffffu);
-        if (ST) store16(ta ? ta + 3 * tr_ls + 32 * m : nullptr, v, F16_GUNSCALE);
+        if (ST) store16(ta ? ta + 3 * tr_ls + F16_ST_M(m) : nullptr, v, F16_GUNSCALE);
         track16(ovf, v);
         split16<true>(v, bh[m], bl[m]);
     }

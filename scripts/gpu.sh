@@ -48,7 +48,7 @@ for step in "$@"; do
          pmcpass $D grbm "$C" GRBM_GUI_ACTIVE
          python scripts/pmc_summary.py $D ${O}_pmc$(echo "$arg" | tr -c 'a-zA-Z0-9\n' '_').json | cut -c1-300 | head -10; rm -rf $D;;
     traintrace) rm -rf gpurun_out/proft_$TAG; rocprofv3 --kernel-trace --stats -d gpurun_out/proft_$TAG -o t -- python bench.py --train --steps 5 --warmup 2 $args > ${O}_traintrace.log 2>&1
-           python scripts/rocpd_summary.py gpurun_out/proft_$TAG/t_results.db > ${O}_train_kernel_trace.txt; cut -c1-160 ${O}_train_kernel_trace.txt | head -${TRACE_LINES:-24}; rm -rf gpurun_out/proft_$TAG;;
+           python scripts/rocpd_summary.py gpurun_out/proft_$TAG/t_results.db > ${O}_train_kernel_trace.txt; python scripts/rocpd_sequence.py gpurun_out/proft_$TAG/t_results.db k_sample_gg > ${O}_train_sequence.txt; python scripts/rocpd_period.py gpurun_out/proft_$TAG/t_results.db > ${O}_train_period.txt; cut -c1-160 ${O}_train_kernel_trace.txt | head -${TRACE_LINES:-24}; rm -rf gpurun_out/proft_$TAG;;
     trainpmc) D=gpurun_out/pmct_$TAG; rm -rf $D; C="python bench.py --train --steps 3 --warmup 2 $args"
          pmcpass $D fetch "$C" FETCH_SIZE; pmcpass $D write "$C" WRITE_SIZE
          pmcpass $D sq "$C" SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES; pmcpass $D grbm "$C" GRBM_GUI_ACTIVE
