@@ -371,7 +371,7 @@ DSN_EXPORT int dsn_debug_nn_stats(const void* scene, int V, int F, int32_t* out1
  * work).  Header layout (int32 words): [8] cells, [9] ok (1 = the level is in use; 0 = not built, or its lists did not fit the
  * capacity - queries then fall through to the next level / the exhaustive sweep: SAME index, 10-50x slower), [10] list entries
  * the level needs, [11] capacity.  The host mirror copies the posed mesh's headers out asynchronously every few frames and warns
- * when entries > capacity (a mesh whose tessellation the fixed capacities 1600 F / 1000 F do not cover). */
+ * when entries > capacity (a mesh whose tessellation the fixed capacities - 2000 F entries per level - do not cover). */
 DSN_EXPORT int dsn_nn_header_offsets(int V, int F, size_t* out4_host);
 
 /* diagnostics: after a DSN_SKIP_TRANSPARENT render, int32 word 0 of `workspace` holds the number of non-transparent
