@@ -4,9 +4,11 @@
 A "step" = one pass of the whole hot path (per-frame setup, geometry-guided sampling, nearest-face warp,
 canonical field + d sigma/dx, normals + lighting MLP, compositing) over one synthetic 512x512 frame at
 64 samples/ray (BASELINE.json configs[1]) per GPU, inputs resident in HBM.  With N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank renders its own frame of the multi-frame batch
+torch.distributed.run, one rank per GPU) every rank renders one frame of the multi-frame batch
 (configs[4], rays partitioned across GPUs in contiguous blocks = frames) and the rendered pixels are
 exchanged with one RCCL all-gather inside the timed region: weak scaling, value = all rays / max time.
+The frames of the batch are copies of the N = 1 line's frame by default (fixed per-GPU work as N grows);
+--per-rank-frames different gives every rank its own pose (the step then waits for the slowest frame).
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     - k_field16<forward> (the dominant kernel), timed live with HIP events on the launch stream in a
@@ -98,6 +100,12 @@ def parse():
                     help="strong-scaling mode (BASELINE configs[3]): ONE 1024 x 1024 x 128 frame, its rays dealt to the ranks in "
                          "round-robin 3072-ray tiles (RayParallel.tile_indices), rendered pixels all-gathered inside the timed "
                          "region; N = 1 renders the whole frame on one GPU")
+    ap.add_argument("--per-rank-frames", default="same", choices=["same", "different"],
+                    help="weak mode / --train with N > 1: same (default) = every rank renders the SAME synthetic frame / batch as the N = 1 line "
+                         "(pose seeds 3, 5): per-GPU work is fixed as N grows, which is what makes the line a weak-scaling measurement; "
+                         "different = rank r renders its own pose (seeds 3 + r, 5 + r: frames of a sequence dealt to the GPUs, BASELINE "
+                         "configs[4]) - the frames then differ by up to 13 %% in non-transparent samples and every step waits for the slowest "
+                         "(profiles/r04_weak_emulated8.json: max / mean 1.06), a property of the data, not of the scaling")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements of the default N = 1 line (screen off, exact fp32, host-to-host "
                          "render_view, eager-torch GPU baseline, torch CPU baseline)")
@@ -325,8 +333,9 @@ def main():
     R = H * W
     canon, faces = synth.make_body()
     sd = load_weights(synth, args.weights)
-    poses = synth.make_poses(seed=5 + rank)
-    xyz = synth.pose_body(canon, seed=3 + rank)          # every rank renders its own frame of the batch
+    pose_rank = rank if args.per_rank_frames == "different" else 0      # (same: fixed per-GPU work, see --per-rank-frames)
+    poses = synth.make_poses(seed=5 + pose_rank)
+    xyz = synth.pose_body(canon, seed=3 + pose_rank)
     rays = synth.make_rays(H, W, xyz, fit_box=True)    # every ray crosses the padded body AABB (= mask_at_box rays)
 
     depth = max(1, args.pipeline)
@@ -535,6 +544,8 @@ def main():
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
             "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
             "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if use_dist else "none",
+            "per_rank_frames": ("every rank renders the same synthetic frame as the N = 1 line (fixed per-GPU work)" if args.per_rank_frames == "same"
+                                else "rank r renders its own pose (seeds 3 + r, 5 + r): the step waits for the slowest frame"),
         },
         "ranks": rk.info(per_rank_s, args.steps),
         "early_stop": stop_info,
@@ -854,10 +865,11 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
 
 
 def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
-    """The weak-scaling line's per-rank work, measured on ONE GPU: with N ranks every rank renders its own frame of the multi-frame
-    batch (pose / posed-mesh seeds 3 + rank, 5 + rank as in main()) and one all-gather of [R,6] pixels follows.  Each emulated rank's
-    frame is rendered alone here (two frames in flight, as the ranks do); the spread of the N times is the load imbalance a real run
-    waits for, max over ranks is its step time before the exchange."""
+    """The weak-scaling line's per-rank work with --per-rank-frames different, measured on ONE GPU: every rank renders its own frame
+    of the multi-frame batch (pose / posed-mesh seeds 3 + rank, 5 + rank) and one all-gather of [R,6] pixels follows.  Each emulated
+    rank's frame is rendered alone here (frames in flight as the ranks do); the spread of the N times is the load imbalance such a
+    run waits for every step - a property of the poses, which is why the default weak line gives every rank the SAME frame (rank 0's
+    here): `predicted_weak_scaling_efficiency_same_frames` prices that case (only the all-gather is added to rank 0's time)."""
     H = W = args.hw
     S = args.samples
     R = H * W
@@ -919,6 +931,7 @@ def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
                       "ranks": ranks, "frame_ms_max": float(t.max()), "frame_ms_mean": float(t.mean()), "frame_ms_min": float(t.min()),
                       "max_over_mean": float(t.max() / t.mean()), "all_gather_ms_PRICED_not_measured": ag_ms,
                       "predicted_weak_scaling_efficiency": float(t.mean() / (t.max() + ag_ms)),
+                      "predicted_weak_scaling_efficiency_same_frames": float(t[0] / (t[0] + ag_ms)),
                       "density_screen_calibration": info}}
     _flush_c_stdio()
     print(json.dumps(res), flush=True)
@@ -1047,7 +1060,8 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
     S, R = args.samples, args.train_rays
     canon, faces = synth.make_body()
     sd = load_weights(synth, weights or args.weights)
-    xyz = synth.pose_body(canon, seed=3 + rank)
+    pose_rank = rank if args.per_rank_frames == "different" else 0      # (the draws below differ per rank either way)
+    xyz = synth.pose_body(canon, seed=3 + pose_rank)
     rays = synth.make_rays(args.hw, args.hw, xyz, fit_box=True)
     sel = np.linspace(0, args.hw * args.hw - 1, R).astype(np.int64)
     cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
@@ -1060,7 +1074,7 @@ def train_measure(args, dsnerf_amd, synth, dev, world, rank, use_dist, steps, wa
     r.train()
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     batch = {"ray_o": T(rays["ray_o"][sel])[None], "ray_d": T(rays["ray_d"][sel])[None], "near": T(rays["near"][sel])[None],
-             "far": T(rays["far"][sel])[None], "xyz": T(xyz)[None], "poses": T(synth.make_poses(seed=5 + rank))[None],
+             "far": T(rays["far"][sel])[None], "xyz": T(xyz)[None], "poses": T(synth.make_poses(seed=5 + pose_rank))[None],
              "Th": torch.zeros(1, 1, 3, device=dev), "frame": torch.tensor([5])}
     target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
