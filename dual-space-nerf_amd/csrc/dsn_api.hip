@@ -622,8 +622,8 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     if (cellmajor) {
         // cell-major search: samples counting-sorted by fine cell, lists through the scalar cache, and the rest of the warp stage
         // fused behind the search (dsn_nn.hip, k_nns_search<WARP>).  Scratch: buffers that are not written before the field's
-        // reverse pass / the normal and lighting kernels - cell ids in the gradient buffer (N ints of 3 N), the sorted (point, id)
-        // records in n_w | colour (16 N bytes of 24 N; a colour is read only where the density is positive: no clearing).
+        // forward pass - G | E, 24 N bytes back to back (dsn_carve): cell ids (4 N) and ranks (4 N) at the start of G, the sorted
+        // (point, id) records (16 N) behind them, into E (an essence / colour is read only where the density is positive: no clearing).
         // Samples outside the fine grid (none for rays clipped to the body's bounds) are left to a k_warp pass of their own.
         int32_t* g3 = (int32_t*)w.grad;
         if (!fused_nn) {      // (DSN_NN_UNFUSED, cross-check / A-B switch: round 2's form - search writes nn[], k_warp reads it)
