@@ -154,6 +154,15 @@ def require_gpu():
         raise RuntimeError("dsnerf_amd needs a ROCm device (gfx950); no CPU fallback exists")
 
 
+def _scratch(nbytes, device):
+    """opaque device scratch for the library (scene blobs, workspaces): uninitialised, as the C ABI allows.  DSN_POISON_SCRATCH=1 (tests):
+    every byte 0xFF - NaN floats, -1 integers - so that nothing can come to rely on a fresh allocation reading as zeros"""
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if os.environ.get("DSN_POISON_SCRATCH"):
+        t.fill_(255)
+    return t
+
+
 def _ptr(t, dtype=None):
     if t is None:
         return C.c_void_p(0)
@@ -237,7 +246,7 @@ class PackedParams:
         calibration points are then the canonical points of that frame's non-transparent samples (+ a 2 cm halo) instead of a cube
         around the canonical centroids - what Renderer and bench.py do: the margin and the share the screen drops are measured on what
         is rendered (dsn_calibrate_screen_frame)."""
-        ws = torch.empty(lib().dsn_calibrate_workspace_bytes(C.c_int64(n_points)), dtype=torch.uint8, device=self.device)
+        ws = _scratch(lib().dsn_calibrate_workspace_bytes(C.c_int64(n_points)), self.device)
         out = torch.zeros(8, dtype=torch.float32, device=self.device)
 
         def run(n):
@@ -299,7 +308,7 @@ class Scene:
         canon = _f32(canonical_vertex.reshape(-1, 3), self.device)
         f = faces.to(device=self.device, dtype=torch.int32).contiguous()
         self.V, self.F = canon.shape[0], f.shape[0]
-        self.buf = torch.empty(lib().dsn_scene_bytes(self.V, self.F), dtype=torch.uint8, device=self.device)
+        self.buf = _scratch(lib().dsn_scene_bytes(self.V, self.F), self.device)
         _check(lib().dsn_set_body(_ptr(self.buf), _ptr(canon), _ptr(f), self.V, self.F, _stream()), "dsn_set_body")
         self._keep = (canon, f)
         self.frame_key = None
@@ -322,6 +331,8 @@ class Scene:
 
     def _judge_level(self, name, rec):
         ncell, ok, total, cap = rec
+        if cap <= 0:          # a level that was not built (fine-only frames leave the posed mesh's coarse level switched off)
+            return
         if total > cap and name not in self.nn_overflow:
             import warnings
             warnings.warn(f"dsnerf_amd: the {name.replace('_', ' ')} nearest-face level of this mesh needs {total} list entries, its capacity is "
@@ -420,7 +431,7 @@ def light(packed: PackedParams, normal, xyz_world, view_dir_world, essence, fp32
     N = a[0].shape[0]
     assert all(t.shape[0] == N for t in a), "normal, xyz_world, view_dir_world and essence_feature must have one row per point"
     col = torch.empty(N, 3, dtype=torch.float32, device=dev)
-    scratch = torch.empty(lib().dsn_pose_state_bytes(), dtype=torch.uint8, device=dev)
+    scratch = _scratch(lib().dsn_pose_state_bytes(), dev)
     _check(lib().dsn_light(_ptr(packed.buf), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), C.c_int64(N), _ptr(col), _ptr(scratch),
                            FIELD_FP32 if fp32 else 0, _stream()), "dsn_light")
     return col
@@ -495,7 +506,7 @@ def field_forward(scene: Scene, packed: PackedParams, x_c, active=None):
     dev = scene.device
     sigma = torch.zeros(N, dtype=torch.float32, device=dev)
     ess = torch.zeros(N, 3, dtype=torch.float32, device=dev)
-    rec = torch.empty(lib().dsn_field_record_bytes(C.c_int64(N)), dtype=torch.uint8, device=dev)
+    rec = _scratch(lib().dsn_field_record_bytes(C.c_int64(N)), dev)
     pos = torch.zeros(N, dtype=torch.int32, device=dev)
     pcnt = torch.zeros(1, dtype=torch.int32, device=dev)
     lst, cnt = (None, None) if active is None else active
@@ -605,7 +616,7 @@ class RenderWorkspace:
     def get(self, R, S):
         need = lib().dsn_render_workspace_bytes(R, S)
         if self.buf is None or self.cap < need:
-            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.buf = _scratch(need, self.device)
             self.cap = need
         return self.buf
 
@@ -809,7 +820,7 @@ class GradWorkspace:
         need = lib().dsn_grad_workspace_bytes(int(R), int(S))
         if self.buf is None or self.buf.numel() < need:
             self.buf = None
-            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.buf = _scratch(need, self.device)
         return self.buf
 
 
@@ -903,7 +914,7 @@ def image_scatter(out: dict, mask_at_box, H, W, clamp=False):
     dev = out["color"].device
     mask = mask_at_box.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
     R = out["color"].shape[0]
-    ws = torch.empty(lib().dsn_image_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    ws = _scratch(lib().dsn_image_workspace_bytes(H, W), dev)
     img = {k: torch.empty(H, W, c, dtype=torch.float32, device=dev) for k, c in
            (("coarse_color", 3), ("coarse_disp", 1), ("coarse_acc", 1), ("coarse_depth", 1))}
     _check(lib().dsn_image_scatter(_ptr(out["color"], torch.float32), _ptr(out["disp_map"]), _ptr(out["acc_map"]),
@@ -920,7 +931,7 @@ def image_psnr(img_rgb, gt, mask_at_box=None):
     gt = gt.reshape(H, W, 3).to(dev).contiguous()
     assert gt.dtype in (torch.float64, torch.float32)
     mask = None if mask_at_box is None else mask_at_box.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
-    ws = torch.empty(lib().dsn_image_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    ws = _scratch(lib().dsn_image_workspace_bytes(H, W), dev)
     out = torch.empty(4, dtype=torch.float64, device=dev)
     g64, g32 = (gt, None) if gt.dtype == torch.float64 else (None, gt)
     _check(lib().dsn_image_psnr(_ptr(img_rgb.contiguous(), torch.float32), _ptr(g64), _ptr(g32), _ptr(mask), H, W, _ptr(out),

@@ -264,6 +264,7 @@ static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi
 // a level that is not built: dsn_grid_cell() answers -1 for every point (ok = 0), queries go on to the next level / the sweep
 __global__ void k_grid_disable(DsnGrid* __restrict__ g) {
     g->ok = 0; g->ncell = 0; g->total = 0; g->nx = g->ny = g->nz = 0;
+    g->cap = 0; g->maxcell = 0;      // (the whole header: the host mirror reads `total` against `cap` - a scene blob starts as uninitialised memory)
 }
 
 void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,

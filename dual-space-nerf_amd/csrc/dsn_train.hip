@@ -68,11 +68,12 @@ __device__ __forceinline__ int64_t rows_at_u(const Rows& r, int64_t k) {
     return r.list ? (int64_t)*reinterpret_cast<cptr>((uintptr_t)(r.list + k)) : k;
 }
 // rows a workgroup of a row-chunked kernel takes: an even share of the listed rows, in multiples of `mult`, at least `least`
-__device__ __forceinline__ int64_t rows_share(int64_t NL, int mult, int least) {
-    int64_t rows = (NL + gridDim.x - 1) / gridDim.x;
+__device__ __forceinline__ int64_t rows_share_of(int64_t NL, int64_t groups, int mult, int least) {
+    int64_t rows = (NL + groups - 1) / groups;
     if (rows < least) rows = least;
     return (rows + mult - 1) / mult * mult;
 }
+__device__ __forceinline__ int64_t rows_share(int64_t NL, int mult, int least) { return rows_share_of(NL, (int64_t)gridDim.x, mult, least); }
 
 // ascending list of the rows with flag != 0: per-block counts, single-block scan, fill (deterministic; N / 256 <= 4096 blocks)
 __global__ void __launch_bounds__(T_THREADS) k_t_rows_count(const uint8_t* __restrict__ flag, int64_t N, int32_t* __restrict__ bcnt) {
@@ -834,6 +835,9 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
 // splits 0.44 -> LDS-DMA staging 0.345 -> convert-once 0.33 -> one workgroup per CU (256 instead of 512 groups) 0.28.  (Storing
 // per-workgroup tiles and reducing them in a second kernel instead of the atomicAdd epilogue measured the same: 0.24 + 0.04.)
 #define W16S_STAGES 4
+// floats of one workgroup's partial result in the two-stage form: the [256][C] tile + 256 column sums (bias gradient)
+#define W16_PART(C) (256 * (C) + 256)
+#define W16_PART_GROUPS 512          // most workgroups a two-stage product launches (k_t_wgrad16p: two per CU)
 #ifndef W16D_VALU
 #define W16D_VALU 5           // k_t_wgrad16d: VALU instructions the scheduler places behind each MFMA of a pipelined step
 #endif
@@ -1031,7 +1035,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
 __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
-                                                     float* __restrict__ dbias, Rows rw) {
+                                                     float* __restrict__ dbias, Rows rw, float* __restrict__ part) {
     constexpr int OT = 4, IT = 4, WI = 2;
     __shared__ __attribute__((aligned(16))) float ring[W16D_STAGES][2][16][256];
     __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][2][256];      // [buffer][operand][hi | lo][8-sample group][feature]
@@ -1218,6 +1222,24 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
         mfmas(ah, al, bh, bl);
     }
     const float back = sy * sx;
+    if (part) {
+        // this workgroup's partial tile (unscaled) + its column sums, plain coalesced stores: k_t_wgrad_reduce adds the workgroups up in
+        // a fixed order (the 65 536 float atomics per workgroup this replaces cost 0.087 of the kernel's 0.22 ms, and their order - hence
+        // the rounding of every gradient - changed from run to run)
+        // (in the accumulators' own order - piece (wave, a, b, r / 4) = 64 lanes x 4 registers, one 1 KB store per wave-instruction;
+        //  k_t_wgrad_reduce knows where the four values of a lane belong)
+        float4* const mine = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * W16_PART(256));
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int b = 0; b < IT; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    mine[(((wave * OT + a) * IT + b) * 4 + r4) * 64 + lane] =
+                        make_float4(acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]);
+        part[(size_t)blockIdx.x * W16_PART(256) + 256 * 256 + tid] = bsum;
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < OT; ++a)
 #pragma unroll
@@ -1232,6 +1254,78 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
     if (dbias) atomicAdd(dbias + tid, bsum);
 }
 
+// Second stage of the split-fp16 weight-gradient products: dW[i][j] += back * sum over the workgroups g of part[g][i][j], in ascending g -
+// a fixed order, so the gradients are bit-reproducible from run to run (the atomicAdd epilogue's were not).  `groups` workgroups were
+// launched; with a row list only those whose share of the listed rows is not empty have written (the same share rule as stage one).
+// C = columns of the tile (256, or 64 of which `in_valid` are written).  A workgroup owns one 1 KB piece of the partials (64 lanes x
+// 4 accumulator registers, in stage one's own order); its four waves take every fourth partial each and meet in LDS.  Workgroups
+// 0 .. 3 also add up 64 bias columns each.
+template <int C>
+__global__ void __launch_bounds__(256) k_t_wgrad_reduce(const float* __restrict__ part, int64_t N, int groups, int rows_per_wg, Rows rw,
+                                                         const float* __restrict__ sy_ptr, const float* __restrict__ sx_ptr,
+                                                         float* __restrict__ dW, int ldw, int in_valid, float* __restrict__ dbias) {
+    __shared__ float4 s_sum[4][64];
+    __shared__ float s_b[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t NL = rows_n(rw, N);
+    const int64_t rows = rw.cnt ? rows_share_of(NL, groups, 16, 64) : (int64_t)rows_per_wg;      // stage one's share rule
+    const int active = (int)((NL + rows - 1) / rows);
+    const int o = blockIdx.x * 64 + lane;            // float4 piece of the tile
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = part + (size_t)o * 4;
+    int g = q;
+    for (; g + 12 < active; g += 16) {
+        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * W16_PART(C));
+        const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(g + 4) * W16_PART(C));
+        const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(g + 8) * W16_PART(C));
+        const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(g + 12) * W16_PART(C));
+        acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+        acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+        acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+        acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+    }
+    for (; g < active; g += 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * W16_PART(C));
+        acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+    }
+    s_sum[q][lane] = acc;
+    float bs = 0.0f;
+    const bool bias_block = dbias && blockIdx.x < 4;             // workgroup-uniform
+    if (bias_block) {
+        const float* bsrc = part + 256 * C + blockIdx.x * 64 + lane;
+        for (int gg = q; gg < active; gg += 4) bs += bsrc[(size_t)gg * W16_PART(C)];
+        s_b[q][lane] = bs;
+    }
+    __syncthreads();
+    if (q != 0) return;
+    const float back = (sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f) * (sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f);
+    float4 t = s_sum[0][lane];
+    const float4 t1 = s_sum[1][lane], t2 = s_sum[2][lane], t3 = s_sum[3][lane];
+    t.x = ((t.x + t1.x) + t2.x) + t3.x; t.y = ((t.y + t1.y) + t2.y) + t3.y;
+    t.z = ((t.z + t1.z) + t2.z) + t3.z; t.w = ((t.w + t1.w) + t2.w) + t3.w;
+    // piece blockIdx.x = ((wave * OT + a) * IT + b) * 4 + r4 of the stage-one kernel's accumulators (k_t_wgrad16d: OT = IT = 4, waves 2 x 2;
+    // k_t_wgrad16p: 2 x 2 tiles per wave, wave = 64 output rows): the lane's four values are rows i .. i + 3 of column j
+    const int r4 = blockIdx.x & 3, half = lane >> 5, col = lane & 31;
+    int i, j;
+    if (C == 256) {
+        const int b = (blockIdx.x >> 2) & 3, a = (blockIdx.x >> 4) & 3, wv = blockIdx.x >> 6;
+        i = ((wv >> 1) * 4 + a) * 32 + 8 * r4 + 4 * half;
+        j = ((wv & 1) * 4 + b) * 32 + col;
+    } else {
+        const int b = (blockIdx.x >> 2) & 1, a = (blockIdx.x >> 3) & 1, wv = blockIdx.x >> 4;
+        i = 64 * wv + 32 * a + 8 * r4 + 4 * half;
+        j = 32 * b + col;
+    }
+    if (j < in_valid) {
+        float* out = dW + (int64_t)i * ldw + j;
+        out[0] += t.x * back;
+        out[(int64_t)ldw] += t.y * back;
+        out[2 * (int64_t)ldw] += t.z * back;
+        out[3 * (int64_t)ldw] += t.w * back;
+    }
+    if (bias_block) dbias[blockIdx.x * 64 + lane] += ((s_b[0][lane] + s_b[1][lane]) + s_b[2][lane]) + s_b[3][lane];
+}
+
 // The 256 x 64 sibling for the positional-encoding columns: dW[256, 63] += dY[N,256]^T X[N,64] (X = pe or its tangent).  Same
 // machinery with smaller pieces - 3 stages of (16 KB + 4 KB), 20 KB of operands, 80 KB of LDS = two workgroups per CU; wave w
 // owns output rows 64 w .. 64 w + 63 and all 64 columns (2 x 2 tiles).  Column 63 is the zero pad and is not written.
@@ -1239,7 +1333,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
 __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
-                                                        float* __restrict__ dbias, Rows rw) {
+                                                        float* __restrict__ dbias, Rows rw, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
     __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
     __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
@@ -1389,6 +1483,19 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
         multiply();
     }
     const float back = sy * sx;
+    if (part) {      // two-stage form: see k_t_wgrad16d / k_t_wgrad_reduce
+        float4* const mine = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * W16_PART(64));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    mine[(((wave * 2 + a) * 2 + b) * 4 + r4) * 64 + lane] =
+                        make_float4(acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]);
+        part[(size_t)blockIdx.x * W16_PART(64) + 256 * 64 + tid] = bsum;
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1404,28 +1511,44 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
     if (dbias) atomicAdd(dbias + tid, bsum);
 }
 
+// How the workgroups' partial products meet.  Default: two stages - every workgroup stores its tile into `part` (the training
+// workspace's W16_PART_GROUPS x W16_PART(256) floats), k_t_wgrad_reduce adds them in a fixed order: bit-reproducible gradients, and
+// 0.13 + 0.02 ms per 256 x 256 product instead of 0.22 (the 65 536 float atomics per workgroup were 40 % of the kernel).
+// DSN_WGRAD_REDUCE=atomic: round 1-3's atomicAdd epilogue (A/B switch).
+static bool wgrad_two_stage() {
+    static const bool v = [] { const char* e = getenv("DSN_WGRAD_REDUCE"); return !(e && e[0] == 'a'); }();
+    return v;
+}
 void wgrad_mfma16p(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, int in_valid,
-                   hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}) {
-    int groups = 512;                 // two workgroups per CU
+                   hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr) {
+    int groups = W16_PART_GROUPS;     // two workgroups per CU
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
-    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias, rw);
+    if (!wgrad_two_stage()) part = nullptr;
+    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias, rw, part);
+    if (part)
+        hipLaunchKernelGGL(k_t_wgrad_reduce<64>, dim3(256 * 64 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, sy, sx, dW, ldw,
+                           in_valid, dbias);
 }
 
 // dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
 // dbias (optional) [256] += column sums of dY
 void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
-                  float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}) {
+                  float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr) {
     int groups = 256;                 // one workgroup per CU, one round (with 512 the launch ran 0.33 instead of 0.28 ms)
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
     static const bool old_kernel = [] { const char* e = getenv("DSN_WGRAD16"); return e && e[0] == 'c'; }();
+    if (old_kernel || !wgrad_two_stage()) part = nullptr;
     if (old_kernel) hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
-    else hipLaunchKernelGGL(k_t_wgrad16d, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
+    else hipLaunchKernelGGL(k_t_wgrad16d, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw, part);
+    if (part)
+        hipLaunchKernelGGL(k_t_wgrad_reduce<256>, dim3(256 * 256 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, sy, sx, dW,
+                           ldw, 256, dbias);
 }
 
 
@@ -1551,6 +1674,7 @@ struct TrainWs {
     float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
     void* masks;
     float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
+    float* wg_part;                // the workgroups' partial tiles of one split-fp16 weight-gradient product (k_t_wgrad_reduce)
     uint8_t* live;                 // [N] row flags (scratch of the list builds)
     int32_t *list1, *list2;        // [N] rows the forward evaluates / rows with non-zero cotangents (ascending sample indices)
     int32_t *bcnt;                 // [N / 256 + 1] per-block counts / offsets of a list build
@@ -1597,6 +1721,13 @@ TrainWs carve(void* base, int64_t N) {
     w.live = (uint8_t*)take(n);
     w.list1 = (int32_t*)take(4 * n);
     w.list2 = (int32_t*)take(4 * n);
+    {   // (a product launches at most N / 64 workgroups: small batches keep a small workspace)
+        size_t g = (n + 63) / 64;
+        if (g > W16_PART_GROUPS) g = W16_PART_GROUPS;
+        const size_t fl = g * (size_t)W16_PART(256) > (size_t)256 * W16_PART(256) ? (size_t)256 * W16_PART(256) : g * (size_t)W16_PART(256);
+        const size_t fp = g * (size_t)W16_PART(64);
+        w.wg_part = (float*)take(4 * (fl > fp ? fl : fp));
+    }
     w.bcnt = (int32_t*)take(4 * (n / T_THREADS + 2));
     w.rowcnt = (int32_t*)take(256);           // (the 256 bytes in front of `small`: the host mirror reads the two counts there)
     w.small = (float*)take(4 * 1024);         // (last: the host mirror finds its counters at the end of the workspace)
@@ -1746,10 +1877,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* const g_adj = w.small + 301;
     int32_t* const range_cnt = (int32_t*)(w.small + 303);      // samples whose tangent / adjoint left the fp16 range (zeroed with w.small)
     dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt, R2.list, R2.cnt);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st, nullptr, R2);
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st, nullptr, R2, w.wg_part);
     for (int l = 1; l < 7; ++l)
-        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, nullptr, R2);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2);
+        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, nullptr, R2, w.wg_part);
+    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
     colsum(w.tn[6], 256, N64, grd[P_DEN_W], st, R2);   // d (w_d . hdot_6) / d w_d
     float* cur = w.t0;
 
@@ -1767,11 +1898,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt, R2.list, R2.cnt);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
-        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2);
-        if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2);
+        wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2, w.wg_part);
+        if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
     }
     // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
-    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2);
+    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part);
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
     if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
     hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,

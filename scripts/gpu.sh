@@ -8,6 +8,7 @@
 #   train            bench.py --train (default + w4 start)
 #   trace[:ARGS]     rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipeline 1 ARGS`
 #   pmc[:ARGS]       the separate --pmc passes of the same command (FETCH_SIZE, WRITE_SIZE, TCC, SQ, GRBM) -> TAG_pmc*.json
+#   poison           pytest -m gpu with every scratch allocation of the binding filled with 0xFF first (DSN_POISON_SCRATCH=1)
 #   traintrace / trainpmc   the same two for `bench.py --train --steps 5 --warmup 2`
 #   strong / weak8 / strong8    bench.py --strong; --emulate-world 8 in the weak / strong mode
 #   dist1            the RCCL path with ONE rank (DSN_BENCH_FORCE_DIST=1) in weak, --strong and --train mode
@@ -37,6 +38,7 @@ for step in "$@"; do
   case "$step" in
     tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -k "$args" 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-400 | tee ${O}_tests_k.txt
            else timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-400 | tee ${O}_tests.txt; fi;;
+    poison) DSN_POISON_SCRATCH=1 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-400 | tee ${O}_tests_poisoned.txt;;
     smoke) timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -E "smoke ok|Error|error" | cut -c1-200 | tee ${O}_smoke.txt;;
     bench) n=$(echo "bench$arg" | tr -c 'a-zA-Z0-9\n' '_'); timeout 1200 python bench.py $args > ${O}_$n.log 2> ${O}_$n.err; tail -1 ${O}_$n.log > ${O}_$n.json; summ ${O}_$n.json || tail -5 ${O}_$n.err;;
     train) for w in default w4; do timeout 400 python bench.py --train --weights $w --steps 30 --warmup 5 $args 2>/dev/null | tail -1 > ${O}_train_$w.json; summ ${O}_train_$w.json; done;;

@@ -63,7 +63,8 @@ def test_render_view_between_the_callers_torch_cpu_ops():
         assert torch.get_num_threads() == threads
         for k in ref:
             assert torch.equal(torch.nan_to_num(out[k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0)), k
-    assert np.median(busy) <= 1.25 * np.median(plain) + 1e-3, (np.median(plain), np.median(busy), sorted(busy))
+    # (a throttled frame takes 5-8 x: the bound only has to tell that from noise of a shared box)
+    assert np.median(busy) <= 1.5 * np.median(plain) + 2e-3, (np.median(plain), np.median(busy), sorted(busy))
 
 
 @pytest.mark.parametrize("wname", ["", "x_w4"])
