@@ -689,6 +689,8 @@ __device__ __forceinline__ float dsn_wave_sum(float v) {
 // lazy_colour (eval mode with the transparent skip): a colour exists only where the density is positive (elsewhere the weight is
 // exactly 0 and the reference's colour never reaches the pixel), so it is read only there - the colour array needs no clearing.
 // colour == NULL: weights from the densities alone (the shading list of DSN_EARLY_STOP); rgb_map == NULL: no per-ray outputs.
+// WEIGHTS_ONLY: the early-stop shading list's call - no colour, no per-ray outputs: the same scan, none of the five reductions
+template <bool WEIGHTS_ONLY>
 __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ colour, const float* __restrict__ sigma,
                                                     const uint8_t* __restrict__ transparent,
                                                     const float* __restrict__ z_vals, const float* __restrict__ ray_d,
@@ -719,7 +721,7 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
             if (transparent && transparent[g]) s = 0.f;
             if (noise) s = s + noise[g];
             s = s > 0.f ? s : 0.f;
-            if (colour && (!lazy_colour || s > 0.f)) { cr = colour[3 * g]; cg = colour[3 * g + 1]; cb = colour[3 * g + 2]; }
+            if (!WEIGHTS_ONLY && colour && (!lazy_colour || s > 0.f)) { cr = colour[3 * g]; cg = colour[3 * g + 1]; cb = colour[3 * g + 2]; }
         }
         const float alpha = in ? (1.0f - expf(-s * dist)) : 0.f;
         const float fac = in ? ((1.0f - alpha) + 1e-10f) : 1.0f;
@@ -735,6 +737,7 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
         carry = carry * __shfl(incl, 63);
         const float w = alpha * T;
         if (in && weights) weights[g] = w;
+        if (WEIGHTS_ONLY) continue;
         sr += dsn_wave_sum(w * cr);
         sg += dsn_wave_sum(w * cg);
         sb += dsn_wave_sum(w * cb);
@@ -762,8 +765,12 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour, int32_t* colour_max) {
-    hipLaunchKernelGGL(k_composite, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
-                       noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0, colour ? colour_max : nullptr);
+    if (!colour && !rgb_map)
+        hipLaunchKernelGGL(k_composite<true>, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
+                           noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, 0, (int32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(k_composite<false>, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
+                           noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0, colour ? colour_max : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
