@@ -65,6 +65,7 @@ RAYS_ZJU, RAYS_H36M = 0, 1
 FRAME_FINE_ONLY = 1           # dsn_set_frame_ex: only the fine nearest-face level of the posed mesh (points beyond it: exhaustive sweep)
 # int32 words of the render workspace the library leaves diagnostics in (include/dsnerf.h)
 CNT_ACTIVE, CNT_POS, CNT_KEEP, CNT_AUDIT, CNT_RANGE = 0, 16, 32, 40, 48
+CNT_SEL, CNT_LIT = 13, 14       # DSN_EARLY_STOP frames: slots of the reverse pass, shaded samples (DSN_CNT_SEL / DSN_CNT_LIT)
 
 
 def lib():

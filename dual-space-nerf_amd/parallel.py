@@ -51,6 +51,72 @@ class RayParallel:
             self._plans[key] = plan
         return plan
 
+    # ---- cost-balanced contiguous blocks (round 5: the partition of the metric's own 512 x 512 x 64 frame) ----
+    # A contiguous block of an image keeps a rank's samples in a compact part of space: the cells of the posed mesh's nearest-face
+    # grid it visits are (nearly) its own, so the per-frame list build can be restricted to them and the cell-major search runs on
+    # full waves - a round-robin tile share spreads an eighth of the samples over ALL the cells the frame visits.  The blocks are cut
+    # where the cumulative per-ray COST (evaluated samples, from a probe frame or from measured share times) crosses k / world.
+    @staticmethod
+    def balanced_bounds(cost, world: int, align: int = 64):
+        """cut points b_0 = 0 <= b_1 <= ... <= b_world = R of `world` contiguous blocks with (nearly) equal sums of cost [R]
+        (any non-negative per-ray estimate; all-zero -> equal ray counts).  Cuts are rounded to multiples of `align` rays."""
+        c = torch.as_tensor(cost, dtype=torch.float64).reshape(-1).clamp_min(0.0)
+        R = c.numel()
+        world = int(world)
+        if float(c.sum()) <= 0.0:
+            c = torch.ones(R, dtype=torch.float64)
+        cum = torch.cumsum(c, 0)
+        total = float(cum[-1])
+        bounds = [0]
+        for k in range(1, world):
+            b = int(torch.searchsorted(cum, torch.tensor(total * k / world, dtype=torch.float64)))
+            b = min(R, max(bounds[-1], ((b + align // 2) // align) * align))
+            bounds.append(b)
+        bounds.append(R)
+        return bounds
+
+    @staticmethod
+    def rebalance_bounds(bounds, seconds, align: int = 64):
+        """one step of measured re-balancing: block r = [bounds[r], bounds[r+1]) took seconds[r]; with the cost taken as uniform
+        inside each block the cuts move to where the cumulative measured time crosses k / world"""
+        R = bounds[-1]
+        dens = torch.zeros(R, dtype=torch.float64)
+        for r, t in enumerate(seconds):
+            n = bounds[r + 1] - bounds[r]
+            if n > 0:
+                dens[bounds[r]:bounds[r + 1]] = float(t) / n
+        return RayParallel.balanced_bounds(dens, len(seconds), align)
+
+    def block_plan(self, R: int, bounds, device=None):
+        """Cached partition of R rays into the contiguous blocks [bounds[r], bounds[r + 1]): the same dict as tile_plan (slab = rows
+        of the equal slabs exchanged = the largest block; mine = this rank's ray indices; src = for every ray its row in the gathered
+        [world * slab, C] tensor), so undeal() is the same ONE index_select."""
+        world = len(bounds) - 1
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        key = ("blocks", int(R), tuple(int(b) for b in bounds), str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            assert bounds[0] == 0 and bounds[-1] == R and all(bounds[i] <= bounds[i + 1] for i in range(world))
+            self.plan_builds += 1
+            counts = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+            slab = max(counts)
+            src = torch.empty(R, dtype=torch.int64)
+            for r in range(world):
+                src[bounds[r]:bounds[r + 1]] = r * slab + torch.arange(counts[r])
+            me = self.rank if self.rank < world else 0
+            plan = {"slab": slab, "mine": torch.arange(bounds[me], bounds[me + 1]).to(device), "src": src.to(device), "counts": counts,
+                    "bounds": [int(b) for b in bounds]}
+            self._plans[key] = plan
+        return plan
+
+    @staticmethod
+    def undeal(gathered: torch.Tensor, plan: dict, out: torch.Tensor = None) -> torch.Tensor:
+        """gathered [world * slab, C] (rank-major slabs) -> [R, C] in ray order through a plan's permutation (tile_plan / block_plan)"""
+        if out is None:
+            return gathered.index_select(0, plan["src"])
+        torch.index_select(gathered, 0, plan["src"], out=out)
+        return out
+
     def block(self, R: int) -> int:
         return (R + self.world - 1) // self.world
 
@@ -106,9 +172,19 @@ class RayParallel:
     def render_tiled(self, render_fn, ray_o, ray_d, near, far, tile: int = 3072):
         """like render(), with the round-robin tile partition.  NOTE: the geometry-guided sampler takes the FIRST ray's
         origin for the whole batch (utils/pts_utils.py:31), so this is meant for rays of one camera."""
+        return self.render_partitioned(render_fn, ray_o, ray_d, near, far, self.tile_plan(ray_o.shape[0], tile, ray_o.device))
+
+    def render_blocks(self, render_fn, ray_o, ray_d, near, far, cost=None):
+        """like render(), with contiguous blocks cut for equal cost (cost [R]: any per-ray estimate, e.g. the evaluated samples of a
+        previous frame of the sequence; None = equal ray counts).  Every rank must pass the same cost."""
+        R = ray_o.shape[0]
+        bounds = self.balanced_bounds(torch.ones(R) if cost is None else cost, self.world)
+        return self.render_partitioned(render_fn, ray_o, ray_d, near, far, self.block_plan(R, bounds, ray_o.device))
+
+    def render_partitioned(self, render_fn, ray_o, ray_d, near, far, plan: dict):
+        """this rank renders plan["mine"], ONE all-gather of equal slabs, ONE index_select into ray order (plan: tile_plan / block_plan)"""
         R = ray_o.shape[0]
         dev = ray_o.device
-        plan = self.tile_plan(R, tile, dev)
         idx = plan["mine"]
         if idx.numel():
             loc = render_fn(ray_o[idx].contiguous(), ray_d[idx].contiguous(), near[idx].contiguous(), far[idx].contiguous())
@@ -123,7 +199,7 @@ class RayParallel:
             pad[: packed.shape[0]] = packed
             allp = torch.empty(self.world * slab, 6, dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(allp, pad, group=self.group)
-            full = self.undeal_tiles(allp, R, tile)
+            full = self.undeal(allp, plan)
         return {"color": full[:, 0:3], "disp_map": full[:, 3], "acc_map": full[:, 4], "depth_map": full[:, 5]}
 
     # ---- multi-frame batches (BASELINE configs[4]: novel-pose sequences, novel_pose_vis.py:41-66) ----

@@ -10,7 +10,7 @@
 #   pmc[:ARGS]       the separate --pmc passes of the same command (FETCH_SIZE, WRITE_SIZE, TCC, SQ, GRBM) -> TAG_pmc*.json
 #   poison           pytest -m gpu with every scratch allocation of the binding filled with 0xFF first (DSN_POISON_SCRATCH=1)
 #   traintrace / trainpmc   the same two for `bench.py --train --steps 5 --warmup 2`
-#   strong / weak8 / strong8    bench.py --strong; --emulate-world 8 in the weak / strong mode
+#   strong[:ARGS] / weak8 / strong8[:ARGS]    bench.py --strong (one GPU); --emulate-world 8 in the weak mode; the strong partition emulated at 2 / 4 / 8 ranks
 #   dist1            the RCCL path with ONE rank (DSN_BENCH_FORCE_DIST=1) in weak, --strong and --train mode
 #   world2           TWO ranks sharing this one GPU over gloo (debug): the real multi-rank code paths of all three modes end to end
 #   ab:"A=1 B=2":"C=3"   A/B of environment settings (two interleaved rounds), BENCH_ARGS from the environment
@@ -55,15 +55,28 @@ for step in "$@"; do
          pmcpass $D fetch "$C" FETCH_SIZE; pmcpass $D write "$C" WRITE_SIZE
          pmcpass $D sq "$C" SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES; pmcpass $D grbm "$C" GRBM_GUI_ACTIVE
          python scripts/pmc_summary.py $D ${O}_train_pmc.json 5 | cut -c1-300 | head -12; rm -rf $D;;
-    strong) timeout 600 python bench.py --strong --no-cpu-baseline $args 2>/dev/null | tail -1 > ${O}_strong.json; summ ${O}_strong.json;;
-    strong8) timeout 900 python bench.py --strong --emulate-world 8 --steps 5 --warmup 2 $args 2>/dev/null | tail -1 > ${O}_strong_emulated8.json; summ ${O}_strong_emulated8.json;;
+    strong) timeout 600 python bench.py --strong --no-cpu-baseline $args 2>/dev/null | tail -1 > ${O}_strong$(echo "$arg" | tr -c 'a-zA-Z0-9\n' '_').json; summ ${O}_strong$(echo "$arg" | tr -c 'a-zA-Z0-9\n' '_').json;;
+    strong8) # one frame partitioned for N emulated ranks, each share rendered alone on this GPU: strong8 = the metric's 512 x 512 x 64 frame at
+             # 2 / 4 / 8 ranks in one run; strong8:--big-frame = configs[3]; strong8:--partition,tiles = the round-robin deal
+             n=$(echo "strong_emulated$arg" | tr -c 'a-zA-Z0-9\n' '_')
+             timeout 1500 python bench.py --strong --emulate-world 8 --emulate-sweep ${SWEEP:-2,4,8} --steps ${EMU_STEPS:-12} --warmup 3 $args 2>${O}_$n.err | tail -1 > ${O}_$n.json
+             python - ${O}_$n.json <<'PY' || tail -5 ${O}_$n.err
+import json, sys
+d = json.load(open(sys.argv[1])); c = d['config']
+w = c['whole_frame_one_gpu']; print('whole frame: %.3f ms pipelined, %.3f alone' % (w['ms'], w['ms_alone']))
+for n, v in sorted(c['worlds'].items(), key=lambda kv: int(kv[0])):
+    print(' N=%s  share max %.3f mean %.3f (alone max %.3f)  max/mean %.3f  sum/whole %.3f  -> %.3f ms/frame, speed-up %.2f (eff %.2f; one at a time %.2f)  %s' % (
+        n, v['share_ms_max'], v['share_ms_mean'], v['share_ms_alone_max'], v['max_over_mean'], v['sum_of_shares_over_whole_frame'], v['predicted_ms_per_frame'],
+        v['predicted_speedup'], v['predicted_strong_scaling_efficiency'], v['predicted_speedup_one_frame_at_a_time'], v['partition'].get('bounds', v['partition'].get('tile_rays'))))
+PY
+             ;;
     weak8) timeout 900 python bench.py --emulate-world 8 --steps 8 --warmup 3 $args 2>/dev/null | tail -1 > ${O}_weak_emulated8.json; summ ${O}_weak_emulated8.json;;
     dist1) DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > ${O}_weak_rccl.json; summ ${O}_weak_rccl.json
            DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --strong --no-cpu-baseline 2>/dev/null | tail -1 > ${O}_strong_rccl.json; summ ${O}_strong_rccl.json
            DSN_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --train --steps 10 --warmup 3 2>/dev/null | tail -1 > ${O}_train_rccl.json; summ ${O}_train_rccl.json;;
     world2) # the REAL multi-rank code paths with 2 ranks on this one GPU over gloo (RCCL refuses two ranks per device): control flow, collectives and
             # reassembly of all three modes end to end; the ranks share the GPU, so the times mean nothing
-            for m in "" "--strong --hw 512 --samples 64" "--train"; do
+            for m in "" "--weak" "--partition tiles" "--train"; do
               n=$(echo "world2$m" | tr -c 'a-zA-Z0-9\n' '_')
               DSN_BENCH_BACKEND=gloo DSN_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-roofline $m > ${O}_$n.log 2> ${O}_$n.err
               tail -1 ${O}_$n.log > ${O}_$n.json; summ ${O}_$n.json || tail -5 ${O}_$n.err; done;;

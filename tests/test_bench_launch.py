@@ -32,7 +32,7 @@ def _json_lines(out):
     return lines
 
 
-@pytest.mark.parametrize("mode", [[], ["--strong"], ["--train"]])
+@pytest.mark.parametrize("mode", [[], ["--weak"], ["--strong"], ["--strong", "--partition", "tiles"], ["--train"]])
 def test_gpus_flag_launches_that_many_ranks(mode):
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0"] + mode,
                        env=_env(), capture_output=True, text=True, timeout=600)
@@ -46,7 +46,10 @@ def test_gpus_flag_launches_that_many_ranks(mode):
     assert len(j["ranks"]["per_rank_ms_per_step"]) == 2
     assert j["value"] is None                           # a dry launch must not look like a measurement
     assert all(j["checks"].values())
-    assert j["scaling"] == ("strong" if mode == ["--strong"] else "weak")
+    # N > 1 without a mode flag is the STRONG line (the metric's frame partitioned over the ranks); --weak opts out
+    assert j["scaling"] == ("weak" if mode in (["--weak"], ["--train"]) else "strong")
+    if j["scaling"] == "strong" and "tiles" not in mode:
+        assert j["checks"]["blocks_are_cost_balanced"] is True
 
 
 def test_under_the_drivers_own_launcher():

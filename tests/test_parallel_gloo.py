@@ -39,12 +39,27 @@ def _worker(rank, world, port, R, q):
         ok = ok and all(torch.equal(out2[k], ref[k]) for k in ref)
         owned = torch.cat([rp.tile_indices(R, tile, r) for r in range(world)])
         ok = ok and torch.equal(torch.sort(owned).values, torch.arange(R))
+    # cost-balanced contiguous blocks (round 5, bench.py --strong's default partition): ragged blocks, equal slabs, same pixels; a
+    # second frame with the same cuts builds nothing
+    for cost in (None, torch.arange(R).float() ** 2 + 0.1, torch.zeros(R), torch.cat([torch.zeros(R - 1), torch.ones(1)])):
+        out3 = rp.render_blocks(_fake_render, o, d, n, f, cost=cost)
+        ok = ok and all(torch.equal(out3[k], ref[k]) for k in ref)
+        b = rp.balanced_bounds(torch.ones(R) if cost is None else cost, world, align=1)
+        ok = ok and b[0] == 0 and b[-1] == R and len(b) == world + 1 and all(b[i] <= b[i + 1] for i in range(world))
+    builds = rp.plan_builds
+    rp.render_blocks(_fake_render, o, d, n, f, cost=None)
+    ok = ok and rp.plan_builds == builds
+    # (measured re-balancing: the block that took twice as long gives rays away)
+    if R >= 8:
+        b0 = rp.balanced_bounds(torch.ones(R), 2, align=1)
+        b1 = rp.rebalance_bounds(b0, [2.0, 1.0], align=1)
+        ok = ok and b1[1] < b0[1]
     q.put((rank, s, e, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R", [10, 7, 1])
+@pytest.mark.parametrize("R", [10, 7, 1, 200])
 def test_ray_parallel_world2(R):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
