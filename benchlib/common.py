@@ -20,6 +20,9 @@ FLOP_SCREEN_PER_SAMPLE = 2.0 * 425728.0      # k_screen16: trunk + density head,
 FLOP_ALL_PER_SAMPLE = 2.0 * 902272.0         # + lighting MLP 17 664 MAC
 PEAK_F32_MATRIX_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_F16_MATRIX_TFLOPS = 2500.0              # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
+# per-frame set-up the way Renderer does it for eval frames: the posed mesh's nearest-face lists built by the frame's own render call for
+# the cells its samples visit (DSN_FRAME_LAZY_LISTS); DSN_BENCH_LAZY_LISTS=0 = every cell's lists in dsn_set_frame (rounds 1-4), for A/B
+LAZY_LISTS = os.environ.get("DSN_BENCH_LAZY_LISTS", "1") != "0"
 SPLIT_PRODUCTS = 3                           # split-fp16: 3 f16 MFMA products per algorithmic product
 
 

@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-from .common import FLOP_ALL_PER_SAMPLE, ROOT, load_weights, _flush_c_stdio
+from .common import LAZY_LISTS, FLOP_ALL_PER_SAMPLE, ROOT, load_weights, _flush_c_stdio
 
 
 def frame_bench(args, dsnerf_amd, _lib, synth, rk):
@@ -79,8 +79,9 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
             # (like Renderer: the probe frame sizes the relu-record array for these parameters - a dense field gets more than the default
             #  quarter of the samples instead of the overflow pass on every frame; every slot's workspace grows at its next get().  The
             #  probe is one pass: sliced frames put far fewer samples on the sigma > 0 list, estimated by what termination leaves out)
-            _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if will_stop else 1.0),
-                                     1.6 if will_stop else 1.25)
+            for w_ in wss:
+                w_.fit_records(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if will_stop else 1.0),
+                               1.6 if will_stop else 1.25)
             scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
             eps = _lib.early_stop_eps(S, scale)
             schedule = None
@@ -145,7 +146,7 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
         def geometry():
             nears[j].copy_(near0)
             fars[j].copy_(far0)
-            scenes[j].set_frame(cur["packed"], d_xyz, d_poses, 5, False, None, None, None, fine_only=True)   # what Renderer does per frame
+            scenes[j].set_frame(cur["packed"], d_xyz, d_poses, 5, False, None, None, None, fine_only=True, lazy=LAZY_LISTS)   # what Renderer does per frame
             if pipe is not None:
                 frame_call(j, _lib.PHASE_GEOMETRY)
 
@@ -248,7 +249,7 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
         # (the headline's own counters, before the other parameter sets reuse the workspaces)
         headline_cw = wss[(k_step - 1) % depth].buf[:256].view(torch.int32).cpu()
         headline_st = _lib.read_stop_stats(wss[(k_step - 1) % depth])
-        headline_ws_gb = _lib.lib().dsn_render_workspace_bytes(R, S) / 1e9
+        headline_ws_gb = wss[0].bytes_for(R, S) / 1e9
         by = {}
         share_cus[0] = depth > 1 and os.environ.get("DSN_BENCH_SHARE_CUS", "1") != "0"      # (frames in flight again)
 
@@ -320,7 +321,7 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
                 n_.copy_(near0); f_.copy_(far0)
                 torch.cuda.synchronize()
                 t = time.perf_counter()
-                scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
+                scene.set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True, lazy=LAZY_LISTS)
                 _lib.render_rays(scene, packed, ws, ray_o, ray_d, n_, f_, S, t_vals, None, None, want_weights=False, out=outs[0], **kw)
                 torch.cuda.synchronize()
                 if i:
@@ -341,9 +342,9 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
         chunk = (H * W) // 4
         ex["chunked_frame"] = {"chunk_rays": chunk,
                                "workspace_gb_whole_frame_headline": headline_ws_gb,      # (at the record fraction the headline's probe frame left)
-                               "record_capacity_fraction_now": _lib.record_capacity_fraction(),      # (process-wide, grown by the densest set of by_weights)
-                               "workspace_gb_whole_frame": _lib.lib().dsn_render_workspace_bytes(H * W, S) / 1e9,
-                               "workspace_gb_chunked": _lib.lib().dsn_render_workspace_bytes(chunk, S) / 1e9,
+                               "record_capacity_fraction_now": wss[0].want_fraction,      # (of the bench's own workspaces: grown by the densest set of by_weights)
+                               "workspace_gb_whole_frame": wss[0].bytes_for(H * W, S) / 1e9,
+                               "workspace_gb_chunked": wss[0].bytes_for(chunk, S) / 1e9,
                                "host_to_host_ms": host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
                                                                chunk=chunk)}
         # BASELINE configs[2] in the same line: 8192 x 64 training step (render + MSE + backward + Adam)
@@ -371,11 +372,12 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
 
 
 
-def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, screen, reduce_max=None):
+def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, screen, reduce_max=None, more_ws=()):
     """Front-to-back slicing for the secondary modes, decided like Renderer / the headline loop do: one probe render (one pass,
     DSN_STOP_STATS) of these rays says what termination would leave out, how large the colours are (-> the threshold's colour scale)
     and how the slices should be cut (choose_stop_schedule).  reduce_max(tensor): all-reduce MAX over the ranks of a multi-GPU run, so
-    that every rank takes the same decision and threshold.  Returns (enabled, schedule | None, info dict)."""
+    that every rank takes the same decision and threshold.  more_ws: the other workspaces that will render these rays (frames in flight):
+    they get the record capacity the probe asks for as well.  Returns (enabled, schedule | None, info dict)."""
     if args.early_stop == "off" or args.dense or args.fp32:
         return False, None, {"enabled": False}
     R = o.shape[0]
@@ -394,7 +396,8 @@ def stop_setup(_lib, args, scene, packed, ws, o, d, near0, far0, S, t_vals, scre
     enabled = finite and (args.early_stop == "on" or frac >= _lib.EARLY_STOP_MIN_SKIPPED)
     # (relu records: the probe frame is one pass; sliced frames put far fewer samples on the sigma > 0 list - estimated here, and a
     #  frame that still overflows takes the exact overflow pass)
-    _lib.fit_record_capacity(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if enabled else 1.0), 1.6 if enabled else 1.25)
+    for w_ in [ws] + list(more_ws):
+        w_.fit_records(int(ws.buf[64:68].view(torch.int32)[0]) / float(R * S) * ((1.0 - frac) if enabled else 1.0), 1.6 if enabled else 1.25)
     scale = packed.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax) if finite else 1.0
     schedule = None
     if args.stop_schedule == "auto":      # (every rank cuts its own rays' slices from its own histogram: no collective needed)
@@ -448,7 +451,7 @@ def weak_emulated(args, dsnerf_amd, _lib, synth, dev):
             with torch.cuda.stream(streams[j]):
                 nears[j].copy_(near0)
                 fars[j].copy_(far0)
-                scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True)
+                scenes[j].set_frame(packed, d_xyz, d_poses, 5, False, None, None, None, fine_only=True, lazy=LAZY_LISTS)
                 outs[j] = _lib.render_rays(scenes[j], packed, wss[j], o, d, nears[j], fars[j], S, t_vals, want_weights=False, out=outs[j],
                                            screen=screen, early_stop=stop_on, stop_schedule=schedule, share_cus=depth > 1)
 

@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from .common import load_weights, _flush_c_stdio
+from .common import LAZY_LISTS, load_weights, _flush_c_stdio
 from .frame import stop_setup
 
 XGMI_LINK_GBS = 153.0         # MI355X_MICROARCH.md: per-link xGMI bandwidth (7 links per GPU); used ONLY to price the emulation's gather
@@ -103,13 +103,14 @@ class Share:
         f, sl = self.f, self.sl
         sl.scenes[0].set_frame(f.packed, f.d_xyz, f.d_poses, 5, False, None, None, None)
         on, sched, info = stop_setup(self._lib, self.args, sl.scenes[0], f.packed, sl.wss[0], self.o, self.d, self.near0, self.far0, f.S,
-                                     f.t_vals, self.screen, reduce_max=reduce_max)
+                                     f.t_vals, self.screen, reduce_max=reduce_max, more_ws=sl.wss[1:])
         if frame_decision is not None:
             on = bool(frame_decision[0])
             f.packed.set_early_stop_colour_scale(frame_decision[1])
             sched = sched if on else None
         self.stop_on, self.schedule, self.stop_info = on, sched, info
-        for j in range(sl.depth):         # (the probe may have grown the record capacity: every slot's workspace at its final size)
+        for j in range(sl.depth):         # (the probe may have asked for more records: every slot's workspace at its final size)
+            sl.wss[j].begin_frame()
             sl.wss[j].get(self.Rl, f.S)
         return on
 
@@ -118,7 +119,7 @@ class Share:
         f, sl, L = self.f, self.sl, self._lib
         self.nears[j].copy_(self.near0)
         self.fars[j].copy_(self.far0)
-        sl.scenes[j].set_frame(f.packed, f.d_xyz, f.d_poses, 5, False, None, None, None, fine_only=True)
+        sl.scenes[j].set_frame(f.packed, f.d_xyz, f.d_poses, 5, False, None, None, None, fine_only=True, lazy=LAZY_LISTS)
         out = self.outs[j] = L.render_rays(sl.scenes[j], f.packed, sl.wss[j], self.o, self.d, self.nears[j], self.fars[j], f.S, f.t_vals,
                                            None, None, want_weights=False, out=self.outs[j], screen=self.screen,
                                            early_stop=self.stop_on, stop_schedule=self.schedule, share_cus=share_cus)

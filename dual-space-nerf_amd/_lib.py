@@ -39,8 +39,8 @@ EXPORTS = [
     "dsn_image_workspace_bytes", "dsn_image_scatter", "dsn_image_psnr", "dsn_debug_screen", "dsn_field_screen", "dsn_lbs_warp", "dsn_render_rays_train", "dsn_debug_nn_stats", "dsn_camera_rays",
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
-    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_record_capacity_fraction",
-    "dsn_render_rays_ex",
+    "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_render_workspace_bytes_for",
+    "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_render_rays_ex",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -63,6 +63,8 @@ SCREEN_HEADROOM = 10.0        # = F16_SCREEN_HEADROOM: every calibration point i
 SCREEN_MIN_DROPPED = 0.35     # PackedParams.calibrate_screen: below this share of dropped calibration points the screen stays off
 RAYS_ZJU, RAYS_H36M = 0, 1
 FRAME_FINE_ONLY = 1           # dsn_set_frame_ex: only the fine nearest-face level of the posed mesh (points beyond it: exhaustive sweep)
+FRAME_LAZY_LISTS = 2          # dsn_set_frame_ex: grid geometry only - the frame that uses the level builds the lists of the cells it visits
+LAZY_LISTS = 4096             # dsn_render_rays_ex: ... which is this flag (Scene.lazy says whether the scene's frame was set that way)
 # int32 words of the render workspace the library leaves diagnostics in (include/dsnerf.h)
 CNT_ACTIVE, CNT_POS, CNT_KEEP, CNT_AUDIT, CNT_RANGE = 0, 16, 32, 40, 48
 CNT_SEL, CNT_LIT = 13, 14       # DSN_EARLY_STOP frames: slots of the reverse pass, shaded samples (DSN_CNT_SEL / DSN_CNT_LIT)
@@ -80,13 +82,15 @@ def lib():
         L.dsn_last_error.restype = C.c_char_p
         L.dsn_early_stop_eps.restype = C.c_float
         L.dsn_early_stop_eps_scaled.restype = C.c_float
-        L.dsn_record_capacity_fraction.restype = C.c_float
-        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_field_record_bytes",
+        L.dsn_render_workspace_record_capacity.restype = C.c_int64
+        L.dsn_render_workspace_record_capacity.argtypes = [C.c_int, C.c_int, C.c_size_t]
+        L.dsn_render_workspace_bytes_for.argtypes = [C.c_int, C.c_int, C.c_float]
+        for n in ("dsn_packed_param_bytes", "dsn_scene_bytes", "dsn_render_workspace_bytes", "dsn_render_workspace_bytes_for", "dsn_field_record_bytes",
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 5:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 5 - rebuild it "
+        if L.dsn_abi_version() != 6:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 6 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -321,7 +325,9 @@ class Scene:
         _check(lib().dsn_nn_header_offsets(self.V, self.F, off), "dsn_nn_header_offsets")
         self._nn_off = [int(o) for o in off]
         self._nn_probe = None
+        self._nn_host = None
         self._nn_frames = 0
+        self.lazy = False              # the current frame was set with DSN_FRAME_LAZY_LISTS (render_rays then passes DSN_LAZY_LISTS)
         self.nn_overflow = {}          # level name -> (entries needed, capacity) of every overflow seen
         st = nn_stats(self)
         for name in ("canon_fine", "canon_coarse"):
@@ -355,19 +361,40 @@ class Scene:
                     self._judge_level(name, tuple(int(w[16 * i + k]) for k in (8, 9, 10, 11)))
         return self.nn_overflow
 
+    def _watch_headers(self):
+        """copy the posed mesh's two level headers out (asynchronously, into ONE persistent page-locked buffer: ADVICE r04 - a fresh
+        pin_memory() per probe is a hipHostMalloc on the hot path) for nn_watch() to look at later"""
+        if self._nn_host is None:
+            self._nn_host = torch.empty(128, dtype=torch.uint8).pin_memory()
+        host = self._nn_host
+        for i in range(2):      # world fine / coarse headers, 64 bytes each
+            host[64 * i:64 * i + 64].copy_(self.buf[self._nn_off[i]:self._nn_off[i] + 64], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._nn_probe = (host, ev)
+
     def set_frame(self, packed: PackedParams, xyz, poses, frame_idx: int, zero_code: bool = False,
-                  light_shift=None, rot=None, rot_center=None, reuse: bool = False, fine_only: bool = False):
+                  light_shift=None, rot=None, rot_center=None, reuse: bool = False, fine_only: bool = False, lazy: bool = False):
         """reuse=True: skip the call when the scene already holds exactly this frame for these parameters (same tensors at
         the same versions) - used by the backward of a training step, which follows its own forward.
         fine_only=True (DSN_FRAME_FINE_ONLY): build only the fine nearest-face level of the posed mesh - enough for every sample
         of rays clipped to the body's bounds (what Renderer.render / render_view produce); points further than 0.12 m outside the
-        posed centroids' box then take the exhaustive sweep (same index)."""
+        posed centroids' box then take the exhaustive sweep (same index).
+        lazy=True (DSN_FRAME_LAZY_LISTS, implies fine_only): only the fine grid is laid out; render_rays on this scene then builds
+        the lists of the cells ITS samples visit (it passes DSN_LAZY_LISTS while Scene.lazy is set).  Stage calls on a lazily set
+        scene (warp, lbs_warp, a training forward) stay exact but take the exhaustive sweep: set the frame without `lazy` for those."""
         vkey = lambda a: None if a is None else (a.data_ptr(), a._version, tuple(a.shape))
         key = (vkey(xyz), vkey(poses), int(frame_idx), bool(zero_code), vkey(light_shift), vkey(rot), vkey(rot_center),
-               id(packed), packed._versions, bool(fine_only))
+               id(packed), packed._versions, bool(fine_only), bool(lazy))
         if reuse and key == self.frame_key:
             return self
         self.frame_key = key
+        # (a lazily set frame's lists - and the header that says whether they fit - are completed by its render call: what the previous
+        #  frame left is looked at here, before this frame overwrites it)
+        self.nn_watch()
+        if self.lazy and self._nn_probe is None and self._nn_frames % self.NN_WATCH_EVERY == 1:
+            self._watch_headers()
+        self.lazy = bool(lazy)
         xyz = _f32(xyz.reshape(-1, 3), self.device)
         assert xyz.shape[0] == self.V, "xyz must have the body model's vertex count"
         poses = _f32(poses.reshape(24, 3), self.device)
@@ -376,17 +403,12 @@ class Scene:
         rc = None if rot_center is None else _f32(rot_center.reshape(-1)[:2], self.device)
         _check(lib().dsn_set_frame_ex(_ptr(self.buf), self.V, self.F, _ptr(packed.buf), _ptr(xyz), _ptr(poses),
                                       int(frame_idx), int(bool(zero_code)), _ptr(ls), _ptr(r), _ptr(rc),
-                                      FRAME_FINE_ONLY if fine_only else 0, _stream()), "dsn_set_frame")
+                                      (FRAME_LAZY_LISTS | FRAME_FINE_ONLY) if lazy else (FRAME_FINE_ONLY if fine_only else 0), _stream()),
+               "dsn_set_frame")
         self._keep_frame = (xyz, poses, ls, r, rc)
         self._pose_args = (poses, int(frame_idx), bool(zero_code), ls, r, rc)
-        self.nn_watch()
-        if self._nn_probe is None and self._nn_frames % self.NN_WATCH_EVERY == 0:
-            host = torch.empty(128, dtype=torch.uint8).pin_memory()
-            for i in range(2):      # world fine / coarse headers, 64 bytes each
-                host[64 * i:64 * i + 64].copy_(self.buf[self._nn_off[i]:self._nn_off[i] + 64], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._nn_probe = (host, ev)
+        if not lazy and self._nn_probe is None and self._nn_frames % self.NN_WATCH_EVERY == 0:
+            self._watch_headers()
         self._nn_frames += 1
         return self
 
@@ -593,29 +615,46 @@ def composite(colour, sigma, transparent, z_vals, ray_d, noise=None):
     return rgb, disp, acc, w, dep
 
 
-def record_capacity_fraction(at_least: float = 0.0) -> float:
-    """share of a big frame's samples the relu-record array of the render workspace is sized for (dsn_record_capacity_fraction:
-    process-wide, only grows).  RenderWorkspace.get() picks a raised value up at its next call."""
-    return float(lib().dsn_record_capacity_fraction(C.c_float(at_least)))
-
-
-def fit_record_capacity(positive_fraction: float, headroom: float = 1.25) -> float:
-    """a frame put this share of its samples on the sigma > 0 list: make the record capacity cover `headroom` x that (samples beyond
-    the capacity have their forward pass evaluated twice; Renderer / bench.py call this with their probe frame's count - with more
-    headroom when the share is an ESTIMATE for sliced frames from a one-pass probe)"""
-    if headroom * positive_fraction > record_capacity_fraction():
-        return record_capacity_fraction(min(1.0, float(headroom) * float(positive_fraction)))
-    return record_capacity_fraction()
+RECORD_FRACTION_DEFAULT = 0.125      # = DSN_RECORD_FRACTION_DEFAULT (csrc/dsn_api.hip)
 
 
 class RenderWorkspace:
-    def __init__(self, device):
+    """The caller-owned scratch of the fused path, grown on demand.  Its relu-record capacity is ITS OWN (ABI 6: the library reads the
+    capacity from the size it is handed; rounds 3-4 kept one process-wide fraction that every workspace re-read at every call).
+    `fraction` = share of a big frame's samples the records are sized for; fit_records() asks for more after a frame was seen to
+    need it.  A larger request is applied at the START of the next frame only (begin_frame(), called by render_rays in front of a
+    frame's geometry phase), never between the phase calls of one frame: the buffer a frame's geometry phase filled is the buffer
+    its field and shading phases read."""
+
+    def __init__(self, device, fraction: float = RECORD_FRACTION_DEFAULT):
         self.device = torch.device(device)
         self.buf = None
         self.cap = 0
+        self.fraction = float(fraction)      # in force for the buffer
+        self.want_fraction = float(fraction)      # asked for: applied by begin_frame()
+        self._sized = None
+
+    def fit_records(self, positive_fraction: float, headroom: float = 1.25) -> float:
+        """a frame put this share of its samples on the sigma > 0 list: make the record capacity cover `headroom` x that from the next
+        frame on (samples beyond the capacity have their forward pass evaluated twice; Renderer / bench.py call this with their probe
+        frame's count - with more headroom when the share is an ESTIMATE for sliced frames from a one-pass probe).  Never shrinks."""
+        want = min(1.0, float(headroom) * float(positive_fraction))
+        if want > self.want_fraction:
+            self.want_fraction = want
+        return self.want_fraction
+
+    def begin_frame(self):
+        self.fraction = max(self.fraction, self.want_fraction)
+
+    def bytes_for(self, R, S):
+        return lib().dsn_render_workspace_bytes_for(int(R), int(S), C.c_float(self.fraction))
+
+    def record_capacity(self, R, S):
+        """records the buffer holds for an R x S frame (what dsn_render_rays_ex will use)"""
+        return int(lib().dsn_render_workspace_record_capacity(int(R), int(S), C.c_size_t(self.cap)))
 
     def get(self, R, S):
-        need = lib().dsn_render_workspace_bytes(R, S)
+        need = self.bytes_for(R, S)
         if self.buf is None or self.cap < need:
             self.buf = _scratch(need, self.device)
             self.cap = need
@@ -662,6 +701,10 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     flags |= int(phases) & (PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE)
     if share_cus:
         flags |= SHARE_CUS
+    if scene.lazy and train_cache is None:
+        flags |= LAZY_LISTS
+    if not phases or (int(phases) & PHASE_GEOMETRY):
+        ws.begin_frame()          # (a larger record capacity asked for since the last frame: the buffer may be replaced HERE, only here)
     buf = ws.get(R, S)
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT
@@ -682,7 +725,7 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
                                     _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
                                     _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
                                     _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
-                                    _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), sched, n_sched, _stream()),
+                                    _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), C.c_size_t(ws.cap), sched, n_sched, _stream()),
            "dsn_render_rays")
     return out
 
@@ -750,9 +793,9 @@ def early_stop_eps(S: int, colour_scale: float = 1.0) -> float:
 
 
 def stop_slice_len(R: int, S: int) -> int:
-    """samples per uniform slice of DSN_EARLY_STOP (= dsn_slice_len of csrc/dsn_api.hip without its experiment override)"""
-    L = 4 if R * S >= (1 << 22) else 8
-    return L if (S + L - 1) // L <= 32 else (S + 31) // 32
+    """samples per uniform slice of DSN_EARLY_STOP for an R x S frame, from the library itself (dsn_stop_slice_len: what
+    dsn_render_rays_ex and the DSN_STOP_STATS histogram use, the DSN_STOP_SLICE experiment override included)"""
+    return int(lib().dsn_stop_slice_len(int(R), int(S)))
 
 
 def read_stop_hist(ws, R: int, S: int):

@@ -149,7 +149,8 @@ class _ViewSlot:
     def __init__(self, renderer, own_scene):
         self.scene = renderer.scene if not own_scene else _lib.Scene(renderer.canonical_model["vertex"], renderer.face_idx,
                                                                     renderer.device)
-        self.ws = renderer._ws if not own_scene else _lib.RenderWorkspace(renderer.device)
+        # (a new slot's workspace starts with the record capacity the renderer's frames were seen to need)
+        self.ws = renderer._ws if not own_scene else _lib.RenderWorkspace(renderer.device, fraction=renderer._ws.want_fraction)
         self.stream = torch.cuda.Stream(device=renderer.device)
 
 
@@ -176,6 +177,10 @@ class Renderer:
         self._frame_src = None
         self._slots = []
         self.skip_transparent = True      # eval mode: networks only on non-transparent samples (exact)
+        # eval frames: the posed mesh's nearest-face lists are built by the frame's own render call, for the cells its samples visit
+        # (DSN_FRAME_LAZY_LISTS: same lists entry for entry, for 48 % of the cells on a whole 512 x 512 frame, a tenth on a rank's
+        # block of a partitioned frame).  False: every cell's lists in dsn_set_frame, as rounds 1-4 did.
+        self.lazy_lists = True
         # eval mode: plain-fp16 density screen in front of the accurate pass.  OPT-IN since round 4: its margin is
         # calibrated for the loaded parameters and audited while it runs - frames are bit-identical with it on or off on everything
         # tested - but that is statistical safety, not a proof, and the one converged checkpoint (w4) calibrates it off anyway.
@@ -287,9 +292,10 @@ class Renderer:
         src = self._frame_src
         return src is not None and src[0]() is xyz and src[1] == xyz._version
 
-    def _set_frame(self, batch, scene=None, frame=None):
+    def _set_frame(self, batch, scene=None, frame=None, lazy=False):
         """dsn_set_frame from a batch.  Returns the arguments as used (device tensors), which a training forward keeps for
-        its backward."""
+        its backward.  lazy: the frame is about to be rendered by _lib.render_rays (eval frames): only the posed mesh's fine grid is
+        laid out here and the render call builds the candidate lists of the cells its samples visit (DSN_FRAME_LAZY_LISTS)."""
         scene = self.scene if scene is None else scene
         if frame is None:
             frame = int(torch.as_tensor(batch["frame"]).reshape(-1)[0])
@@ -298,7 +304,8 @@ class Renderer:
         poses = batch["poses"][0].to(device=self.device, dtype=torch.float32).contiguous()
         # (fine level only: the samples of rays clipped to the body's bounds never leave it; stage calls on far-away points - w2l
         #  on arbitrary points - still get the exact index, from the exhaustive sweep)
-        scene.set_frame(self.net.packed(self.device), xyz, poses, frame, zero_code, ls, rot, rc, fine_only=True)
+        scene.set_frame(self.net.packed(self.device), xyz, poses, frame, zero_code, ls, rot, rc, fine_only=True,
+                        lazy=bool(lazy) and self.lazy_lists)
         if scene is self.scene:
             self._mark_frame_src(batch["xyz"])
         return (xyz, poses, frame, zero_code, ls, rot, rc)
@@ -396,7 +403,7 @@ class Renderer:
     def _ensure_mesh(self, batch):
         """the scene must hold batch['xyz'] as its posed mesh (direct callers of the warp / network stages)"""
         xyz = batch["xyz"]
-        if self._is_frame_src(xyz):
+        if self._is_frame_src(xyz) and not self.scene.lazy:      # (a lazily set frame holds lists for its own render call only)
             return
         if "poses" in batch and "frame" in batch:
             self._set_frame(batch)
@@ -473,13 +480,14 @@ class Renderer:
         R = o.shape[0]
         S = self.cfg.MODEL.COARSE_RAY_SAMPLING
         self._poll_training_range()
-        frame_args = self._set_frame(batch)
+        sd = dict(self.net.named_parameters())
+        differentiable = self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in sd.values())
+        frame_args = self._set_frame(batch, lazy=not differentiable)      # (the training forward walks every cell's lists)
         jitter, noise = self._draws(R, S)
         if self.sample_points_mode not in ("GG", "uniform"):
             raise Exception("error")   # the reference fails on unknown modes too (get_sampling_points returns nothing)
         uniform = self.sample_points_mode == "uniform"
-        sd = dict(self.net.named_parameters())
-        if self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in sd.values()):
+        if differentiable:
             outs = _RenderRays.apply(self, (o, d, near, far, S, jitter, noise, uniform, frame_args),
                                      *[sd[k] for k in _lib.PARAM_ORDER])
             out = dict(zip(_OUT_KEYS, outs))
@@ -618,7 +626,7 @@ class Renderer:
             # (the probe frame is one pass; with termination in use the sliced frames list far fewer samples: estimated by what it leaves
             #  out, corrected by the sliced frames themselves in _read_colour_probe, covered by the exact overflow pass in between)
             will_stop = frac >= _lib.EARLY_STOP_MIN_SKIPPED if self.early_stop == "auto" else bool(self.early_stop)
-            _lib.fit_record_capacity(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0), 1.6 if will_stop else 1.25)
+            self._fit_records(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0), 1.6 if will_stop else 1.25)
         self._note_colour_max(packed, st["colour_max"], first=True)
         packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
@@ -629,6 +637,13 @@ class Renderer:
             lens, ev, un = _lib.choose_stop_schedule(hist, L, S_)
             if len(lens) < hist.shape[1]:
                 packed.early_stop.update({"schedule": lens, "schedule_evaluates": ev, "uniform_evaluates": un})
+
+    def _fit_records(self, positive_fraction, headroom=1.25):
+        """the relu-record capacity of THIS renderer's workspaces (its own and its view slots') follows what its frames put on the
+        sigma > 0 list; each workspace applies the request at the start of its next frame (RenderWorkspace.begin_frame) - never
+        between the phases of a frame, and no other renderer's workspace is touched (VERDICT r04 #8, ADVICE r04)"""
+        for ws in [self._ws] + [sl.ws for sl in self._slots if sl.ws is not self._ws]:
+            ws.fit_records(positive_fraction, headroom)
 
     def _note_colour_max(self, packed, cmax, first=False):
         """the early-stop threshold's colour scale follows the largest colour seen: scale = 2 x that (never below 1, never lowered)"""
@@ -664,7 +679,7 @@ class Renderer:
         c = snap.view(torch.int32).cpu()
         self._note_colour_max(packed, float(c[_lib.CNT_COLOUR_MAX:_lib.CNT_COLOUR_MAX + 1].view(torch.float32)[0]))
         if getattr(self, "_watch_samples", 0) > 0:      # what the sliced frames really put on the sigma > 0 list
-            _lib.fit_record_capacity(int(c[_lib.CNT_POS]) / float(self._watch_samples))
+            self._fit_records(int(c[_lib.CNT_POS]) / float(self._watch_samples))
 
     def last_screen_audit(self, ws=None):
         """what the audit of the last audited eval frame found - synchronises.  dict(audited, violations, max_sigma): `violations`
@@ -724,7 +739,7 @@ class Renderer:
         ws = self._ws if ws is None else ws
         # the frame's state first: its kernels (0.45 ms of nearest-face lists for the posed mesh) need the 82 KB of vertices only and
         # run while this thread stages the 8 MB of rays through page-locked memory (-0.1 ms per render_view, A/B in one call)
-        self._set_frame(batch, scene=scene)
+        self._set_frame(batch, scene=scene, lazy=True)
         o, d = self._dev(ray_o[0]), self._dev(ray_d[0])
         n, f = self._dev(near[0]).clone(), self._dev(far[0]).clone()
         S = self.cfg.MODEL.COARSE_RAY_SAMPLING

@@ -4,7 +4,6 @@
 #include "../../include/dsnerf.h"
 #include "dsn_common.h"
 #include "dsn_kernels.h"
-#include <atomic>
 #include <cstdlib>
 
 #include <stdio.h>
@@ -24,7 +23,6 @@ static int dsn_check_launch(const char* what) {
 #define DSN_REQUIRE(cond, msg) do { if (!(cond)) return dsn_fail("%s", msg); } while (0)
 
 thread_local int g_dsn_persistent_override = 0;
-static std::atomic<float> g_record_fraction{0.125f};      // dsn_record_capacity_fraction
 namespace {
 struct DsnShareCus {      // DSN_SHARE_CUS for the duration of one dsn_render_rays call
     explicit DsnShareCus(bool on) {
@@ -100,7 +98,8 @@ int dsn_set_frame_ex(void* scene, int V, int F, const void* packed, const float*
         return dsn_fail("%s", "dsn_set_frame_ex: copy failed");
     dsn_launch_face_setup(s.xyz, s.faces, F, s.face_world, s.cent_world, st);
     // world-space queries lie inside the (padded) body AABB the rays were clipped to; coarse level beyond
-    dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st, (flags & DSN_FRAME_FINE_ONLY) != 0);
+    dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st, (flags & DSN_FRAME_FINE_ONLY) != 0, false,
+                        (flags & DSN_FRAME_LAZY_LISTS) != 0);
     dsn_launch_pose_setup((const float*)packed, poses24x3, frame_idx, zero_code, light_shift3, rot2x2, rot_center2,
                           s.frame, st);
     return dsn_check_launch("dsn_set_frame_ex");
@@ -477,21 +476,26 @@ static inline size_t dsn_slice_entries(size_t R, int S) {
 }
 // Capacity of the relu-record array of a frame.  The records (224 B per sample) are what the reverse pass needs of the forward
 // pass, only for samples with sigma > 0, so they are indexed by the slot on that list and sized for a FRACTION of the samples of a
-// big frame: an eighth until a caller asks for more (dsn_record_capacity_fraction; round 3: half - 1.9 of the 3.4 GB of a
-// 512 x 512 x 64 frame).  The bench frame puts 11.6 % (hash-random parameters) / 14 % (converged parameters, front-to-back slices)
-// of its samples there, a briefly trained solid 39 %: the host mirror's probe frame sizes it per checkpoint; samples beyond the capacity
-// take the single-launch forward + reverse pass instead (dsn_launch_field16_from): same values, no records, ~10 % more time for them.
-// DSN_RECORD_CAP (tests, or a caller who wants the records of every sample) overrides the capacity.
-static int64_t dsn_record_cap(int64_t N) {
-    const char* e = getenv("DSN_RECORD_CAP");
-    if (e) { const long long v = atoll(e); return v < 1 ? 1 : (v > N ? N : v); }
+// big frame.  The capacity is a property of the WORKSPACE (round 5; rounds 3-4 kept a process-wide fraction): the records are the
+// LAST array of the carve, everything else has a place that depends on (R, S) alone, and the capacity is whatever the caller's
+// workspace_bytes leave behind the fixed part - dsn_render_workspace_bytes_for(R, S, fraction) sizes it, dsn_render_rays_ex reads
+// it back from the size it is handed.  The bench frame puts 11.6 % (hash-random parameters) / 14 % (converged parameters,
+// front-to-back slices) of its samples there, a briefly trained solid 39 %: the host mirror's probe frame sizes each of its
+// workspaces per checkpoint; samples beyond the capacity take the single-launch forward + reverse pass instead
+// (dsn_launch_field16_from): same values, no records, ~10 % more time for them.
+// DSN_RECORD_CAP (tests) lowers the capacity IN USE below what the workspace holds.
+#define DSN_RECORD_FRACTION_DEFAULT 0.125f
+static int64_t dsn_record_cap_for(int64_t N, float fraction) {
     const int64_t floor_ = (int64_t)1 << 21;
     if (N <= floor_) return N;
-    int64_t c = (int64_t)((double)N * (double)g_record_fraction.load());
+    if (!(fraction > 0.0f)) fraction = DSN_RECORD_FRACTION_DEFAULT;
+    if (fraction > 1.0f) fraction = 1.0f;
+    int64_t c = (int64_t)((double)N * (double)fraction);
     c = (c + 255) & ~(int64_t)255;
     return c < floor_ ? floor_ : (c > N ? N : c);
 }
-static DsnWorkspace dsn_carve(void* base, int R, int S) {
+// rec_cap < 0: the fixed part only (w.bytes = where the records begin)
+static DsnWorkspace dsn_carve(void* base, int R, int S, int64_t rec_cap) {
     DsnWorkspace w;
     size_t N = (size_t)R * S;
     char* p = (char*)base;
@@ -505,8 +509,6 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.essence = w.colour = (float*)p;    p += dsn_align256(12 * N + 256);   // E
     w.sort_scratch = (void*)((char*)w.grad + ((8 * N + 15) & ~(size_t)15));      // (16-byte aligned records; E carries 256 bytes of slack)
     w.pos = (int32_t*)p;          p += dsn_align256(4 * N);
-    w.rec_cap = dsn_record_cap((int64_t)N);
-    w.masks = (void*)p;           p += dsn_align256(224 * (size_t)w.rec_cap);
     w.nn_small = (void*)p;        p += dsn_nn_sort_scratch_size((int64_t)N);
     // the density screen's keep list lives from the screen to the forward launch of a slice / frame: inside the field phase, where the
     // normal buffer is free (the geometry phase's sort is done with it, the early-stop shading weights and the normals come later)
@@ -516,27 +518,40 @@ static DsnWorkspace dsn_carve(void* base, int R, int S) {
     w.T = (void*)p;               p += dsn_align256(8 * (size_t)R);
     w.slices = (int32_t*)p;       p += dsn_align256(4 * dsn_slice_entries((size_t)R, S));
     w.alive = (int32_t*)p;        p += dsn_align256(4 * N);
+    // the relu records LAST: nothing else moves with their capacity
+    w.rec_cap = rec_cap < 0 ? 0 : rec_cap;
+    w.masks = (void*)p;           p += dsn_align256(224 * (size_t)w.rec_cap);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
-
-// share of a big frame's samples the relu-record array is sized for (process-wide, only ever grows; see dsnerf.h)
-float dsn_record_capacity_fraction(float at_least) {
-    if (at_least == at_least && at_least > 0.0f) {
-        const float want = at_least > 1.0f ? 1.0f : at_least;
-        float cur = g_record_fraction.load();
-        while (want > cur && !g_record_fraction.compare_exchange_weak(cur, want)) {}
-    }
-    return g_record_fraction.load();
+static size_t dsn_workspace_fixed_bytes(int R, int S) { return dsn_carve(nullptr, R, S, -1).bytes; }
+// records a workspace of `bytes` bytes holds for an R x S frame (-1: not even the fixed part fits)
+static int64_t dsn_record_cap_of(int R, int S, size_t bytes) {
+    const size_t fixed = dsn_workspace_fixed_bytes(R, S);
+    if (bytes < fixed) return -1;
+    const int64_t N = (int64_t)R * S;
+    int64_t c = (int64_t)((bytes - fixed) / 224);
+    if (c > N) c = N;
+    const char* e = getenv("DSN_RECORD_CAP");      // tests: a smaller capacity IN USE (provokes the overflow pass)
+    if (e) { const long long v = atoll(e); c = v < 1 ? (c < 1 ? c : 1) : (v < c ? v : c); }
+    return c;
 }
+
+size_t dsn_render_workspace_bytes_for(int R, int S, float record_fraction) {
+    if (R <= 0 || S <= 0) return 0;
+    return dsn_carve(nullptr, R, S, dsn_record_cap_for((int64_t)R * S, record_fraction)).bytes;
+}
+size_t dsn_render_workspace_bytes(int R, int S) { return dsn_render_workspace_bytes_for(R, S, DSN_RECORD_FRACTION_DEFAULT); }
+int64_t dsn_render_workspace_record_capacity(int R, int S, size_t workspace_bytes) {
+    if (R <= 0 || S <= 0) return -1;
+    return dsn_record_cap_of(R, S, workspace_bytes ? workspace_bytes : dsn_render_workspace_bytes(R, S));
+}
+
+// samples per uniform slice of DSN_EARLY_STOP for an R x S frame (what dsn_render_rays_ex cuts and the DSN_STOP_STATS histogram counts)
+int dsn_stop_slice_len(int R, int S) { return (R > 0 && S > 0) ? dsn_slice_len(R, S) : 0; }
 
 float dsn_early_stop_eps(int S) { return dsn_stop_eps_scaled(S > 0 ? S : 1, 1.0f); }
 float dsn_early_stop_eps_scaled(int S, float colour_scale) { return dsn_stop_eps_scaled(S > 0 ? S : 1, colour_scale); }
-
-size_t dsn_render_workspace_bytes(int R, int S) {
-    if (R <= 0 || S <= 0) return 0;
-    return dsn_carve(nullptr, R, S).bytes;
-}
 
 // the same calibration on the points of a FRAME: see dsnerf.h
 int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, const void* render_workspace, int R, int S,
@@ -544,7 +559,7 @@ int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, co
     DSN_REQUIRE(scene && packed && workspace && render_workspace, "dsn_calibrate_screen_frame: null argument");
     DSN_REQUIRE(V > 0 && F > 0 && n_points > 0 && R > 0 && S > 0, "dsn_calibrate_screen_frame: bad sizes");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    const DsnWorkspace w = dsn_carve((void*)render_workspace, R, S);
+    const DsnWorkspace w = dsn_carve((void*)render_workspace, R, S, -1);      // (the fixed part: x_c, the active list, the count words)
     dsn_launch_calibrate_screen(s, (float*)packed, n_points, workspace, out4, (hipStream_t)stream, w.x_c, w.active, w.count + DSN_CNT_ACTIVE);
     return dsn_check_launch("dsn_calibrate_screen_frame");
 }
@@ -555,13 +570,14 @@ int dsn_render_rays(const void* scene, int V, int F, const void* packed, const f
                     int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
                     float* out_weights, float* out_z, void* workspace, void* stream) {
     return dsn_render_rays_ex(scene, V, F, packed, ray_o, ray_d, near, far, R, S, t_vals, jitter, noise, flags, out_rgb, out_disp, out_acc,
-                              out_depth, out_weights, out_z, workspace, nullptr, 0, stream);
+                              out_depth, out_weights, out_z, workspace, 0, nullptr, 0, stream);
 }
 
 int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                        float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                        int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
-                       float* out_weights, float* out_z, void* workspace, const int32_t* slice_lengths_host, int n_slices, void* stream) {
+                       float* out_weights, float* out_z, void* workspace, size_t workspace_bytes, const int32_t* slice_lengths_host,
+                       int n_slices, void* stream) {
     DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays: empty ray batch");      // (first: empty tensors come with null pointers)
     // front-to-back schedule (DSN_EARLY_STOP): uniform slices by default, the caller's lengths otherwise
     int bounds[DSN_STOP_MAX_SLICES + 1];
@@ -588,9 +604,16 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     DSN_REQUIRE(V > 0 && F > 0, "dsn_render_rays: bad V/F");
     const bool skip = (flags & DSN_SKIP_TRANSPARENT) != 0;
     DSN_REQUIRE(!(skip && noise), "dsn_render_rays: DSN_SKIP_TRANSPARENT is only exact without noise (eval mode)");
+    // rays of more than 32 x 64 samples: a uniform slice would hold more than the 64 samples k_advance_T covers per launch (ADVICE r04:
+    // the transmittance was then only partly advanced - safe, but termination silently did nothing).  Such frames render in one pass.
+    if (!custom_schedule && L > 64) flags &= ~DSN_EARLY_STOP;
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    DsnWorkspace w = dsn_carve(workspace, R, S);
+    // the relu-record capacity is what the caller's workspace holds behind the fixed part (0 = sized by dsn_render_workspace_bytes)
+    const int64_t rec_cap = dsn_record_cap_of(R, S, workspace_bytes ? workspace_bytes : dsn_render_workspace_bytes(R, S));
+    DSN_REQUIRE(rec_cap >= 1, "dsn_render_rays_ex: workspace_bytes is smaller than the fixed part of the workspace + one record "
+                              "(size it with dsn_render_workspace_bytes_for)");
+    DsnWorkspace w = dsn_carve(workspace, R, S, rec_cap);
     const int64_t N = (int64_t)R * S;
     float* z = out_z ? out_z : w.z;
     const DsnShareCus share((flags & DSN_SHARE_CUS) != 0);
@@ -608,12 +631,18 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     const long long cellmajor_min = cm_env ? atoll(cm_env) : (long long)DSN_CELLMAJOR_MIN;
     const bool cellmajor = !exh && N >= (int64_t)cellmajor_min;
     const bool fused_nn = cellmajor && !getenv("DSN_NN_UNFUSED");
+    const bool lazy = (flags & DSN_LAZY_LISTS) != 0;
+    // a lazily set frame (DSN_FRAME_LAZY_LISTS) outside the fused cell-major path: every cell's lists, here, before anything reads them
+    // (small ray batches, DSN_NN_UNFUSED, the exhaustive cross-check)
+    if (lazy && !fused_nn) dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st, true);
     if (fused_nn) {
         // the sampler classifies the samples by fine cell while it writes their z (the first step of the cell-major search)
         int32_t *counts = nullptr, *outside0 = nullptr;
         dsn_nn_cellmajor_begin(w.nn_small, &counts, &outside0, st);
         dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st,
                              s.nn_world.fine.g, (int32_t*)w.grad, counts, outside0, (int32_t*)w.grad + N);      // (+ N: every sample's rank in its cell)
+        // ... and a lazily set frame gets the lists of the cells that classification found samples in (counts > 0)
+        if (lazy) dsn_launch_build_nn_visited(s.cent_world, F, s.nn_world, counts, st);
     } else
         dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     if (skip) {
@@ -633,7 +662,7 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
         } else {
             int32_t* outside = nullptr;
             dsn_launch_nn_cellmajor_warp(s.nn_world, ray_o, ray_d, z, N, S, g3, w.sort_scratch, w.nn_small, s.face_world, s.face_canon,
-                                         w.transparent, w.x_c, list, cnt, skip, &outside, st, true);
+                                         w.transparent, w.x_c, list, cnt, skip, &outside, st, true, lazy);
             dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, w.transparent, w.x_c, nullptr, list, cnt, exh, st,
                             nullptr, skip, g3, outside);
         }
@@ -774,7 +803,7 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     DSN_REQUIRE(!(flags & (DSN_SKIP_TRANSPARENT | DSN_FIELD_FP32)), "dsn_render_rays_train: dense split-fp16 evaluation only");
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
-    DsnWorkspace w = dsn_carve(workspace, R, S);
+    DsnWorkspace w = dsn_carve(workspace, R, S, -1);      // (train mode keeps its records in grad_workspace: the fixed part only)
     const int64_t N = (int64_t)R * S;
     const DsnTrainCache c = dsn_train_cache(grad_workspace, N);
     float* z = out_z ? out_z : w.z;

@@ -30,7 +30,10 @@ struct DsnGrid {            // device-resident descriptor (64 B)
     int total;              // number of list entries
     int cap;                // capacity of the list array (entries)
     int maxcell;
-    int pad_[3];
+    int lazy;               // 0: lists of EVERY cell (ok says whether they fit); 1: grid geometry only, lists still to be built by the frame that
+                            // uses them (dsn_set_frame_ex DSN_FRAME_LAZY_LISTS); 2: lists built for the cells that frame's samples visit -
+                            // valid for that frame's fused search only (ok stays 0: every other query takes the next level / the sweep)
+    int pad_[2];
 };
 
 #define DSN_GRID_GUARD 1e-4f     // metres added on every side of a cell before bounding
@@ -101,6 +104,14 @@ __device__ __forceinline__ float dsn_d2(float px, float py, float pz, const floa
     return d;
 }
 
+// cell index of p in grid g by its geometry alone, or -1 when p is outside the grid
+__device__ __forceinline__ int dsn_grid_cell_geom(const DsnGrid& g, float px, float py, float pz) {
+    float fx = (px - g.lo[0]) * g.inv_cell, fy = (py - g.lo[1]) * g.inv_cell, fz = (pz - g.lo[2]) * g.inv_cell;
+    if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f)) return -1;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    if (ix >= g.nx || iy >= g.ny || iz >= g.nz) return -1;
+    return (ix * g.ny + iy) * g.nz + iz;
+}
 // cell index of p in grid g, or -1 when p is outside the grid / the level is unusable
 __device__ __forceinline__ int dsn_grid_cell(const DsnGrid& g, float px, float py, float pz) {
     if (!g.ok) return -1;
@@ -213,7 +224,8 @@ __device__ __forceinline__ int dsn_nns_classify_one(const DsnGrid* __restrict__ 
     const int lane = threadIdx.x & 63;
     int c = -1;
     if (valid) {
-        c = dsn_grid_cell(*gf, px, py, pz);
+        // (a lazy level - lists still to be built for the cells THIS frame visits - classifies by its geometry)
+        c = gf->lazy ? dsn_grid_cell_geom(*gf, px, py, pz) : dsn_grid_cell(*gf, px, py, pz);
         cell_of[i] = c;
     }
     const NnsRun r = nns_run(c, lane);

@@ -6,7 +6,7 @@
 #include <cstdlib>
 
 __global__ void __launch_bounds__(256) k_grid_params(const float4* __restrict__ cent, int F, float pad,
-                                                      int target_cells, int maxcell, int cap, DsnGrid* __restrict__ g) {
+                                                      int target_cells, int maxcell, int cap, DsnGrid* __restrict__ g, int lazy) {
     __shared__ float s_lo[3][256], s_hi[3][256];
     const int t = threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256) k_grid_params(const float4* __restrict__ 
         g->cell = cell; g->inv_cell = 1.0f / cell;
         g->nx = nx; g->ny = ny; g->nz = nz; g->ncell = nx * ny * nz;
         g->ok = 0; g->total = 0; g->cap = cap; g->maxcell = maxcell;
+        g->lazy = lazy;      // (1: this is all dsn_set_frame_ex does for the level - the frame that uses it builds the lists of the cells it visits)
     }
 }
 
@@ -81,8 +82,11 @@ __device__ __forceinline__ int dsn_super_of(const DsnGrid& g, int cell) {
 
 __global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ cent, int F, const DsnGrid* __restrict__ gp,
                                                      int maxsuper, int32_t* __restrict__ super_cnt,
-                                                     float4* __restrict__ super_list) {
+                                                     float4* __restrict__ super_list, const int32_t* __restrict__ visited) {
+    // visited (optional; the lazy build of a frame, DsnGrid::lazy): per-cell sample counts of the frame - only super-cells with a visited
+    // cell are swept, and only for a level that is waiting for its lists
     const DsnGrid g = *gp;
+    if (visited && !g.lazy) return;
     int sx, sy, sz;
     const int nsuper = dsn_super_dims(g, sx, sy, sz);
     const int sb = blockIdx.x;
@@ -91,6 +95,15 @@ __global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ c
     // union of the guarded cell boxes: lo of the first cell, hi of the last cell (the cells' own expressions)
     const int x0 = kx * DSN_SUPER, y0 = ky * DSN_SUPER, z0 = kz * DSN_SUPER;
     const int x1 = min(x0 + DSN_SUPER, g.nx) - 1, y1 = min(y0 + DSN_SUPER, g.ny) - 1, z1 = min(z0 + DSN_SUPER, g.nz) - 1;
+    if (visited) {
+        int any = 0;
+        if (threadIdx.x < DSN_SUPER * DSN_SUPER * DSN_SUPER) {
+            const int cx = x0 + (int)threadIdx.x / (DSN_SUPER * DSN_SUPER), cy = y0 + ((int)threadIdx.x / DSN_SUPER) % DSN_SUPER,
+                      cz = z0 + (int)threadIdx.x % DSN_SUPER;
+            if (cx <= x1 && cy <= y1 && cz <= z1) any = visited[(cx * g.ny + cy) * g.nz + cz] > 0;
+        }
+        if (!__syncthreads_or(any)) return;
+    }
     float blo[3], bhi[3], t0[3], t1[3];
     dsn_cell_box(g, (x0 * g.ny + y0) * g.nz + z0, blo, t1);
     dsn_cell_box(g, (x1 * g.ny + y1) * g.nz + z1, t0, bhi);
@@ -141,11 +154,17 @@ __device__ __forceinline__ const float4* dsn_cell_source(const DsnGrid& g, int c
 // pass 1+2: U(B)^2 and the list length of every cell (one wavefront per cell)
 __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                      float* __restrict__ u2, int32_t* __restrict__ offsets, int maxsuper,
-                                                     const int32_t* __restrict__ super_cnt, const float4* __restrict__ super_list) {
+                                                     const int32_t* __restrict__ super_cnt, const float4* __restrict__ super_list,
+                                                     const int32_t* __restrict__ visited) {
     const DsnGrid g = *gp;
+    if (visited && !g.lazy) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
+    if (visited && visited[cell] <= 0) {      // (lazy build: a cell no sample of the frame lies in gets an empty list)
+        if (lane == 0) offsets[cell + 1] = 0;
+        return;
+    }
     float blo[3], bhi[3];
     dsn_cell_box(g, cell, blo, bhi);
     int F;
@@ -185,9 +204,10 @@ __device__ __forceinline__ int dsn_block_exscan(int v, int* s_w, int& tot) {
 // Single-workgroup exclusive scan of the per-cell counts (offsets[i + 1] holds count(i) on entry).  The cells go through LDS in
 // tiles with coalesced global accesses; the earlier version walked the array with a stride of `per` cells per thread and
 // scanned the 1024 partial sums with 20 barriers.
-__global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int32_t* __restrict__ offsets) {
+__global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int32_t* __restrict__ offsets, int lazy_build) {
     __shared__ int s_n[1024 * SCAN_PER];
     __shared__ int s_w[16];
+    if (lazy_build && !g->lazy) return;      // (block-uniform: the level holds the lists of every cell already)
     const int n = g->ncell;
     const int t = threadIdx.x;
     int carry = 0;
@@ -206,7 +226,12 @@ __global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int
         carry += tot;
         __syncthreads();
     }
-    if (t == 0) { offsets[0] = 0; g->total = carry; g->ok = (carry <= g->cap) ? 1 : 0; }
+    if (t == 0) {
+        offsets[0] = 0; g->total = carry;
+        // lazy build: `ok` stays 0 - the lists cover the visited cells only, good for the frame's own fused search and nothing else
+        if (lazy_build) g->lazy = (carry <= g->cap) ? 2 : 1;
+        else g->ok = (carry <= g->cap) ? 1 : 0;
+    }
 }
 
 // pass 3: write the lists in ascending face order (ballot compaction keeps the order)
@@ -214,12 +239,13 @@ template <bool INLINE>
 __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                     const float* __restrict__ u2, const int32_t* __restrict__ offsets,
                                                     void* __restrict__ list, int maxsuper, const int32_t* __restrict__ super_cnt,
-                                                    const float4* __restrict__ super_list) {
+                                                    const float4* __restrict__ super_list, const int32_t* __restrict__ visited) {
     const DsnGrid g = *gp;
-    if (!g.ok) return;
+    if (visited ? g.lazy != 2 : !g.ok) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
+    if (visited && visited[cell] <= 0) return;
     float blo[3], bhi[3];
     dsn_cell_box(g, cell, blo, bhi);
     int F;
@@ -241,34 +267,57 @@ __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ ce
 }
 
 static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, float pad, int target, int maxcell, int cap,
-                            bool inline_entries, hipStream_t st) {
+                            bool inline_entries, hipStream_t st, bool params_only = false) {
     const int maxsuper = dsn_grid_maxsuper(maxcell);
     DsnGridView vv = v;
     if (getenv("DSN_NN_NO_SUPER")) vv.super_cnt = nullptr;     // cross-check switch: build with full sweeps
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, st, cent, F, pad, target, maxcell, cap, v.g);
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, st, cent, F, pad, target, maxcell, cap, v.g, params_only ? 1 : 0);
+    if (params_only) return;
+    const int32_t* none = nullptr;
     if (vv.super_cnt)
-        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list);
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
-    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
+    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets, 0);
     if (inline_entries)
         hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
     else
         hipLaunchKernelGGL(k_grid_fill<false>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
+}
+
+// The lists of a LAZY fine level (DsnGrid::lazy = 1 after dsn_set_frame_ex with DSN_FRAME_LAZY_LISTS), for the cells the frame's samples
+// visit: visited[cell] = samples of the frame in that cell (the sampler's classification counts, dsn_nns_classify_one).  Same kernels,
+// same sweeps, same lists entry for entry as the full build - for fewer cells: a 512 x 512 frame's samples visit 48 % of the posed
+// mesh's fine cells, an eighth of its rays (a rank's block of a partitioned frame) a tenth.  No-ops on a level that holds every
+// cell's lists (lazy = 0).
+void dsn_launch_build_nn_visited(const float4* cent, int F, const DsnNNView& nn, const int32_t* visited, hipStream_t st) {
+    const DsnGridView& v = nn.fine;
+    const int maxcell = DSN_NN_FINE_MAXCELL, maxsuper = dsn_grid_maxsuper(maxcell);
+    DsnGridView vv = v;
+    if (getenv("DSN_NN_NO_SUPER")) vv.super_cnt = nullptr;
+    if (vv.super_cnt)
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, visited);
+    hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited);
+    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets, 1);
+    hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
+                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited);
 }
 
 static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // a level that is not built: dsn_grid_cell() answers -1 for every point (ok = 0), queries go on to the next level / the sweep
 __global__ void k_grid_disable(DsnGrid* __restrict__ g) {
-    g->ok = 0; g->ncell = 0; g->total = 0; g->nx = g->ny = g->nz = 0;
+    g->ok = 0; g->ncell = 0; g->total = 0; g->nx = g->ny = g->nz = 0; g->lazy = 0;
     g->cap = 0; g->maxcell = 0;      // (the whole header: the host mirror reads `total` against `cap` - a scene blob starts as uninitialised memory)
 }
 
 void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float pad_fine, float pad_coarse, hipStream_t st,
-                         bool fine_only, bool dense_fine) {
+                         bool fine_only, bool dense_fine, bool lazy) {
+    // lazy (implies fine_only): only the fine grid's geometry - the frame that uses the level builds the lists of the cells its
+    // samples visit (dsn_launch_build_nn_visited, behind the sampler's classification)
     // dense_fine (the canonical mesh: built once, queried by a per-lane list scan in k_normal): as many fine cells as the level
     // holds - shorter lists per query; the posed mesh's lists are rebuilt per frame and stay at 3 F cells
     const int t_fine = dense_fine ? dsn_clampi(5 * F, 512, 62000) : dsn_clampi(3 * F, 512, 44000);
@@ -277,8 +326,8 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
     // through to the coarse level / the sweep, the host mirror warns) on a mesh that fits the real one
     const char* ce = getenv("DSN_NN_FINE_CAP");
     const int fine_cap = ce && atoll(ce) > 0 && atoll(ce) < dsn_nn_fine_cap(F) ? (int)atoll(ce) : dsn_nn_fine_cap(F);
-    dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, fine_cap, true, st);
-    if (fine_only) hipLaunchKernelGGL(k_grid_disable, dim3(1), dim3(1), 0, st, nn.coarse.g);
+    dsn_build_level(cent, F, nn.fine, pad_fine, t_fine, DSN_NN_FINE_MAXCELL, fine_cap, true, st, lazy);
+    if (fine_only || lazy) hipLaunchKernelGGL(k_grid_disable, dim3(1), dim3(1), 0, st, nn.coarse.g);
     else dsn_build_level(cent, F, nn.coarse, pad_coarse, t_coarse, DSN_NN_COARSE_MAXCELL, dsn_nn_coarse_cap(F), false, st);
 }
 
@@ -324,7 +373,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
                                                     int32_t* __restrict__ totals, int keep_counts) {
     __shared__ int s_n[1024 * SCAN_PER];
     __shared__ int s_w[16];
-    const int ncell = gf->ok ? gf->ncell : 0;
+    const int ncell = (gf->ok || gf->lazy == 2) ? gf->ncell : 0;      // (lazy = 2: lists of the visited cells, built for this very search)
     const int t = threadIdx.x;
     int carry_a = 0, carry_b = 0;
     for (int base = 0; base < ncell; base += 1024 * SCAN_PER) {
@@ -356,7 +405,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
 __global__ void __launch_bounds__(NNS_THREADS) k_nns_expand(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ wave_offs,
                                                             const int32_t* __restrict__ totals, int32_t* __restrict__ wave_cell) {
     const int c = blockIdx.x * NNS_THREADS + threadIdx.x;
-    const int ncell = gf->ok ? gf->ncell : 0;
+    const int ncell = (gf->ok || gf->lazy == 2) ? gf->ncell : 0;
     if (c >= ncell) return;
     const int w0 = wave_offs[c], w1 = (c + 1 < ncell) ? wave_offs[c + 1] : totals[0];
     for (int w = w0; w < w1; ++w) wave_cell[w] = c;
@@ -384,11 +433,22 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter(const int32_t* __re
 
 // the same scatter from the ranks the classification kept (dsn_nns_classify_one, rank_of): position = cell offset + rank, no atomics
 // (k_nns_scatter spent its 0.29 ms per 16.8 M samples on them), the per-cell counts stay what the classification counted
-__global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter_ranked(const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter_ranked(int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
                                                                     const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                                     const float* __restrict__ z_vals, int64_t N, int S,
-                                                                    const int32_t* __restrict__ offs, float4* __restrict__ sorted) {
+                                                                    const int32_t* __restrict__ offs, float4* __restrict__ sorted,
+                                                                    const DsnGrid* __restrict__ gf, int32_t* __restrict__ outside) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    if (gf->lazy == 1) {
+        // a lazy level whose visited cells' lists did not fit the capacity (k_grid_scan left lazy = 1; the host mirror sees
+        // total > cap in the header and warns): the cell-major search has nothing to walk - every sample is handed to the k_warp
+        // pass behind it as "outside the fine grid", which sweeps all centroids: the same index, slowly
+        const bool mine = i < N && cell_of[i] >= 0;
+        if (mine) cell_of[i] = -1;
+        const unsigned long long m = __ballot(mine);
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(outside, __popcll(m));
+        return;
+    }
     if (i >= N) return;
     const int c = cell_of[i];
     if (c < 0) return;
@@ -590,7 +650,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
 void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
                                   int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
                                   uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
-                                  int32_t** outside, hipStream_t st, bool classified) {
+                                  int32_t** outside, hipStream_t st, bool classified, bool force_ranked) {
     // classified: the sampler has filled cell_of / counts / the outside counter already (dsn_nn_cellmajor_begin + dsn_launch_sample_gg)
     char* q = (char*)small;
     int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
@@ -607,11 +667,14 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
                            counts, totals + 2);
     }
     // classified by the sampler: it also kept every sample's rank inside its cell (cell_of + N) - the scatter places by rank
-    const bool ranked = classified && !getenv("DSN_NN_ATOMIC_SCATTER");      // (A/B switch: round 3's scatter with atomic cursors)
+    // (DSN_NN_ATOMIC_SCATTER: A/B switch, round 3's scatter with atomic cursors; a lazily built level always takes the ranked form - it
+    //  is the one that hands the samples over when the visited cells' lists did not fit)
+    const bool ranked = classified && (force_ranked || !getenv("DSN_NN_ATOMIC_SCATTER"));
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, ranked ? 1 : 0);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
     if (ranked)
-        hipLaunchKernelGGL(k_nns_scatter_ranked, gN, b, 0, st, cell_of, cell_of + N, ray_o, ray_d, z_vals, N, S, offs, (float4*)sorted);
+        hipLaunchKernelGGL(k_nns_scatter_ranked, gN, b, 0, st, cell_of, (const int32_t*)(cell_of + N), ray_o, ray_d, z_vals, N, S, offs,
+                           (float4*)sorted, (const DsnGrid*)v.fine.g, totals + 2);
     else
         hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;

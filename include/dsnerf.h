@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 5
+#define DSN_ABI_VERSION 6
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -67,6 +67,14 @@ DSN_EXPORT int dsn_set_frame(void* scene, int V, int F, const void* packed, cons
  * all Renderer.render / render_view ever produce, utils/rays_utils.py:63-97 + utils/pts_utils.py:18-58); points beyond it
  * take the exhaustive sweep instead of the coarse lists - the same index, slower for such points, 0.3 ms less per frame. */
 #define DSN_FRAME_FINE_ONLY 1
+/* DSN_FRAME_LAZY_LISTS (ABI 6; implies DSN_FRAME_FINE_ONLY): dsn_set_frame_ex only lays out the fine level's grid; the candidate
+ * lists are built by the frame that uses them - dsn_render_rays[_ex] with DSN_LAZY_LISTS - and only for the cells its own samples
+ * lie in (the sampler classifies the samples by cell while it writes them; the build sits between it and the search).  Same kernels,
+ * same sweeps, same lists entry for entry as the full build, for fewer cells: the samples of a 512 x 512 frame visit 48 % of the
+ * posed mesh's fine cells, a rank's contiguous eighth of a partitioned frame a tenth (0.44 ms of list build per frame -> 0.1).
+ * Such a level answers NO other query (its header keeps ok = 0): dsn_warp / dsn_lbs_warp / dsn_render_rays_train on a lazily set
+ * frame take the exhaustive sweep - the same index, slowly; set the frame without the flag for those. */
+#define DSN_FRAME_LAZY_LISTS 2
 DSN_EXPORT int dsn_set_frame_ex(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
                      int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2, int flags,
                      void* stream);
@@ -306,6 +314,9 @@ DSN_EXPORT int dsn_module_grad(const void* scene, int V, int F, const void* pack
 /* the termination / shading threshold DSN_EARLY_STOP and DSN_STOP_STATS use for rays of S samples (host functions, no device work):
  * dsn_early_stop_eps(S) = dsn_early_stop_eps_scaled(S, 1) */
 DSN_EXPORT float dsn_early_stop_eps(int S);
+/* samples per uniform slice of an R x S frame: 4 on frames of >= 4 M samples, 8 below, S / 32 (rounded up) beyond 32 slices; rays of
+ * more than 2048 samples (a slice would exceed 64 samples) render in one pass whatever the flag says */
+DSN_EXPORT int dsn_stop_slice_len(int R, int S);
 DSN_EXPORT float dsn_early_stop_eps_scaled(int S, float colour_scale);
 /* colour scale c of the early-stop threshold for THESE parameters (stream-ordered write into `packed`; values < 1 count as 1) */
 DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale, void* stream);
@@ -330,19 +341,30 @@ DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale,
  * ... 28 of 32 per XCD on the MI355X) and leaves the rest to the neighbours' small kernels: -1.4 % per frame with three frames in
  * flight, +3 to +6 % for a frame that runs alone (profiles/r03_frames_in_flight.txt) - set it only when frames overlap.  Same values. */
 #define DSN_SHARE_CUS 2048
-/* (The test overrides DSN_RECORD_CAP / DSN_STOP_SLICE change the workspace layout and are read at every call: set them before
- *  the workspace is sized and leave them alone while it is in use.) */
+/* the scene's frame was set with DSN_FRAME_LAZY_LISTS: this call's geometry phase completes the posed mesh's fine lists - for the
+ * cells its samples visit (frames of >= 1 M samples: the cell-major search), for every cell otherwise.  Without the flag a lazily set
+ * frame still renders exactly (every sample takes the exhaustive sweep); with the flag on a fully built level nothing is rebuilt. */
+#define DSN_LAZY_LISTS 4096
+/* (The test override DSN_STOP_SLICE changes the workspace layout and is read at every call: set it before the workspace is sized
+ *  and leave it alone while it is in use.) */
 DSN_EXPORT size_t dsn_render_workspace_bytes(int R, int S);
 /* The relu records the eval-mode reverse pass reads (224 B per sample with sigma > 0) are the largest item of the workspace.  Frames
- * of more than 2 M samples reserve them for a FRACTION of the samples - 1/8 until somebody asks for more (a frame of hash-random
- * parameters puts 12 % of its samples there, the converged checkpoint 14 % with front-to-back slices, a briefly trained solid 39 %:
- * the host mirror's probe frame asks for what its checkpoint needs); samples beyond the capacity are evaluated by a
- * single-launch forward + reverse pass: same values, but their forward pass runs twice.  dsn_record_capacity_fraction(f) raises the
- * fraction to at least f (process-wide, it never shrinks; f <= 0 or NaN only reads it) and returns the value in force: a caller who
- * has seen word 16 of a frame's workspace come near the capacity calls it and re-sizes its workspaces with dsn_render_workspace_bytes
- * (the host mirror does, from its probe frame).  Host function, no device work; not to be called while a frame is being enqueued
- * from another thread. */
-DSN_EXPORT float dsn_record_capacity_fraction(float at_least);
+ * of more than 2 M samples reserve them for a FRACTION of the samples (a frame of hash-random parameters puts 12 % of its samples
+ * there, the converged checkpoint 14 % with front-to-back slices, a briefly trained solid 39 %); samples beyond the capacity are
+ * evaluated by a single-launch forward + reverse pass: same values, but their forward pass runs twice.  The capacity is a property of
+ * the WORKSPACE, not of the process (ABI 6; ABI 5 kept a process-wide fraction): the records are the last array of the workspace and
+ * everything in front of them depends on (R, S) alone, so
+ *   dsn_render_workspace_bytes_for(R, S, f)          bytes of a workspace with records for a fraction f of the samples (f <= 0 or
+ *                                                    NaN: the default 1/8 = dsn_render_workspace_bytes(R, S); frames of <= 2 M
+ *                                                    samples always get records for all of them);
+ *   dsn_render_rays_ex(..., workspace, workspace_bytes, ...)
+ *                                                    takes the capacity from the size it is handed (0 = "sized by
+ *                                                    dsn_render_workspace_bytes(R, S)"); a size below the fixed part fails loudly;
+ *   dsn_render_workspace_record_capacity(R, S, bytes) says what a workspace of that size holds (-1: too small).
+ * A caller who has seen word 16 of a frame's workspace (samples with sigma > 0) come near the capacity gives ITS workspace more -
+ * between frames; two workspaces of one process never size each other.  Host functions, no device work, no state. */
+DSN_EXPORT size_t dsn_render_workspace_bytes_for(int R, int S, float record_fraction);
+DSN_EXPORT int64_t dsn_render_workspace_record_capacity(int R, int S, size_t workspace_bytes);
 DSN_EXPORT int dsn_calibrate_screen_frame(const void* scene, int V, int F, void* packed, const void* render_workspace, int R, int S,
                                int64_t n_points, void* workspace, float* out8, void* stream);
 DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
@@ -357,11 +379,12 @@ DSN_EXPORT int dsn_render_rays(const void* scene, int V, int F, const void* pack
  * `workspace`, hist[g][k] (g = 0 .. K, k = 0 .. K - 1, K = ceil(S / L) uniform slices) = non-transparent samples of slice k on rays whose
  * first slice with T < eps at its start is g (g = K: never) - a group of slices that starts at slice a evaluates slice k >= a on the
  * rays with g > a.  NULL / 0 = uniform slices = dsn_render_rays.  (The host mirror picks the schedule by dynamic programming over
- * that histogram: _lib.choose_stop_schedule.) */
+ * that histogram: _lib.choose_stop_schedule.)  workspace_bytes: see dsn_render_workspace_bytes_for. */
 DSN_EXPORT int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                        float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise,
                        int flags, float* out_rgb, float* out_disp, float* out_acc, float* out_depth,
-                       float* out_weights, float* out_z, void* workspace, const int32_t* slice_lengths_host, int n_slices, void* stream);
+                       float* out_weights, float* out_z, void* workspace, size_t workspace_bytes, const int32_t* slice_lengths_host,
+                       int n_slices, void* stream);
 
 /* diagnostics, NOT for the hot path (synchronises `stream`): {ncell, ok, total entries, capacity} of the four
  * nearest-face list levels (world fine/coarse, canonical fine/coarse) into a HOST array of 16 int32. */

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.dsn_abi_version() == 5
+    assert lib.dsn_abi_version() == 6
     assert lib.dsn_pose_state_bytes() >= 256 + 4 * (64 + 256)          # header + DsnFrameState
     assert lib.dsn_calibrate_workspace_bytes(C.c_int64(1 << 20)) >= (1 << 20) * 28
     assert lib.dsn_packed_param_bytes() > 3_000_000            # fwd + transposed images of ~0.5 M params
@@ -45,10 +45,9 @@ def test_version_and_sizes(lib):
     # per-slice lists sized for the slice length in use, the screen's keep list inside the gradient buffer - and 12 GB for the
     # 1024 x 1024 x 128 frame of configs[3] on ONE GPU (27.3).  The arrays stay indexed by sample.)
     whole, quarter = lib.dsn_render_workspace_bytes(512 * 512, 64), lib.dsn_render_workspace_bytes(512 * 512 // 4, 64)
-    frac = lib.dsn_record_capacity_fraction(C.c_float(0.0)) if hasattr(lib, "dsn_record_capacity_fraction") else 0.125
-    if frac <= 0.126:      # (the fraction is process-wide and only grows: other tests of this process may have raised it)
-        assert 1.45e9 < whole < 1.6e9 and whole / (512 * 512 * 64) < 90
-        assert lib.dsn_render_workspace_bytes(1024 * 1024, 128) < 13e9
+    # (ABI 6: the default fraction is a constant of the library - no process-wide setting another test could have raised)
+    assert 1.45e9 < whole < 1.6e9 and whole / (512 * 512 * 64) < 90
+    assert lib.dsn_render_workspace_bytes(1024 * 1024, 128) < 13e9
     assert 0.24 * whole < quarter < 0.50 * whole              # (at 4 M samples the record array keeps its 2 M-sample floor: half of them)
 
 
@@ -97,10 +96,9 @@ def test_every_entry_point_rejects_null_arguments(lib):
 
 
 def test_round4_host_functions(lib):
-    """the host-side entry points of ABI 5 need no GPU: threshold of the early stop with a colour scale, the slice-schedule checks of
-    dsn_render_rays_ex, the offsets of the nearest-face level headers, the (process-wide, monotone) relu-record capacity fraction"""
+    """the host-side entry points of ABI 5 / 6 need no GPU: threshold of the early stop with a colour scale, the slice-schedule checks of
+    dsn_render_rays_ex, the offsets of the nearest-face level headers, the per-workspace relu-record capacity"""
     lib.dsn_early_stop_eps_scaled.restype = C.c_float
-    lib.dsn_record_capacity_fraction.restype = C.c_float
     cap = 2.0 ** -20
     e1 = lib.dsn_early_stop_eps(64)
     assert e1 == pytest.approx(min(cap, 1e-4 / (2 * 65)), rel=1e-6)
@@ -113,7 +111,7 @@ def test_round4_host_functions(lib):
     # the schedule of dsn_render_rays_ex is checked before anything else is touched
     one = C.c_void_p(64)
     args = lambda lens: (one, 1, 1, one, one, one, one, one, 4, 16, one, None, None, 1 | 64, one, one, one, one, None, None, one,
-                         (C.c_int32 * len(lens))(*lens), len(lens), None)
+                         C.c_size_t(0), (C.c_int32 * len(lens))(*lens), len(lens), None)
     for lens, msg in (([4, 4, 4], b"add up to S"), ([0, 8, 8], b"1 to 64"), ([1] * 33, b"32 slices")):
         assert lib.dsn_render_rays_ex(*args(lens)) != 0 and msg in lib.dsn_last_error(), (lens, lib.dsn_last_error())
     # level headers: four distinct 64-byte slots inside the scene blob, in the order of dsn_debug_nn_stats
@@ -123,12 +121,35 @@ def test_round4_host_functions(lib):
     assert offs == sorted(offs) and len(set(offs)) == 4 and offs[0] > 256 and offs[-1] + 64 <= lib.dsn_scene_bytes(6890, 13776)
     assert all(o % 256 == 0 for o in offs)
     assert lib.dsn_nn_header_offsets(0, 0, off) != 0
-    # record capacity: reading does not change it, it only grows, and the workspace follows it
-    f0 = lib.dsn_record_capacity_fraction(C.c_float(0.0))
-    assert 0.125 <= f0 <= 1.0 and lib.dsn_record_capacity_fraction(C.c_float(float("nan"))) == f0
-    assert lib.dsn_record_capacity_fraction(C.c_float(0.1)) == f0
-    # (not raised here: the setting is process-wide and other tests size their workspaces with it)
-    assert lib.dsn_render_workspace_bytes(512 * 512, 64) >= 1.45e9
+    # ABI 6: the relu-record capacity belongs to the WORKSPACE - its size says what it holds, the library keeps no setting
+    lib.dsn_render_workspace_bytes_for.restype = C.c_size_t
+    lib.dsn_render_workspace_bytes_for.argtypes = [C.c_int, C.c_int, C.c_float]
+    lib.dsn_render_workspace_record_capacity.restype = C.c_int64
+    lib.dsn_render_workspace_record_capacity.argtypes = [C.c_int, C.c_int, C.c_size_t]
+    R, S = 512 * 512, 64
+    N = R * S
+    base = lib.dsn_render_workspace_bytes(R, S)
+    assert base >= 1.45e9
+    assert lib.dsn_render_workspace_bytes_for(R, S, 0.125) == base == lib.dsn_render_workspace_bytes_for(R, S, 0.0) \
+        == lib.dsn_render_workspace_bytes_for(R, S, float("nan"))
+    half, full = lib.dsn_render_workspace_bytes_for(R, S, 0.5), lib.dsn_render_workspace_bytes_for(R, S, 7.0)
+    assert base < half < full == lib.dsn_render_workspace_bytes_for(R, S, 1.0)
+    assert half - base == pytest.approx(224 * (0.5 - 0.125) * N, rel=1e-3)          # nothing but the records moves with the fraction
+    cap = lib.dsn_render_workspace_record_capacity
+    assert cap(R, S, base) == cap(R, S, 0) == N // 8 and cap(R, S, half) == N // 2 and cap(R, S, full) == N == cap(R, S, full + (1 << 30))
+    assert cap(R, S, base - 224 * 1000) == N // 8 - 1000 or cap(R, S, base - 224 * 1000) == N // 8 - 1001      # (256-byte rounding)
+    fixed = base - 224 * (N // 8)
+    assert cap(R, S, fixed - 4096) == -1 and cap(0, S, base) == -1
+    # small frames hold a record for every sample whatever the fraction
+    assert cap(1024, 64, lib.dsn_render_workspace_bytes(1024, 64)) == 1024 * 64
+    # a workspace below the fixed part is refused before anything is touched
+    one = C.c_void_p(64)
+    rr = lambda nbytes: lib.dsn_render_rays_ex(one, 1, 1, one, one, one, one, one, R, S, one, None, None, 1, one, one, one, one, None, None,
+                                               one, C.c_size_t(nbytes), None, 0, None)
+    assert rr(fixed - 4096) != 0 and b"workspace_bytes" in lib.dsn_last_error()
+    # the uniform slice length comes from the library (the binding mirrored it by hand)
+    assert lib.dsn_stop_slice_len(512 * 512, 64) == 4 and lib.dsn_stop_slice_len(4096, 64) == 8 and lib.dsn_stop_slice_len(4096, 512) == 16
+    assert lib.dsn_stop_slice_len(0, 64) == 0
 
 
 def test_no_fallback_without_gpu():

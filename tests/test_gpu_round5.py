@@ -1,0 +1,231 @@
+"""Round-5 GPU tests: nearest-face lists built lazily for the cells a frame visits, per-workspace relu-record capacity, the
+cost-balanced block partition of the metric's own frame, the bench's own frame against the oracle, early stop that enforces its
+bound.  All through the C ABI (ctypes), as everywhere."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from helpers import maxdiff, state
+from test_gpu_round2 import full_frame, renderer_with
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+
+
+def _frame_inputs(r, batch):
+    o, d = r._dev(batch["ray_o"][0]), r._dev(batch["ray_d"][0])
+    return o, d, r._dev(batch["near"][0]), r._dev(batch["far"][0])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# DSN_FRAME_LAZY_LISTS / DSN_LAZY_LISTS: the lists of the cells a frame's samples visit == every cell's lists, for that frame
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nonuniform,wname", [(False, ""), (True, "x_w4")])
+@pytest.mark.parametrize("hw", [256, 48])
+def test_lazy_lists_give_the_same_frame(nonuniform, wname, hw):
+    """hw = 256: 4.2 M samples, the fused cell-major search (visited cells only); hw = 48: below DSN_CELLMAJOR_MIN, where a lazily set
+    frame has every cell's lists built by the render call instead.  Bit-identical outputs, near / far included; a contiguous
+    eighth of the rays (a rank's block of a partitioned frame) likewise; the exhaustive search agrees."""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=hw, nonuniform=nonuniform)
+    r = renderer_with(state(wname) if wname else state(), canon, faces, density_screen=False)
+    r.eval()
+    S = 64
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    pk = r.net.packed(r.device)
+    xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
+
+    def run(lazy, sl=slice(None), **kw):
+        r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=lazy)
+        assert r.scene.lazy == lazy
+        n, f = n0[sl].clone(), f0[sl].clone()
+        out = _lib.render_rays(r.scene, pk, _lib.RenderWorkspace(r.device), o[sl].contiguous(), d[sl].contiguous(), n, f, S, r._t_vals(S), **kw)
+        return out, n, f
+
+    R = hw * hw
+    for sl in (slice(None), slice(3 * R // 8, R // 2)):
+        (a, na, fa), (b, nb, fb) = run(False, sl), run(True, sl)
+        assert torch.equal(na, nb) and torch.equal(fa, fb)
+        for k in a:
+            assert _same(a[k], b[k]), (k, sl)
+        assert float(a["acc_map"].max()) > 0.05
+    ex, _, _ = run(True, exhaustive=True)
+    full, _, _ = run(False)
+    for k in ex:
+        assert _same(ex[k], full[k]), k
+    # a lazily set frame's level answers no other query: the stage call stays exact (exhaustive sweep) ...
+    r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=True)
+    pts, _ = _lib.sample(r.scene, o[:4096].contiguous(), d[:4096].contiguous(), n0[:4096].clone(), f0[:4096].clone(), S, r._t_vals(S), None, want_pts=True)
+    wl = _lib.warp(r.scene, pts[:64], d[:64], S, want_dir=False)
+    r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=False)
+    wf = _lib.warp(r.scene, pts[:64], d[:64], S, want_dir=False)
+    assert torch.equal(wl["x_c"], wf["x_c"]) and torch.equal(wl["transparent"], wf["transparent"])
+
+
+def test_lazy_lists_through_the_renderer():
+    """Renderer sets eval frames lazily (lazy_lists = True, the default): render_view / render / render_views == the same with every
+    cell's lists; a stage call after a lazily rendered frame re-sets the frame and answers from full lists; training is never lazy"""
+    canon, faces, batch = full_frame(hw=256)
+    sd = state("x_w4")
+    r1 = renderer_with(sd, canon, faces, density_screen=False)
+    r2 = renderer_with(sd, canon, faces, density_screen=False)
+    r2.lazy_lists = False
+    for r in (r1, r2):
+        r.eval()
+        r.early_stop = False
+
+    def fresh():
+        b = dict(batch)
+        b["near"], b["far"] = batch["near"].clone(), batch["far"].clone()
+        return b
+
+    a, b = r1.render_view(fresh()), r2.render_view(fresh())
+    assert r1.scene.lazy and not r2.scene.lazy
+    for k in a:
+        assert _same(a[k], b[k]), k
+    va = r1.render_views([fresh(), fresh(), fresh()], frames_in_flight=3, device_output=False)
+    for v in va:
+        for k in a:
+            assert _same(v[k], b[k]), k
+    # stage call on the batch the renderer has just rendered lazily
+    pts = torch.rand(1, 16, 8, 3) * 0.4 + batch["xyz"][0].mean(0)
+    x1, t1 = r1.w2l_without_lbs(pts, batch, r1.canonical_model)
+    assert not r1.scene.lazy
+    x2, t2 = r2.w2l_without_lbs(pts, batch, r2.canonical_model)
+    assert torch.equal(x1, x2) and torch.equal(t1, t2)
+    r1.train()
+    sub = {k: (v[:, :2048].contiguous() if k in ("ray_o", "ray_d", "near", "far") else v) for k, v in fresh().items()}
+    torch.manual_seed(1)
+    out = r1.render(sub)["coarse"]
+    assert not r1.scene.lazy and out["color"].requires_grad
+
+
+def test_lazy_lists_that_do_not_fit_stay_exact_and_warn(monkeypatch):
+    """DSN_NN_FINE_CAP (a smaller logical capacity) provokes the overflow of a lazily built level: the cell-major search hands every
+    sample to the exhaustive pass - same frame bit for bit - and the host mirror reports the level"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=160)          # 1.6 M samples: the fused path
+    r = renderer_with(state(), canon, faces, density_screen=False)
+    r.eval()
+    S = 64
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    pk = r.net.packed(r.device)
+    xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
+
+    def run(lazy):
+        r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=lazy)
+        return _lib.render_rays(r.scene, pk, _lib.RenderWorkspace(r.device), o, d, n0.clone(), f0.clone(), S, r._t_vals(S))
+
+    ref = run(False)
+    monkeypatch.setenv("DSN_NN_FINE_CAP", "200000")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = run(True)
+        torch.cuda.synchronize()
+        r.scene._nn_frames = 1                     # (the header of the frame just rendered is looked at when the next one is set)
+        r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=True)
+        r.scene.nn_watch(wait=True)
+    monkeypatch.delenv("DSN_NN_FINE_CAP")
+    for k in ref:
+        assert _same(ref[k], got[k]), k
+    assert "world_fine" in r.scene.nn_overflow and any("nearest-face level" in str(x.message) for x in w)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# ABI 6: the relu-record capacity belongs to the workspace
+# ------------------------------------------------------------------------------------------------------------------------
+def test_workspaces_size_their_own_records():
+    """VERDICT r04 #8 / ADVICE r04: (1) a workspace asked for more records does not touch another one; (2) a request made between
+    the phase calls of a frame takes effect at the NEXT frame - the buffer the geometry phase filled is the one the field and
+    shading phases read; (3) frames are bit-identical whatever the capacity (overflow pass)"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=384)          # 9.4 M samples: the default capacity is the 2 M-record floor
+    r = renderer_with(state("x_w2"), canon, faces, density_screen=False)      # w2: solid, 39 % of the samples have sigma > 0
+    r.eval()
+    S = 64
+    R = 384 * 384
+    r._set_frame(batch)
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    pk = r.net.packed(r.device)
+    a, b = _lib.RenderWorkspace(r.device), _lib.RenderWorkspace(r.device)
+    ref = _lib.render_rays(r.scene, pk, a, o, d, n0.clone(), f0.clone(), S, r._t_vals(S))
+    n_pos = int(a.buf[:256].view(torch.int32)[_lib.CNT_POS])
+    cap0 = a.record_capacity(R, S)
+    assert cap0 == max(1 << 21, R * S // 8) and n_pos > cap0          # (this frame overflows the default capacity)
+    size_b = b.bytes_for(R, S)
+    a.fit_records(n_pos / float(R * S))
+    assert b.bytes_for(R, S) == size_b and b.want_fraction == 0.125   # (1)
+    # (2) geometry phase, THEN the request, then field + shading on the same buffer
+    out = _lib.render_rays(r.scene, pk, b, o, d, n0.clone(), f0.clone(), S, r._t_vals(S), phases=_lib.PHASE_GEOMETRY)
+    buf = b.buf.data_ptr()
+    b.fit_records(0.9)
+    for ph in (_lib.PHASE_FIELD, _lib.PHASE_SHADE):
+        out = _lib.render_rays(r.scene, pk, b, o, d, n0.clone(), f0.clone(), S, r._t_vals(S), phases=ph, out=out)
+    assert b.buf.data_ptr() == buf and b.record_capacity(R, S) == cap0
+    for k in ref:
+        assert _same(ref[k], out[k]), k
+    big = _lib.render_rays(r.scene, pk, b, o, d, n0.clone(), f0.clone(), S, r._t_vals(S))
+    assert b.record_capacity(R, S) >= int(0.9 * R * S) - 256 and b.buf.data_ptr() != buf
+    fitted = _lib.render_rays(r.scene, pk, a, o, d, n0.clone(), f0.clone(), S, r._t_vals(S))
+    assert a.record_capacity(R, S) >= n_pos
+    for k in ref:                                                        # (3)
+        assert _same(ref[k], big[k]) and _same(ref[k], fitted[k]), k
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the strong-scaling partition of the metric's own frame
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("partition", ["blocks", "tiles"])
+def test_partitioned_512_frame_reassembles_bit_for_bit(partition):
+    """bench.py --strong: the 512 x 512 x 64 frame cut into 8 cost-balanced contiguous blocks (or dealt in
+    round-robin tiles), every share rendered alone - lazily built lists of ITS cells - and put back into ray order through the
+    plan's permutation == the frame rendered in one piece, bit for bit (one pass: every ray's pixel is independent of which other
+    rays share its launch)"""
+    import dsnerf_amd
+    from dsnerf_amd import _lib
+    H = 512
+    canon, faces, batch = full_frame(hw=H)
+    r = renderer_with(state("x_w4"), canon, faces, density_screen=False)
+    r.eval()
+    S = 64
+    R = H * H
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    pk = r.net.packed(r.device)
+    xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
+    ws = _lib.RenderWorkspace(r.device)
+
+    def render(idx, want_weights=False):
+        r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=True)
+        out = _lib.render_rays(r.scene, pk, ws, o[idx].contiguous(), d[idx].contiguous(), n0[idx].clone(), f0[idx].clone(), S,
+                               r._t_vals(S), want_weights=want_weights)
+        px = torch.cat([out["color"], out["disp_map"][:, None], out["acc_map"][:, None], out["depth_map"][:, None]], 1)
+        return (px, out["weights"]) if want_weights else px
+
+    whole, w = render(torch.arange(R, device=r.device), want_weights=True)
+    rp = dsnerf_amd.RayParallel()
+    Nw = 8
+    if partition == "blocks":
+        cost = (w > 1e-6).sum(1).double().cpu() + 3.0
+        bounds = rp.balanced_bounds(cost, Nw)
+        shares = [float(cost[bounds[k]:bounds[k + 1]].sum() / cost.sum()) for k in range(Nw)]
+        assert max(shares) < 1.05 / Nw and len({bounds[k + 1] - bounds[k] for k in range(Nw)}) > 1      # balanced in cost, ragged in rays
+        plan = rp.block_plan(R, bounds, r.device)
+        mine = [torch.arange(bounds[k], bounds[k + 1], device=r.device) for k in range(Nw)]
+    else:
+        plan = rp.tile_plan(R, 2979, r.device, world=Nw)
+        mine = [rp.tile_indices(R, 2979, k, Nw).to(r.device) for k in range(Nw)]
+        assert len({m.numel() // 2979 for m in mine}) == 1            # every rank owns the same number of tiles
+    slab = plan["slab"]
+    allp = torch.zeros(Nw * slab, 6, device=r.device)
+    for k in range(Nw):
+        allp[k * slab: k * slab + mine[k].numel()] = render(mine[k])
+    full = rp.undeal(allp, plan)
+    assert _same(full, whole)
+    assert float(whole[:, 4].max()) > 0.9
