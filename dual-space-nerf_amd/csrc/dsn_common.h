@@ -250,6 +250,18 @@ __host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) 
     const float e = 1e-4f / (2.0f * (float)(S + 1) * c);
     return e < cap ? e : cap;
 }
+// DSN_OWN_SIMD(): the wave's register allocation covers the WHOLE 512-entry register file of its SIMD, so that no wave of another kernel
+// can be resident beside it.  Why (round 5, docs/LAB_NOTEBOOK.md "frames in flight were not bit-identical"): with several frames in
+// flight, waves of the small kernels of one frame (k_normal, k_nns_search, ...: 24-64 registers) that landed on a SIMD beside a wave of
+// the split-fp16 field kernels of another frame (448 registers, so 64 stay free) consumed registers BEFORE their own global loads had
+// landed - 0.2-1 % of a frame's samples came out with a slightly different canonical point or normal, never the same ones twice.  The
+// field kernels themselves are unaffected and stay within their allocation (checked in the ISA); neither a register-heavy spinner, nor
+// LDS-DMA loops, nor MFMA-free builds of the kernel alone reproduce it; a field wave that owns its SIMD does not cause it (0 differing
+// samples in every configuration tested, scripts/dbg/race_*.py).  Two dummy register writes at kernel entry; costs the co-residency of other
+// frames' small kernels on the compute units the persistent field workgroups occupy (they keep the eighth DSN_SHARE_CUS leaves them).
+// (v255 AND a255: 256 architectural + 256 accumulation registers whatever the kernel itself needs - a255 alone sits behind the kernel's own
+//  VGPR count, rounded to 4)
+#define DSN_OWN_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
 #define DSN_SCREEN_MARGIN_DEFAULT 0.01f          // conservative margin of the density screen until it has been calibrated
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
 #define DSN_LO_INV (1.0f / 4096.0f)

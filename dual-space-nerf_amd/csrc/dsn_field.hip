@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(FIELD_THREADS, 1)
 k_field(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c,
         int64_t N, const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
         float* __restrict__ sigma, float* __restrict__ essence, float* __restrict__ grad, const int32_t* __restrict__ flag_count) {
+    DSN_OWN_SIMD();      // (480 registers as it is: 32 would be left for another kernel's waves - see dsn_common.h)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (fix) the split-fp16 launches count what they flag: nothing flagged - the normal case - and there is nothing to look for
     if (FIX && flag_count && *flag_count == 0) return;

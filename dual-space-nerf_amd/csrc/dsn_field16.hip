@@ -575,6 +575,9 @@ k_field16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     __shared__ __attribute__((aligned(16))) float s_vec[256 + 2304 + 8];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
     __shared__ int s_app[8];      // forward kernel: per-wave counts + base of the tile's append to the sigma > 0 list
+#ifndef F16_SHARE_SIMD      // (experiments: -DF16_SHARE_SIMD restores rounds 1-4, where other kernels' waves could sit beside these)
+    DSN_OWN_SIMD();
+#endif
     const int tid0 = threadIdx.x;
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1405,7 +1408,7 @@ __device__ __forceinline__ void layer16s(W16& w, int& blk, int lane, const float
 // NW = 4: 256 threads, two workgroups per CU (58 KB of LDS each).  NW = 8: ONE workgroup of 512 threads per CU - the same eight
 // waves per CU share one weight ring, i.e. half the L2 -> LDS weight traffic per sample (DSN_SCREEN_WAVES selects).
 template <int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
+__global__ void __launch_bounds__(64 * NW, 1)
 k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ x_c, int64_t N,
            const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count, float* __restrict__ sigma,
            int32_t* __restrict__ keep_list, int32_t* __restrict__ keep_count, float* __restrict__ dbg_sigma,
@@ -1416,6 +1419,11 @@ k_screen16(const float* __restrict__ packed, const DsnFrameState* __restrict__ f
     __shared__ __attribute__((aligned(16))) half8 s_pe[4][64 * NW];
     __shared__ int s_cnt[NW];
     __shared__ int s_base;
+#ifndef F16_SHARE_SIMD
+    // no other kernel's wave beside these (dsn_common.h, DSN_OWN_SIMD): the 512-thread form keeps TWO of its own waves per SIMD, 256
+    // registers each; the 256-thread form one
+    if (NW == 8) asm volatile("v_mov_b32 v255, 0" ::: "v255"); else DSN_OWN_SIMD();
+#endif
     const int tid0 = threadIdx.x;
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1658,6 +1666,9 @@ k_screen16x2(const float* __restrict__ packed, const DsnFrameState* __restrict__
     __shared__ __attribute__((aligned(16))) half8 s_pe[2][4][256];
     __shared__ int s_cnt[4];
     __shared__ int s_base;
+#ifndef F16_SHARE_SIMD
+    DSN_OWN_SIMD();
+#endif
     const int tid0 = threadIdx.x;
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2026,7 +2037,7 @@ __device__ __forceinline__ void light_block(const char* __restrict__ blkp, int l
 // 10 TB/s, the kernel was L2-bound (0.41 ms).  Now a workgroup stages the 20 blocks once (72 KB: two workgroups per CU) and walks
 // its tiles of 128 samples with ds_read_b128 operands.  Same products in the same order: bit-identical colours.
 #define LIGHT_LDS_BYTES (4 * 2048 + 16 * 4096)
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 1)
 k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
           const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
           const float* __restrict__ z_vals, const float* essence, int64_t N, int S,
@@ -2037,6 +2048,9 @@ k_light16(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs
     // tr_*: (training forward) the two hidden layers after their ReLU, row-major [N,128], and the pre-activation of the output
     // [N] - what the backward of the lighting MLP needs, so that it does not have to evaluate the MLP again
     __shared__ __attribute__((aligned(16))) char s_w[LIGHT_LDS_BYTES];      // [LT0: 4 x (hi, lo of k-step 0) | LT1: 16 x 4 KB]
+#ifndef F16_SHARE_SIMD
+    DSN_OWN_SIMD();      // (round 5: this kernel too made co-resident waves of other kernels read registers early - dsn_common.h)
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -2159,6 +2173,7 @@ void dsn_launch_light16(const float* packed, const DsnFrameState* fs, const floa
                         float* tr_hl1, float* tr_hl2, float* tr_pre) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_light16, dim3((unsigned)std::min<int64_t>(blocks, 2 * (int64_t)dsn_cu_count())), dim3(256), 0, st, packed, fs, n_w,
+    // (one workgroup per compute unit since round 5: its waves own their SIMDs' register files, two no longer fit)
+    hipLaunchKernelGGL(k_light16, dim3((unsigned)std::min<int64_t>(blocks, (int64_t)dsn_cu_count())), dim3(256), 0, st, packed, fs, n_w,
                        x_w, ray_o, ray_d, z_vals, essence, N, S, active_list, active_count, colour, tr_hl1, tr_hl2, tr_pre);
 }

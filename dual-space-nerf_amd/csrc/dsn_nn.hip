@@ -82,11 +82,11 @@ __device__ __forceinline__ int dsn_super_of(const DsnGrid& g, int cell) {
 
 __global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ cent, int F, const DsnGrid* __restrict__ gp,
                                                      int maxsuper, int32_t* __restrict__ super_cnt,
-                                                     float4* __restrict__ super_list, const int32_t* __restrict__ visited) {
+                                                     float4* __restrict__ super_list, const int32_t* __restrict__ visited, int lazy_build) {
     // visited (optional; the lazy build of a frame, DsnGrid::lazy): per-cell sample counts of the frame - only super-cells with a visited
     // cell are swept, and only for a level that is waiting for its lists
     const DsnGrid g = *gp;
-    if (visited && !g.lazy) return;
+    if (lazy_build && !g.lazy) return;
     int sx, sy, sz;
     const int nsuper = dsn_super_dims(g, sx, sy, sz);
     const int sb = blockIdx.x;
@@ -155,9 +155,9 @@ __device__ __forceinline__ const float4* dsn_cell_source(const DsnGrid& g, int c
 __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                      float* __restrict__ u2, int32_t* __restrict__ offsets, int maxsuper,
                                                      const int32_t* __restrict__ super_cnt, const float4* __restrict__ super_list,
-                                                     const int32_t* __restrict__ visited) {
+                                                     const int32_t* __restrict__ visited, int lazy_build) {
     const DsnGrid g = *gp;
-    if (visited && !g.lazy) return;
+    if (lazy_build && !g.lazy) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
@@ -239,9 +239,9 @@ template <bool INLINE>
 __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                     const float* __restrict__ u2, const int32_t* __restrict__ offsets,
                                                     void* __restrict__ list, int maxsuper, const int32_t* __restrict__ super_cnt,
-                                                    const float4* __restrict__ super_list, const int32_t* __restrict__ visited) {
+                                                    const float4* __restrict__ super_list, const int32_t* __restrict__ visited, int lazy_build) {
     const DsnGrid g = *gp;
-    if (visited ? g.lazy != 2 : !g.ok) return;
+    if (lazy_build ? g.lazy != 2 : !g.ok) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
@@ -275,16 +275,16 @@ static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, flo
     if (params_only) return;
     const int32_t* none = nullptr;
     if (vv.super_cnt)
-        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none);
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none, 0);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
     hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets, 0);
     if (inline_entries)
         hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
     else
         hipLaunchKernelGGL(k_grid_fill<false>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
 }
 
 // The lists of a LAZY fine level (DsnGrid::lazy = 1 after dsn_set_frame_ex with DSN_FRAME_LAZY_LISTS), for the cells the frame's samples
@@ -297,13 +297,14 @@ void dsn_launch_build_nn_visited(const float4* cent, int F, const DsnNNView& nn,
     const int maxcell = DSN_NN_FINE_MAXCELL, maxsuper = dsn_grid_maxsuper(maxcell);
     DsnGridView vv = v;
     if (getenv("DSN_NN_NO_SUPER")) vv.super_cnt = nullptr;
+    if (getenv("DSN_LAZY_ALL_CELLS")) visited = nullptr;      // (cross-check switch: the lazy build for every cell)
     if (vv.super_cnt)
-        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, visited);
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, visited, 1);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1);
     hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets, 1);
     hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited);
+                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1);
 }
 
 static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
