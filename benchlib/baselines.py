@@ -61,6 +61,43 @@ def host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, ray
     return float(np.mean(ms))
 
 
+def host_to_host_pipelined(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S, frames=12, in_flight=3):
+    """The loop the reference's callers run (novel_pose_vis.py:41-66, test.py:55-64: `for batch in loader: render.render_view(batch)`)
+    as ONE Renderer.render_views call over a loader of `frames` HOST batches with `in_flight` frames in flight: host batch -> four HOST
+    images per frame, staging uploads, per-frame set-up, early-stop hand-over checks and downloads included.  Per frame, after one
+    untimed pass over the same loader (a new Renderer's one-off work: probe frame, staging buffers, slots)."""
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
+                          MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0, raw_noise_std=1.0,
+                                                TYPE="nerf", FINE_RAY_SAMPLING=-1))
+    net = dsnerf_amd.DualSpaceNeRF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(dev)
+    r = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+    r.eval()
+    C = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    base = {"ray_o": C(rays["ray_o"])[None], "ray_d": C(rays["ray_d"])[None], "near": C(rays["near"])[None], "far": C(rays["far"])[None],
+            "xyz": C(xyz)[None], "poses": C(poses)[None], "Th": torch.zeros(1, 1, 3), "frame": torch.tensor([5]),
+            "img": torch.zeros(1, H, W, 3, dtype=torch.float64), "mask_at_box": torch.ones(1, H * W, dtype=torch.bool)}
+
+    def loader(n):
+        for _ in range(n):      # (fresh near / far per batch, made with numpy like the product of a DataLoader worker process)
+            b = dict(base)
+            b["near"], b["far"] = torch.from_numpy(base["near"].numpy().copy()), torch.from_numpy(base["far"].numpy().copy())
+            yield b
+
+    for _ in range(4):
+        r.render_view(next(loader(1)))
+    r.render_views(loader(in_flight + 1), frames_in_flight=in_flight, device_output=False)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = r.render_views(loader(frames), frames_in_flight=in_flight, device_output=False)
+    dt = time.perf_counter() - t
+    assert len(out) == frames and not out[0]["coarse_color"].is_cuda
+    return {"ms_per_frame": 1e3 * dt / frames, "frames": frames, "frames_in_flight": in_flight, "early_stop": bool(r.last_frame_info.get("early_stop")),
+            "what": "Renderer.render_views(loader of host batches, device_output=False): host batch -> host images, per frame"}
+
+
 def eager_baseline(args, _lib, synth, dev, chunks=5, train=True):
     """Stand-in for "the reference on one MI355X" (it cannot travel): the differentiable torch restatement the tests
     use as their oracle, run with eager PyTorch-ROCm on this GPU.  The parameter-independent geometry (sampling, both

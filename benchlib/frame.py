@@ -9,12 +9,13 @@ import time
 import numpy as np
 import torch
 
-from .common import LAZY_LISTS, FLOP_ALL_PER_SAMPLE, ROOT, load_weights, _flush_c_stdio
+from .common import (LAZY_LISTS, FLOP_ALL_PER_SAMPLE, FLOP_FIELD_FWD_PER_SAMPLE, FLOP_FIELD_REV_PER_SAMPLE, PEAK_F16_MATRIX_TFLOPS, ROOT,
+                     SPLIT_PRODUCTS, load_weights, _flush_c_stdio)
 
 
 def frame_bench(args, dsnerf_amd, _lib, synth, rk):
     import torch.distributed as dist
-    from .baselines import cpu_baseline, cpu_baseline_torch, eager_baseline, host_to_host
+    from .baselines import cpu_baseline, cpu_baseline_torch, eager_baseline, host_to_host, host_to_host_pipelined
     from .roofline import roofline
     from .train import TRAIN_DTYPE, train_measure, train_roofline
     world, rank, dev, use_dist = rk.world, rk.rank, rk.dev, rk.on
@@ -126,6 +127,16 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
                                    screen=not cur["no_screen"], early_stop=cur["early"], phases=phases,
                                    audit=audit_of.get(j, False), share_cus=share_cus[0], stop_schedule=cur.get("schedule"))
 
+    # what Renderer does behind every sliced frame (round 5): the frame's counter words to page-locked memory, for the hand-over check of
+    # its early-stop bound (largest colour weighed <= the threshold's colour scale) - in the timed loop like everything else it does
+    guard_host = [torch.empty(256, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    guard_seen = {"frames": 0, "largest_colour": 0.0}
+
+    def guard(j):
+        if cur["early"]:
+            guard_host[j].copy_(wss[j].buf[:256], non_blocking=True)
+            guard_seen["frames"] += 1
+
     def exchange(j):
         if use_dist:
             packed_px[j][:, 0:3] = outs[j]["color"]
@@ -151,11 +162,12 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
                 frame_call(j, _lib.PHASE_GEOMETRY)
 
         if pipe is not None:
-            pipe.submit(geometry, lambda: frame_call(j, _lib.PHASE_FIELD), lambda: (frame_call(j, _lib.PHASE_SHADE), exchange(j)))
+            pipe.submit(geometry, lambda: frame_call(j, _lib.PHASE_FIELD), lambda: (frame_call(j, _lib.PHASE_SHADE), guard(j), exchange(j)))
             return
         with torch.cuda.stream(streams[j]):
             geometry()
             frame_call(j)
+            guard(j)
             exchange(j)
 
     def barrier():
@@ -198,12 +210,19 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
     n_active = int(ws.buf[:4].view(torch.int32)[0]) if not args.dense else R * S
     n_pos = int(ws.buf[64:68].view(torch.int32)[0]) if (not args.dense and not args.fp32) else n_active
     n_kept = int(ws.buf[128:132].view(torch.int32)[0]) if (not args.dense and not args.fp32 and not cur["no_screen"]) else n_active
+    n_fwd, n_rev, n_lit = (n_kept if not cur["no_screen"] else n_active), n_pos, n_pos      # one pass: what each network kernel ran on
     if early:       # sliced frame: word 32 holds the last slice's count only; report what the termination left out instead
         st = _lib.read_stop_stats(ws)
         stop_info["skipped_fraction_of_non_transparent"] = st["skipped"] / max(st["active"], 1)
         stop_info["unshaded_fraction_of_positive_density"] = st["unshaded"] / max(n_pos, 1)
         n_kept = None
+        cw_ = ws.buf[:1024].view(torch.int32).cpu()
+        K_ = len(cur["schedule"]) if cur.get("schedule") else (S + _lib.stop_slice_len(R, S) - 1) // _lib.stop_slice_len(R, S)
+        base_ = 128 if not cur["no_screen"] else 96      # (DSN_CNT_KEEP_K / DSN_CNT_ALIVE_K: what the forward launch of slice k ran on)
+        n_fwd = sum(int(cw_[base_ + k]) if (k > 0 or not cur["no_screen"]) else int(cw_[64]) for k in range(K_))
+        n_rev, n_lit = int(cw_[_lib.CNT_SEL]), int(cw_[_lib.CNT_LIT])
     ms_step = 1e3 * dt / args.steps
+    tflop_executed = (n_fwd * FLOP_FIELD_FWD_PER_SAMPLE + n_rev * FLOP_FIELD_REV_PER_SAMPLE) / 1e12
     value = world * R * args.steps / dt
 
     result = {
@@ -221,8 +240,12 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
                         + (" (converged on this body by scripts/train_w4.py: a test-split render of a trained model)" if args.weights == "w4" else ""),
             "rays_per_gpu": R, "samples_per_ray": S,
             "transparent_skip": (not args.dense),
-            "evaluated_sample_fraction": n_active / float(R * S),
-            "shaded_sample_fraction": n_pos / float(R * S),
+            # which share of the R x S samples each stage ran on ("evaluated_sample_fraction" used to be the first of these)
+            "non_transparent_sample_fraction": n_active / float(R * S),
+            "forward_sample_fraction": n_fwd / float(R * S),          # k_field16<forward>: non-transparent, ray still alive, not screened out
+            "reverse_sample_fraction": n_rev / float(R * S),          # k_field16<reverse>: sigma > 0 and weight above the threshold
+            "shaded_sample_fraction": n_lit / float(R * S),           # normals + lighting
+            "positive_density_sample_fraction": n_pos / float(R * S),
             "density_screen": not (args.dense or args.fp32 or cur["no_screen"]),
             "density_screen_calibration": screen_info, "density_screen_audit_every_n_frames": audit_every, "weights": args.weights,
             "accurate_pass_sample_fraction": None if n_kept is None else n_kept / float(R * S),
@@ -233,13 +256,19 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
             "setup_frames_per_slot": 1,      # (untimed, before the W warm-up steps: a slot's first frame carries its one-off costs)
             # every ray is fully rendered, so the dense-equivalent rate is `value`; this is the dense
             # algorithmic work of the frame (2 x 902 272 MAC x R x S) over the frame time
-            "dense_equivalent_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
+            # - work NOT done (transparent / terminated samples) divided by time: never a throughput, it exceeds the chip's peak by design
+            "dense_equivalent_work_rate_NOT_throughput_tflops": FLOP_ALL_PER_SAMPLE * R * S / (ms_step * 1e-3) / 1e12,
             "exchange": "all_gather_into_tensor [R,6] fp32 per rank (RCCL)" if use_dist else "none",
             "per_rank_frames": ("every rank renders the same synthetic frame as the N = 1 line (fixed per-GPU work)" if args.per_rank_frames == "same"
                                 else "rank r renders its own pose (seeds 3 + r, 5 + r): the step waits for the slowest frame"),
         },
         "ranks": rk.info(per_rank_s, args.steps),
         "early_stop": stop_info,
+        # the whole frame against the matrix roofline: field FLOPs actually executed (forward + reverse samples above) over the frame time
+        "whole_frame": {"tflop_executed": tflop_executed, "achieved": tflop_executed / (ms_step * 1e-3),
+                        "peak": PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "unit": "TFLOP/s",
+                        "frac": tflop_executed / (ms_step * 1e-3) / (PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS),
+                        "forward_samples": n_fwd, "reverse_samples": n_rev, "shaded_samples": n_lit},
     }
 
     if rank == 0 and world == 1 and not args.no_extras and not (args.dense or args.fp32):
@@ -300,6 +329,8 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
         cur = headline
         k_step = 0
         result["config"]["by_weights"] = by
+        # (top level: the frame time is a property of the checkpoint - one number per parameter set, same frame, same pipeline)
+        result["ms_per_frame_by_weights"] = {k: v["ms_per_frame"] for k, v in by.items()}
         share_cus[0] = False
         result["config"]["by_weights_note"] = ("same frame and pipeline for every parameter set, Renderer's defaults (density screen off, early "
                                                "stop decided by the probe frame); default = hash-random init (thin fog), w2 = 400 reference-"
@@ -335,6 +366,8 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
         ex["host_to_host_ms"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
         ex["host_to_host_ms_after_a_caller_torch_cpu_op"] = host_to_host(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S,
                                                                          caller_torch_op=True)
+        # ... and the loop the callers run: a sequence of host batches through render_views, three frames in flight
+        ex["host_to_host_ms_pipelined"] = host_to_host_pipelined(args, dsnerf_amd, synth, dev, canon, faces, sd, xyz, poses, rays, H, W, S)
         ex["host_threads"] = torch.get_num_threads()
         ex["host_cpu_quota_cores"] = _lib.cpu_quota_cores()
         # the per-sample workspace is the caller's to size: the same render_view in four ray chunks (the reference's own loop runs

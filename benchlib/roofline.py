@@ -160,6 +160,27 @@ def roofline(_lib, scene, packed, ray_o, ray_d, near0, far0, S, t_vals, args, ea
         # forward (achieved = average samples per launch x 0.918 MFLOP / average launch time); the single whole-frame launch measured
         # above moves to `single_launch`
         single = {k: out[k] for k in ("kernel", "achieved", "frac", "kernel_ms", "samples_per_launch", "x_fp32_matrix_peak")}
+        # ... and the reverse kernel as the sliced frames run it: on the samples whose weight passes the threshold (workspace word 13),
+        # a prefix of the sigma > 0 list of the single-launch pass (records of every slot exist); the one-pass figure moves to `single_launch`
+        n_sel = int(cw[_lib.CNT_SEL])
+        if n_sel > 0 and "reverse_kernel" in out:
+            scnt = torch.tensor([min(n_sel, n_pos)] + [0] * 15, dtype=torch.int32, device=dev)
+            t_rs = []
+            for i in range(reps + 2):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                rc = L.dsn_field_reverse(*a0, _lib._ptr(pos), _lib._ptr(scnt), _lib._ptr(rec), _lib._ptr(g), _lib._ptr(sig), _lib._ptr(ess), _lib._stream())
+                b_.record()
+                assert rc == 0, L.dsn_last_error()
+                torch.cuda.synchronize()
+                if i >= 2:
+                    t_rs.append(a_.elapsed_time(b_))
+            ms_rs = float(np.mean(t_rs))
+            ach_rs = min(n_sel, n_pos) * FLOP_FIELD_REV_PER_SAMPLE / (ms_rs * 1e-3) / 1e12
+            single["reverse_kernel"] = out["reverse_kernel"]
+            out["reverse_kernel"] = {"kernel": "k_field16<reverse> on the samples a sliced frame shades", "kernel_ms": ms_rs,
+                                     "samples_per_launch": min(n_sel, n_pos), "flop_per_sample": FLOP_FIELD_REV_PER_SAMPLE, "achieved": ach_rs,
+                                     "frac": ach_rs / peak}
         rp_ms, rp_src, rp_calls = rocprof_kernel_ms("k_field16ILi1E", args, drop_largest=1)
         traffic, traffic_src = measured_traffic("k_field16<forward>", args)
         out.update({"kernel": "k_field16<forward>, one launch per front-to-back slice (DSN_EARLY_STOP): per-launch averages of a frame",

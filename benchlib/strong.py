@@ -92,6 +92,7 @@ class Share:
         self.outs = [None] * slots.depth
         self.px = [torch.zeros(slab, 6, dtype=torch.float32, device=dev) for _ in range(slots.depth)]
         self.screen = bool(screen)
+        self.guard_host = [torch.empty(256, dtype=torch.uint8).pin_memory() for _ in range(slots.depth)]
         self.stop_on, self.schedule, self.stop_info = False, None, {"enabled": False}
         for j in range(slots.depth):      # (set-up: every slot's workspace exists and has been touched before anything is timed)
             slots.wss[j].get(self.Rl, frame.S).zero_()
@@ -123,6 +124,8 @@ class Share:
         out = self.outs[j] = L.render_rays(sl.scenes[j], f.packed, sl.wss[j], self.o, self.d, self.nears[j], self.fars[j], f.S, f.t_vals,
                                            None, None, want_weights=False, out=self.outs[j], screen=self.screen,
                                            early_stop=self.stop_on, stop_schedule=self.schedule, share_cus=share_cus)
+        if self.stop_on:      # (Renderer's hand-over check of a sliced frame: its counter words to page-locked memory, behind the frame)
+            self.guard_host[j].copy_(sl.wss[j].buf[:256], non_blocking=True)
         px = self.px[j]
         px[:self.Rl, 0:3] = out["color"]
         px[:self.Rl, 3] = out["disp_map"]

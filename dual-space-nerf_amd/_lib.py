@@ -40,7 +40,7 @@ EXPORTS = [
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
     "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_render_workspace_bytes_for",
-    "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_render_rays_ex",
+    "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_early_stop_colour_headroom", "dsn_render_rays_ex",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -82,6 +82,7 @@ def lib():
         L.dsn_last_error.restype = C.c_char_p
         L.dsn_early_stop_eps.restype = C.c_float
         L.dsn_early_stop_eps_scaled.restype = C.c_float
+        L.dsn_early_stop_colour_headroom.restype = C.c_float
         L.dsn_render_workspace_record_capacity.restype = C.c_int64
         L.dsn_render_workspace_record_capacity.argtypes = [C.c_int, C.c_int, C.c_size_t]
         L.dsn_render_workspace_bytes_for.argtypes = [C.c_int, C.c_int, C.c_float]

@@ -202,7 +202,9 @@ class Renderer:
         # True forces it from the first frame (c = 1 until a frame has been looked at), False switches it off.
         self.early_stop = "auto"
         self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
-        self._colour_probe = None         # (packed generation, count words, event) of a sliced frame whose colour maximum is still to be read
+        self._guards = []                 # counter copies of the sliced frames enqueued since the last hand-over (_stop_guard)
+        self._guard_pool = []             # page-locked 256-byte buffers for them
+        self._one_pass_only = False       # set while a frame that broke its early-stop bound is rendered again
         # "auto": the slice lengths of sliced frames follow the probe frame's statistics (longer slices where few rays end: fewer
         # launches, a few more samples, the same error bound - dsn_render_rays_ex); None: uniform slices of 4 / 8 samples
         self.stop_schedule = "auto"
@@ -493,6 +495,7 @@ class Renderer:
             out = dict(zip(_OUT_KEYS, outs))
         else:
             out = self._render_eval(self.scene, self._ws, o, d, near, far, S, jitter, noise)
+            out = self._hand_over(out, lambda: self._render_eval(self.scene, self._ws, o, d, near, far, S, jitter, noise))
         if batch["near"].is_cuda:   # in-place semantics of the reference when the batch already lives on the device
             batch["near"][0].copy_(near)
             batch["far"][0].copy_(far)
@@ -510,8 +513,7 @@ class Renderer:
             screen = skip and noise is None and self._screen_usable()
         packed = self.net.packed(self.device)
         stop, stats = False, False
-        if skip and noise is None:
-            self._read_colour_probe()
+        if skip and noise is None and not self._one_pass_only:
             if self.early_stop == "auto":
                 if packed.early_stop is None:
                     if self._stop_probe is None:
@@ -568,13 +570,13 @@ class Renderer:
             ev.record()
             self._stop_probe = (packed.generation, snap, ev)
         if plan["early_stop"] and (phases == 0 or phases & _lib.PHASE_SHADE):
-            # the colours of sliced frames are watched: every SCREEN_AUDIT_EVERY-th one leaves its largest weighed colour for a later look
-            if self._colour_probe is None and self._stop_frames % SCREEN_AUDIT_EVERY == 0:
-                self._watch_samples = int(o.shape[0]) * int(S)
-                snap = ws.buf[:256].clone()
-                ev = torch.cuda.Event()
-                ev.record()
-                self._colour_probe = (packed.generation, snap, ev)
+            # EVERY sliced frame leaves its counters for the caller's hand-over point (_stop_guard_ok): the bound of early stop holds for
+            # colours up to the scale its threshold was computed with - a frame that weighed a larger colour is rendered again in one
+            # pass BEFORE it is handed to the caller (round 4 looked at every 8th frame and only raised the scale for
+            # later ones)
+            self._guards.append(self._stop_guard(ws, cs, int(o.shape[0]) * int(S)))
+            while len(self._guards) > 64:      # (a caller of batchify_rays_view / render_rays that never reaches a hand-over point)
+                self._guard_pool.append(self._guards.pop(0)[0])
             self._stop_frames += 1
         if plan["audit"] and self.screen_audit == "auto" and (phases == 0 or phases & _lib.PHASE_SHADE):
             snap = ws.buf[:256].clone()
@@ -624,7 +626,7 @@ class Renderer:
         n_pos = int(snap.view(torch.int32)[_lib.CNT_POS])
         if getattr(self, "_probe_samples", 0) > 0:
             # (the probe frame is one pass; with termination in use the sliced frames list far fewer samples: estimated by what it leaves
-            #  out, corrected by the sliced frames themselves in _read_colour_probe, covered by the exact overflow pass in between)
+            #  out, corrected by the sliced frames themselves at their hand-over (_stop_guards_ok), covered by the exact overflow pass in between)
             will_stop = frac >= _lib.EARLY_STOP_MIN_SKIPPED if self.early_stop == "auto" else bool(self.early_stop)
             self._fit_records(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0), 1.6 if will_stop else 1.25)
         self._note_colour_max(packed, st["colour_max"], first=True)
@@ -658,28 +660,62 @@ class Renderer:
             if want > packed.colour_scale:
                 packed.set_early_stop_colour_scale(want)
         elif cmax > packed.colour_scale:
-            warnings.warn("dsnerf_amd: a sliced frame weighed colours up to %.3g, above the scale %.3g of the early-stop threshold: "
-                          "frames since the last look may be off by up to %.2g instead of 5e-5; scale raised to %.3g"
+            warnings.warn("dsnerf_amd: a sliced frame weighed colours up to %.3g, above the scale %.3g of the early-stop threshold (its "
+                          "bound would be %.2g instead of 5e-5): the frame is rendered again in one pass, scale raised to %.3g"
                           % (cmax, packed.colour_scale, 5e-5 * cmax / packed.colour_scale, want))
             packed.set_early_stop_colour_scale(want)
             if packed.early_stop is not None:
                 packed.early_stop["colour_scale"] = packed.colour_scale
 
-    def _read_colour_probe(self, wait=False):
-        if self._colour_probe is None:
-            return
-        gen, snap, ev = self._colour_probe
-        if not wait and not ev.query():
-            return
-        ev.synchronize()
-        self._colour_probe = None
+    def _stop_guard(self, ws, scale, n_samples):
+        """enqueue the copy of a sliced frame's counter words (largest colour weighed, samples on the sigma > 0 list) to page-locked
+        memory behind the frame, on its stream: (host words, event, colour scale the frame's threshold used, samples, generation)"""
+        pool = self._guard_pool
+        host = pool.pop() if pool else torch.empty(256, dtype=torch.uint8).pin_memory()
+        host.copy_(ws.buf[:256], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (host, ev, float(scale), int(n_samples), self.net.packed(self.device).generation)
+
+    def _stop_guards_ok(self, guards):
+        """the hand-over check of sliced frames (waits for their counter copies - the frames themselves are done or about to be):
+        True when every one of them stayed below the colour scale its threshold assumed.  Otherwise the scale is raised (warning) and
+        the caller renders the frame again in one pass.  Also feeds the record capacity with what sliced frames really list."""
+        ok = True
         packed = self.net.packed(self.device)
-        if packed.generation != gen:
-            return
-        c = snap.view(torch.int32).cpu()
-        self._note_colour_max(packed, float(c[_lib.CNT_COLOUR_MAX:_lib.CNT_COLOUR_MAX + 1].view(torch.float32)[0]))
-        if getattr(self, "_watch_samples", 0) > 0:      # what the sliced frames really put on the sigma > 0 list
-            self._fit_records(int(c[_lib.CNT_POS]) / float(self._watch_samples))
+        for host, ev, scale, n_samples, gen in guards:
+            ev.synchronize()
+            c = host.view(torch.int32)
+            cmax = float(c[_lib.CNT_COLOUR_MAX:_lib.CNT_COLOUR_MAX + 1].view(torch.float32)[0])
+            n_pos = int(c[_lib.CNT_POS])
+            self._guard_pool.append(host)
+            if gen != packed.generation:
+                continue
+            if n_samples > 0:
+                self._fit_records(n_pos / float(n_samples))
+            if not (cmax <= scale):                       # (NaN / inf included)
+                ok = False
+                self._note_colour_max(packed, cmax)
+        return ok
+
+    def _hand_over(self, first, again, guards=None):
+        """`first` is a frame that has been enqueued; before it goes to the caller the early-stop guards of its sliced render calls are
+        looked at (their counter copies sit right behind the compositor on the frame's stream).  A frame that weighed a colour above
+        the scale its threshold assumed is rendered AGAIN, in one pass (`again()`), and that is what the caller gets: the stated bound
+        of early stop - 5e-5 absolute - then holds for every frame handed out, not only while the colours stay where the probe frame
+        found them (VERDICT r04 #6)."""
+        if guards is None:
+            guards, self._guards = self._guards, []
+        if not guards or self._stop_guards_ok(guards):
+            return first
+        self._one_pass_only = True
+        try:
+            res = again()
+        finally:
+            self._one_pass_only = False
+            self._guards = []
+        self.last_frame_info = dict(self.last_frame_info, rendered_again_in_one_pass=True)
+        return res
 
     def last_screen_audit(self, ws=None):
         """what the audit of the last audited eval frame found - synchronises.  dict(audited, violations, max_sigma): `violations`
@@ -772,8 +808,9 @@ class Renderer:
 
     def _render_view(self, batch, chunk, device_output):
         img = self._view_images(batch, chunk, self.scene, self._ws)
+        again = lambda: self._view_images(batch, chunk, self.scene, self._ws)
         if device_output:
-            return img
+            return self._hand_over(img, again)
         # four contiguous device images -> one persistent page-locked staging set (asynchronous copies, one synchronisation),
         # then fresh host tensors like the reference's `.cpu()` results.  A pageable `.cpu()` per image goes through the runtime's
         # own bounce buffers and varies between 1 and 20 ms per frame on the GPU boxes (scripts/d2h_probe.py);
@@ -785,6 +822,11 @@ class Renderer:
         for k in keys:
             stage[k].copy_(img[k], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
+        checked = self._hand_over(img, again)      # (the guards' copies have landed with the images: no extra wait in the normal case)
+        if checked is not img:
+            for k in keys:
+                stage[k].copy_(checked[k], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
         # fresh pageable tensors (clone() of a page-locked tensor allocates page-locked memory again: 2-3 ms per image), copied
         # by one thread (see _dev)
         return {k: torch.from_numpy(stage[k].numpy().copy()) for k in keys}
@@ -817,11 +859,16 @@ class Renderer:
         #  scene and its frame is enqueued first)
         keys = ("coarse_color", "coarse_disp", "coarse_acc", "coarse_depth")
         results = []
+        pending = []                       # (frame index, batch, its early-stop guards)
+        self._guards = []
         for k, batch in enumerate(batches):
             slot = slots[k % n]
             slot.stream.wait_stream(cur)
             with torch.cuda.stream(slot.stream):
                 img = self._view_images(batch, chunk, slot.scene, slot.ws)
+                if self._guards:
+                    pending.append((k, batch, self._guards))
+                    self._guards = []
                 if not device_output:
                     host = {kk: torch.empty(img[kk].shape, dtype=torch.float32).pin_memory() for kk in keys}
                     for kk in keys:
@@ -836,6 +883,14 @@ class Renderer:
         if not device_output:
             torch.cuda.current_stream(self.device).synchronize()
         self._frame_src = None      # slot 0 shares the renderer's scene: it now holds the last frame slot 0 rendered
+        # hand-over: every sliced frame's guard is looked at (this waits for the frames' compositors - the images of a device_output
+        # call are then all but done); a frame that broke its bound is rendered again, alone, in one pass
+        for k, batch, guards in pending:
+            again = lambda b=batch: self._render_view(b, chunk, device_output)
+            checked = self._hand_over(results[k], again, guards=guards)
+            if checked is not results[k]:
+                self._frame_src = None
+                results[k] = checked
         return results
 
     def image_metrics(self, color_img, batch, clamp=True):

@@ -550,6 +550,7 @@ int64_t dsn_render_workspace_record_capacity(int R, int S, size_t workspace_byte
 // samples per uniform slice of DSN_EARLY_STOP for an R x S frame (what dsn_render_rays_ex cuts and the DSN_STOP_STATS histogram counts)
 int dsn_stop_slice_len(int R, int S) { return (R > 0 && S > 0) ? dsn_slice_len(R, S) : 0; }
 
+float dsn_early_stop_colour_headroom(void) { return DSN_STOP_COLOUR_HEADROOM; }
 float dsn_early_stop_eps(int S) { return dsn_stop_eps_scaled(S > 0 ? S : 1, 1.0f); }
 float dsn_early_stop_eps_scaled(int S, float colour_scale) { return dsn_stop_eps_scaled(S > 0 ? S : 1, colour_scale); }
 
@@ -786,7 +787,7 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
                          out_weights, out_depth, st, skip, skip ? w.count + DSN_CNT_STOP + 3 : nullptr);
     if ((flags & DSN_STOP_STATS) && skip)
         dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(R, S), (const float*)packed + OFF_SCAL,
-                              w.count + DSN_CNT_STOP + 2, st, w.count + DSN_CNT_HIST);
+                              w.count + DSN_CNT_STOP + 2, st, w.count + DSN_CNT_HIST, w.count + DSN_CNT_STOP + 3);
     }       // shading phase
     return dsn_check_launch("dsn_render_rays");
 }

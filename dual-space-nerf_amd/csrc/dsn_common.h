@@ -244,6 +244,7 @@ __host__ __device__ inline size_t dsn_stream16_index(int gb, int hw) {
 // terminated tail of total weight < eps), so eps shrinks with S AND with the colour scale c of the loaded parameters
 // (packed[OFF_SCAL + 6], dsn_set_early_stop_colour_scale; 1 until measured): eps = min(2^-20, 1e-4 / (2 (S + 1) max(1, c))) - half of
 // the 1e-4 parity bar, absolute, as long as the colours stay below c (colour = (ELU + 1) x essence is unbounded)
+#define DSN_STOP_COLOUR_HEADROOM 2.0f      // colour scale handed to the threshold = this x the largest colour seen (dsn_early_stop_colour_headroom)
 __host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) {
     const float cap = 9.5367431640625e-07f;      // 2^-20
     const float c = colour_scale > 1.0f ? colour_scale : 1.0f;

@@ -1062,7 +1062,7 @@ __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ po
 __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                      const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
                                                      int L, const float* __restrict__ scal, int32_t* __restrict__ out,
-                                                     int32_t* __restrict__ hist) {
+                                                     int32_t* __restrict__ hist, const int32_t* __restrict__ colour_max) {
     __shared__ int s_h[(DSN_STOP_MAX_SLICES + 1) * DSN_STOP_MAX_SLICES];
     const int K = (S + L - 1) / L;
     if (hist) {
@@ -1070,7 +1070,12 @@ __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ si
         __syncthreads();
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
-    const float eps = dsn_stop_eps_scaled(S, scal[6]);
+    // the threshold the sliced frames of these parameters will run with: colour scale = max(the scale in `packed`, DSN_STOP_COLOUR_HEADROOM
+    // x the largest colour THIS frame's compositor weighed) - what the caller sets from this very frame (the statistics
+    // used the unscaled threshold, the frames decided by them a smaller one)
+    float cs = scal[6];
+    if (colour_max) { const float c = DSN_STOP_COLOUR_HEADROOM * __int_as_float(*colour_max); if (c > cs) cs = c; }
+    const float eps = dsn_stop_eps_scaled(S, cs);
     int skipped = 0;
     if (r < R) {
         float t = 1.0f;
@@ -1145,8 +1150,8 @@ void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N
                        lit_count, culled, colour);
 }
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist) {
-    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out, hist);
+                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist, const int32_t* colour_max) {
+    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out, hist, colour_max);
 }
 
 // ---------------------------------------------------------------------------------------------

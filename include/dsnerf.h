@@ -318,6 +318,10 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
  * more than 2048 samples (a slice would exceed 64 samples) render in one pass whatever the flag says */
 DSN_EXPORT int dsn_stop_slice_len(int R, int S);
 DSN_EXPORT float dsn_early_stop_eps_scaled(int S, float colour_scale);
+/* the factor between the largest colour a frame weighed (word 59 of its workspace) and the colour scale a caller should set from it:
+ * 2.  DSN_STOP_STATS applies it itself: its counts and histogram use the threshold for max(the scale in `packed`, 2 x the frame's own
+ * largest colour) - the threshold the sliced frames decided by them will run with. */
+DSN_EXPORT float dsn_early_stop_colour_headroom(void);
 /* colour scale c of the early-stop threshold for THESE parameters (stream-ordered write into `packed`; values < 1 count as 1) */
 DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale, void* stream);
 /* statistics for the caller's decision whether DSN_EARLY_STOP pays (a frame rendered WITHOUT it): word 58 of `workspace` =

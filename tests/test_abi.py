@@ -147,6 +147,9 @@ def test_round4_host_functions(lib):
     rr = lambda nbytes: lib.dsn_render_rays_ex(one, 1, 1, one, one, one, one, one, R, S, one, None, None, 1, one, one, one, one, None, None,
                                                one, C.c_size_t(nbytes), None, 0, None)
     assert rr(fixed - 4096) != 0 and b"workspace_bytes" in lib.dsn_last_error()
+    lib.dsn_early_stop_colour_headroom.restype = C.c_float
+    import dsnerf_amd
+    assert lib.dsn_early_stop_colour_headroom() == dsnerf_amd._lib.EARLY_STOP_COLOUR_HEADROOM == 2.0
     # the uniform slice length comes from the library (the binding mirrored it by hand)
     assert lib.dsn_stop_slice_len(512 * 512, 64) == 4 and lib.dsn_stop_slice_len(4096, 64) == 8 and lib.dsn_stop_slice_len(4096, 512) == 16
     assert lib.dsn_stop_slice_len(0, 64) == 0

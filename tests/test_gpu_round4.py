@@ -70,9 +70,9 @@ def test_renderer_measures_the_colour_scale_on_its_probe_frame():
     cmax = info["colour_max"]
     for k in ("coarse_color", "coarse_acc"):
         assert float((a[k] - b[k]).abs().max()) < 1e-4 + 2e-6 * cmax, k
-    # the watch: a sliced frame's colours are looked at again and never lower the scale
-    r._read_colour_probe(wait=True)
-    assert pk.colour_scale >= _lib.EARLY_STOP_COLOUR_HEADROOM * info["colour_max"] * (1 - 1e-6)
+    # the hand-over check of the sliced frame (round 5: every sliced frame, before it is returned) never lowers the scale
+    assert not r._guards and pk.colour_scale >= _lib.EARLY_STOP_COLOUR_HEADROOM * info["colour_max"] * (1 - 1e-6)
+    assert "rendered_again_in_one_pass" not in r.last_frame_info
 
 
 @pytest.mark.parametrize("S", [64, 40])
