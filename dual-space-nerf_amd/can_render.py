@@ -199,7 +199,7 @@ class Renderer:
         # leave out (DSN_STOP_STATS) and how large its colours are; from the next frame on it is used if it leaves out at least
         # _lib.EARLY_STOP_MIN_SKIPPED of the non-transparent samples, with c = 2 x the largest colour seen (every
         # SCREEN_AUDIT_EVERY-th sliced frame is looked at again, without a wait: larger colours raise c, with a warning).
-        # True forces it from the first frame (c = 1 until a frame has been looked at), False switches it off.
+        # True: the same probe frame, then sliced whatever it leaves out; False switches it off.
         self.early_stop = "auto"
         self._stop_probe = None           # (packed generation, count words, event) of a frame whose statistics are still to be read
         self._guards = []                 # counter copies of the sliced frames enqueued since the last hand-over (_stop_guard)
@@ -507,19 +507,23 @@ class Renderer:
         """per-frame decisions of an eval-mode frame (needs the scene's frame state for a first calibration): keyword arguments
         of _lib.render_rays"""
         skip = self.skip_transparent and not self.net.training
-        if skip and noise is None and self.early_stop == "auto":
+        if skip and noise is None and self.early_stop in ("auto", True):
             self._read_stop_probe()      # (first: whether the screen pays depends on it)
         if screen is None:
             screen = skip and noise is None and self._screen_usable()
         packed = self.net.packed(self.device)
         stop, stats = False, False
         if skip and noise is None and not self._one_pass_only:
-            if self.early_stop == "auto":
+            if self.early_stop in ("auto", True):
+                # the first eval frame of a parameter version is rendered in one pass and measures: what termination would leave out,
+                # how large the colours are (-> the threshold's colour scale), the slice schedule.  "auto" then slices when it pays;
+                # True slices whenever the colours are finite (round 5: it used to slice from the first frame on with the scale 1, which
+                # the hand-over check now refuses for any checkpoint whose colours exceed 1)
                 if packed.early_stop is None:
                     if self._stop_probe is None:
                         stats = True
                 else:
-                    stop = packed.early_stop["usable"]
+                    stop = packed.early_stop["usable"] if self.early_stop == "auto" else packed.early_stop.get("finite", True)
             else:
                 stop = bool(self.early_stop)
         audit = False
@@ -630,7 +634,9 @@ class Renderer:
             will_stop = frac >= _lib.EARLY_STOP_MIN_SKIPPED if self.early_stop == "auto" else bool(self.early_stop)
             self._fit_records(n_pos / float(self._probe_samples) * ((1.0 - frac) if will_stop else 1.0), 1.6 if will_stop else 1.25)
         self._note_colour_max(packed, st["colour_max"], first=True)
-        packed.early_stop = {"skipped_fraction": frac, "usable": frac >= _lib.EARLY_STOP_MIN_SKIPPED,
+        cm = st["colour_max"]
+        finite = cm == cm and cm != float("inf")
+        packed.early_stop = {"skipped_fraction": frac, "usable": finite and frac >= _lib.EARLY_STOP_MIN_SKIPPED, "finite": finite,
                              "colour_max": st["colour_max"], "colour_scale": packed.colour_scale}
         # the slice schedule of the frames to come (longer slices where few rays end: dsn_render_rays_ex), from the probe frame's histogram
         R_, S_ = getattr(self, "_probe_shape", (0, 0))
@@ -652,7 +658,7 @@ class Renderer:
         if not (cmax == cmax) or cmax == float("inf"):
             # a NaN / inf colour reached a pixel: nothing sensible to scale with - termination off for these parameters
             if packed.early_stop is not None:
-                packed.early_stop["usable"] = False
+                packed.early_stop["usable"] = packed.early_stop["finite"] = False
             warnings.warn("dsnerf_amd: a frame weighed a non-finite colour: early stop stays off for these parameters")
             return
         want = _lib.EARLY_STOP_COLOUR_HEADROOM * cmax

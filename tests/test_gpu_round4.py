@@ -31,7 +31,8 @@ def test_early_stop_threshold_follows_the_colour_scale_w3_at_1e_4_absolute():
     assert cmax >= float(ref["color"].abs().max()) * (1 - 1e-6) and cmax > 20.0, cmax
     r = run.renderer
     pk = r.net.packed(r.device)
-    assert pk.colour_scale == 1.0
+    # (the helper follows the callers' protocol: the statistics frame has set the scale to 2 x its largest colour)
+    assert abs(pk.colour_scale - _lib.EARLY_STOP_COLOUR_HEADROOM * cmax) <= 1e-5 * pk.colour_scale
     scale = pk.set_early_stop_colour_scale(_lib.EARLY_STOP_COLOUR_HEADROOM * cmax)
     eps = _lib.early_stop_eps(S, scale)
     assert eps < _lib.early_stop_eps(S) and (S + 1) * eps * scale <= 0.5e-4 * (1 + 1e-5)
