@@ -228,7 +228,9 @@ def frame_bench(args, dsnerf_amd, _lib, synth, rk):
     result = {
         "metric": f"rendered rays/sec ({S} samples/ray), {H}x{W} frame",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # (N = 1 is the first point of the STRONG curve `--gpus N` measures since round 5 - the same frame partitioned over N ranks;
+        #  --weak: one whole frame per rank)
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if (args.weak or world > 1) else "strong", "vs_baseline": None,
         "dtype": ("f32 (v_mfma_f32_32x32x2_f32)" if args.fp32 else
                   "split-f16x3 (3 x v_mfma_f32_32x32x16_f16 on hi/lo fp16 operand halves, f32 accumulate: f32-equivalent accuracy)"
                   + ("" if (args.dense or cur["no_screen"]) else " + plain-f16 density screen")),

@@ -810,12 +810,15 @@ def read_stop_hist(ws, R: int, S: int):
     return c.reshape(K + 1, K), L
 
 
-def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 32768, launch_rounds: float = 0.9):
+def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 128 * 224, launch_rounds: float = 0.3, quantise: bool = True):
     """Slice lengths for dsn_render_rays_ex from a probe frame's histogram (read_stop_hist).  A slice that starts at uniform slice a
     and covers slices a .. b evaluates sum_k M[a][k], M[a][k] = samples of slice k on rays still alive at the start of a (sum over
-    g > a of hist[g][k]); every slice also costs about `launch_rounds` of a round of the chip (the half-empty last round of its forward
-    launch, the list filter and transmittance launches in front of it; a round = round_samples samples: 128 per workgroup).  Dynamic
-    programming over the slice borders minimises samples + launch_rounds x round_samples x slices; slices stay within 64 samples.
+    g > a of hist[g][k]).  Its forward launch runs in ROUNDS of the persistent grid - 128 samples per workgroup, round_samples per
+    round (224 workgroups with frames in flight, DSN_SHARE_CUS) - so it costs ceil(samples / round_samples) rounds whatever its last
+    round holds, plus about `launch_rounds` of a round for the small launches in front of it (transmittance, list filter).  Dynamic
+    programming over the slice borders minimises the sum; slices stay within 64 samples.  quantise=False: round 4's model (samples +
+    0.9 rounds per slice), which ignored the half-empty last round - 4 % on a whole 512 x 512 frame (12 rounds per slice), a third of
+    the forward time of a rank's eighth of it (1.5 rounds per slice).
     Returns (list of lengths in samples, evaluated samples it predicts, evaluated samples of the uniform schedule)."""
     import numpy as np
     hist = np.asarray(hist, np.int64)
@@ -823,15 +826,21 @@ def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 32768, launc
     M = np.zeros((K, K), np.int64)                       # M[a][k]: alive at the start of slice a
     for a in range(K):
         M[a] = hist[a + 1:].sum(0)
-    ov = float(launch_rounds) * float(round_samples)
+    rs = float(round_samples)
+
+    def cost(n):
+        if not quantise:
+            return 0.9 * 32768.0 + float(n)
+        return (float(launch_rounds) + float(-(-int(n) // int(round_samples)))) * rs
+
     best = [0.0] + [float("inf")] * K
     prev = [0] * (K + 1)
     for b in range(1, K + 1):
         for a in range(max(0, b - 64 // max(L, 1)), b):
             if (min(b * L, S) - a * L) > 64:
                 continue
-            c = best[a] + ov + float(M[a][a:b].sum())
-            if c < best[b]:
+            c = best[a] + cost(M[a][a:b].sum())
+            if c < best[b] or (c == best[b] and a > prev[b]):      # (ties: the later border - termination checked more often)
                 best[b], prev[b] = c, a
     cuts, b = [], K
     while b > 0:

@@ -26,7 +26,9 @@ thread_local int g_dsn_persistent_override = 0;
 namespace {
 struct DsnShareCus {      // DSN_SHARE_CUS for the duration of one dsn_render_rays call
     explicit DsnShareCus(bool on) {
-        if (on) { const int n = dsn_cu_count_raw(); g_dsn_persistent_override = std::max(8, (n * 7 / 8) / 8 * 8); }
+        // (DSN_SHARE_EIGHTHS, experiments: how many eighths of the compute units the persistent kernels take; 7 by default)
+        static const int eighths = [] { const char* e = getenv("DSN_SHARE_EIGHTHS"); const int v = e ? atoi(e) : 7; return v >= 1 && v <= 8 ? v : 7; }();
+        if (on) { const int n = dsn_cu_count_raw(); g_dsn_persistent_override = std::max(8, (n * eighths / 8) / 8 * 8); }
     }
     ~DsnShareCus() { g_dsn_persistent_override = 0; }
 };
