@@ -155,7 +155,7 @@ def launch_ranks(args):
 
 
 def _profile_file(stem):
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
         if os.path.exists(path):
             return path
