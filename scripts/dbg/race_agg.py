@@ -73,8 +73,14 @@ def spin(v, a, lds, mode, groups=256, iters=400000):
         rc = CO.launch(v, a, lds, groups, iters, mode, _lib._ptr(dummy), _lib._stream())
         assert rc == 0, rc
     return f
+srcbuf = torch.rand(256 * 256 * 4 + 64, device=dev)
+def spin2(kind, iters=60000):
+    def f():
+        assert CO.launch2(kind, 256, iters, _lib._ptr(srcbuf), _lib._ptr(dummy), _lib._stream()) == 0
+    return f
 oa, nfa = run(sa, wa, ["set", "geom", "field"]); torch.cuda.synchronize()
 SP = tuple((f"spin v{v} a{a} lds{l} mode{m}", spin(v, a, l, m)) for (v, a, l) in ((256, 192, 0), (256, 192, 131072), (256, 0, 0), (128, 0, 0), (128, 64, 0), (256, 64, 0), (0, 0, 0), (0, 0, 131072)) for m in (0, 1))
+SP = (("spin2: global loads into HIGH AGPRs", spin2(1)), ("spin2: global loads into high VGPRs", spin2(2)), ("spin2: ds_read into AGPRs", spin2(3)))
 for name, fn in SP + (("none", agg_none), ("field16 forward", agg_fwd), ("field16 reverse", agg_rev), ("torch bf16 gemm", agg_gemm), ("elementwise", agg_copy),
                  ("exact-fp32 field", agg_fp32), ("shade phase", agg_light)) + tuple(
                  (os.path.basename(v), variant(v)) for v in sorted(__import__("glob").glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", "*.so")))):

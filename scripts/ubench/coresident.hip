@@ -23,6 +23,36 @@ __global__ void __launch_bounds__(256, 1) spin(int iters, int mode, float* out) 
     }
     if (x == 12345.f) out[0] = x + y + lds[0];
 }
+// spin2<KIND>: 448 registers allocated; the loop issues loads whose DESTINATION is (1) high AGPRs, (2) high VGPRs, (3) AGPRs from LDS
+// (the field kernels' compiler-chosen forms: global_load_dwordx3 a[170:172] for the sample points, ds_read_b128 a[0:3] for operands)
+template <int KIND>
+__global__ void __launch_bounds__(256, 1) spin2(int iters, const float* __restrict__ src, float* out) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    asm volatile("v_accvgpr_write_b32 a191, 0" ::: "a191");
+    const float* p = src + (size_t)(blockIdx.x * 256 + threadIdx.x) * 4;
+    lds[threadIdx.x] = 1.0f; lds[threadIdx.x + 256] = 2.0f;
+    __syncthreads();
+    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + threadIdx.x * 16;
+    float x = threadIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 1) asm volatile("global_load_dwordx3 a[170:172], %0, off\n global_load_dwordx3 a[174:176], %0, off offset:16\n global_load_dwordx3 a[144:146], %0, off offset:32\n s_waitcnt vmcnt(0)"
+                                    :: "v"(p) : "a170", "a171", "a172", "a174", "a175", "a176", "a144", "a145", "a146", "memory");
+        if (KIND == 2) asm volatile("global_load_dwordx3 v[200:202], %0, off\n global_load_dwordx3 v[204:206], %0, off offset:16\n global_load_dwordx3 v[240:242], %0, off offset:32\n s_waitcnt vmcnt(0)"
+                                    :: "v"(p) : "v200", "v201", "v202", "v204", "v205", "v206", "v240", "v241", "v242", "memory");
+        if (KIND == 3) asm volatile("ds_read_b128 a[0:3], %0\n ds_read_b128 a[180:183], %0 offset:4096\n ds_read2st64_b32 a[54:55], %0 offset0:8 offset1:12\n s_waitcnt lgkmcnt(0)"
+                                    :: "v"(la) : "a0", "a1", "a2", "a3", "a180", "a181", "a182", "a183", "a54", "a55", "memory");
+        x = fmaf(x, 1.0001f, 1.0f);
+    }
+    if (x == 12345.f) out[0] = x + lds[3];
+}
+extern "C" int launch2(int kind, int groups, int iters, const float* src, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 1) hipLaunchKernelGGL(spin2<1>, dim3(groups), dim3(256), 0, st, iters, src, out);
+    else if (kind == 2) hipLaunchKernelGGL(spin2<2>, dim3(groups), dim3(256), 0, st, iters, src, out);
+    else hipLaunchKernelGGL(spin2<3>, dim3(groups), dim3(256), 0, st, iters, src, out);
+    return hipGetLastError() != hipSuccess;
+}
 extern "C" int launch(int v, int a, int lds, int groups, int iters, int mode, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
 #define L(VV, AA, LL) if (v == VV && a == AA && lds == LL) { hipLaunchKernelGGL((spin<VV, AA, LL>), dim3(groups), dim3(256), 0, st, iters, mode, out); return hipGetLastError() != hipSuccess; }
