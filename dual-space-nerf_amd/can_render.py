@@ -154,6 +154,11 @@ class _ViewSlot:
         self.stream = torch.cuda.Stream(device=renderer.device)
 
 
+class _Renderers:
+    alive = 0          # Renderer objects of this process (the host-pool fit is undone when the last one is gone)
+    lowered = None     # (the caller's torch.get_num_threads(), what fit_host_pool lowered it to)
+
+
 class Renderer:
     def __init__(self, net, fine_net=None, cfg=None, canonical_vertex=None, body_data=None, device=None, host_pool="fit"):
         """`body_data` (optional, not in the reference): dict with 'f' [F,3] (and optionally 'weights',
@@ -216,6 +221,22 @@ class Renderer:
         if host_pool not in ("fit", "keep"):
             raise ValueError('host_pool must be "fit" or "keep"')
         self.host_pool = _lib.fit_host_pool(keep=(host_pool == "keep"))
+        _Renderers.alive += 1
+        if self.host_pool[0] != self.host_pool[1] and _Renderers.lowered is None:
+            _Renderers.lowered = (self.host_pool[0], self.host_pool[1])      # (the caller's setting, what it was lowered to)
+
+    def __del__(self):
+        # the pool setting is the process's, not this object's: when the LAST Renderer goes away and nobody has
+        # changed the setting since it was lowered, the caller gets back the value it had
+        try:
+            _Renderers.alive -= 1
+            if _Renderers.alive == 0 and _Renderers.lowered is not None:
+                before, now = _Renderers.lowered
+                _Renderers.lowered = None
+                if torch.get_num_threads() == now:
+                    torch.set_num_threads(before)
+        except Exception:
+            pass
 
     # ---- mode switches (reference :26-38) ----
     def train(self):

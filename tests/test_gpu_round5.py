@@ -428,3 +428,29 @@ def test_sliced_frame_that_breaks_its_bound_is_rendered_again():
         c = float(b["coarse_color"].abs().max())
         assert maxdiff(a["coarse_color"].numpy(), b["coarse_color"].numpy()) < 1e-4 + 2e-6 * max(c, 1.0), shift
         assert maxdiff(a["coarse_acc"].numpy(), b["coarse_acc"].numpy()) < 1e-4, shift
+
+
+def test_host_pool_fit_is_undone_with_the_last_renderer():
+    """Renderer(host_pool="fit") lowers a PROCESS-wide setting; when the last Renderer is gone and nobody has
+    touched the setting since, the caller's value is back"""
+    import gc
+    from dsnerf_amd import _lib, can_render
+    quota = _lib.cpu_quota_cores()
+    if quota is None:
+        pytest.skip("no cgroup CPU quota on this box: the fit does nothing")
+    gc.collect()
+    if can_render._Renderers.alive:
+        pytest.skip("renderers of earlier tests are still alive")
+    canon, faces, _ = full_frame(hw=16)
+    caller = max(64, int(quota) * 4)
+    torch.set_num_threads(caller)
+    r1 = renderer_with(state(), canon, faces)
+    r2 = renderer_with(state(), canon, faces)
+    lowered = torch.get_num_threads()
+    assert lowered < caller and r1.host_pool[0] == caller and r2.host_pool[0] == lowered
+    del r1
+    gc.collect()
+    assert torch.get_num_threads() == lowered                  # one Renderer is still using it
+    del r2
+    gc.collect()
+    assert torch.get_num_threads() == caller
