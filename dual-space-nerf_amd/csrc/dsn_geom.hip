@@ -3,6 +3,7 @@
 // LDS-staged broadcast tiles, wave-level scans; no MFMA here (the networks live in dsn_field.hip).
 #include "dsn_common.h"
 #include "dsn_kernels.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // setup: per-face records + centroids  (utils/render_utils.py:94, utils/geo_utils.py:181-200)
@@ -748,7 +749,7 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
             m = m == m ? m : INFINITY;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-            if (lane == 0 && __float_as_int(m) > *colour_max) atomicMax(colour_max, __float_as_int(m));
+            if (lane == 0 && __float_as_int(m) > __hip_atomic_load(colour_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(colour_max, __float_as_int(m));   // (a fresh copy: see k_composite16)
         }
     }
     if (lane == 0 && rgb_map) {
@@ -762,9 +763,164 @@ __global__ void __launch_bounds__(256) k_composite(const float* __restrict__ col
     }
 }
 
+// Round 5: SIXTEEN lanes per ray, CH = S / 16 consecutive samples per lane (S = 64: 4, S = 128: 8 - every configuration the reference
+// ships).  The one-wave-per-ray form above spends its time in cross-lane steps - a 6-step product scan, five 6-step sums and a 6-step
+// maximum per 64 samples, most of them LDS-crossbar permutes - for 9 bytes of input per sample (1 TB/s).  Here a lane multiplies its
+// own CH factors in registers, the scan and the reductions run over the 16 lanes of a DPP row (4 row_shr steps each, plain VALU
+// operand shifts), and the inputs are 16-byte loads: four rays per wave for 28 cross-lane steps.  Same per-sample alpha (same expf,
+// same operands); the ORDER of the products of T and of the five sums differs from the wave form (both differ from the reference's
+// cumprod / sum order by the same few ulps).
+__device__ __forceinline__ float dsn_row_shr(float old, float v, int n) {      // value of lane (l - n) of the same 16-lane row, `old` where there is none
+    switch (n) {
+        case 1: return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x111, 0xf, 0xf, false));
+        case 2: return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x112, 0xf, 0xf, false));
+        case 4: return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x114, 0xf, 0xf, false));
+        default: return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x118, 0xf, 0xf, false));
+    }
+}
+__device__ __forceinline__ float dsn_row_sum_to_last(float v) {      // lane 15 of every row ends up with the row's sum
+    v += dsn_row_shr(0.f, v, 1);
+    v += dsn_row_shr(0.f, v, 2);
+    v += dsn_row_shr(0.f, v, 4);
+    v += dsn_row_shr(0.f, v, 8);
+    return v;
+}
+template <bool WEIGHTS_ONLY, int CH>
+__global__ void __launch_bounds__(256) k_composite16(const float* __restrict__ colour, const float* __restrict__ sigma,
+                                                      const uint8_t* __restrict__ transparent,
+                                                      const float* __restrict__ z_vals, const float* __restrict__ ray_d,
+                                                      const float* __restrict__ noise, int R, float* __restrict__ rgb_map,
+                                                      float* __restrict__ disp_map, float* __restrict__ acc_map,
+                                                      float* __restrict__ weights, float* __restrict__ depth_map, int lazy_colour,
+                                                      int32_t* __restrict__ colour_max) {
+    constexpr int S = 16 * CH;
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int r_of_row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    if (r_of_row - (lane >> 4) >= R) return;              // wave-uniform
+    // a row past the last ray stays in step (the wave-wide maximum below reads every row) on a copy of the last ray and stores nothing
+    const bool ok = r_of_row < R;
+    const int r = ok ? r_of_row : R - 1;
+    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    const int64_t g0 = (int64_t)r * S + sub * CH;
+    float z[CH + 1], sg[CH];
+    uint8_t tr[CH];
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+        const float4 z4 = *reinterpret_cast<const float4*>(z_vals + g0 + 4 * q);
+        const float4 s4 = *reinterpret_cast<const float4*>(sigma + g0 + 4 * q);
+        z[4 * q] = z4.x; z[4 * q + 1] = z4.y; z[4 * q + 2] = z4.z; z[4 * q + 3] = z4.w;
+        sg[4 * q] = s4.x; sg[4 * q + 1] = s4.y; sg[4 * q + 2] = s4.z; sg[4 * q + 3] = s4.w;
+        uchar4 t4 = make_uchar4(0, 0, 0, 0);
+        if (transparent) t4 = *reinterpret_cast<const uchar4*>(transparent + g0 + 4 * q);
+        tr[4 * q] = t4.x; tr[4 * q + 1] = t4.y; tr[4 * q + 2] = t4.z; tr[4 * q + 3] = t4.w;
+        if (noise) {
+            const float4 n4 = *reinterpret_cast<const float4*>(noise + g0 + 4 * q);
+            // (the order of the reference: transparent samples have their density forced to 0 first, the noise is added afterwards)
+            sg[4 * q] = (tr[4 * q] ? 0.f : sg[4 * q]) + n4.x; sg[4 * q + 1] = (tr[4 * q + 1] ? 0.f : sg[4 * q + 1]) + n4.y;
+            sg[4 * q + 2] = (tr[4 * q + 2] ? 0.f : sg[4 * q + 2]) + n4.z; sg[4 * q + 3] = (tr[4 * q + 3] ? 0.f : sg[4 * q + 3]) + n4.w;
+        }
+    }
+    // the first depth of the next lane (row_shl:1: lane l reads lane l + 1 of its row; the ray's last sample has no successor)
+    z[CH] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z[0]), 0x101, 0xf, 0xf, false));
+    float alpha[CH], pre[CH];                // pre[j]: product of this lane's factors 0 .. j
+    float run = 1.0f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        float sv = sg[j];
+        if (!noise && tr[j]) sv = 0.f;
+        sv = sv > 0.f ? sv : 0.f;
+        sg[j] = sv;
+        const float dist = ((sub * CH + j + 1 < S) ? (z[j + 1] - z[j]) : 1e10f) * dn;
+        alpha[j] = 1.0f - expf(-sv * dist);
+        run = run * ((1.0f - alpha[j]) + 1e-10f);
+        pre[j] = run;
+    }
+    // exclusive product scan of the lanes' totals over the row
+    float incl = run;
+    incl = incl * dsn_row_shr(1.0f, incl, 1);
+    incl = incl * dsn_row_shr(1.0f, incl, 2);
+    incl = incl * dsn_row_shr(1.0f, incl, 4);
+    incl = incl * dsn_row_shr(1.0f, incl, 8);
+    const float before = dsn_row_shr(1.0f, incl, 1);      // transmittance entering this lane's first sample
+    float w[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) w[j] = alpha[j] * (j == 0 ? before : before * pre[j - 1]);
+    if (weights && ok) {
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q)
+            *reinterpret_cast<float4*>(weights + g0 + 4 * q) = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+    if (WEIGHTS_ONLY) return;
+    float sr = 0.f, sgn = 0.f, sb = 0.f, sdep = 0.f, sacc = 0.f, cm = 0.f;
+    float col[3 * CH];
+    if (colour && !lazy_colour) {            // every colour is wanted: four samples' colours are 48 contiguous bytes
+#pragma unroll
+        for (int q = 0; q < 3 * CH / 4; ++q) {
+            const float4 c4 = *reinterpret_cast<const float4*>(colour + 3 * g0 + 4 * q);
+            col[4 * q] = c4.x; col[4 * q + 1] = c4.y; col[4 * q + 2] = c4.z; col[4 * q + 3] = c4.w;
+        }
+    } else {
+        // a lazily filled colour array holds rubbish where the density is not positive (about one sample in eight is): never let it
+        // into a product, and do not pull its lines through the cache either
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            col[3 * j] = col[3 * j + 1] = col[3 * j + 2] = 0.f;
+            if (colour && sg[j] > 0.f) { col[3 * j] = colour[3 * (g0 + j)]; col[3 * j + 1] = colour[3 * (g0 + j) + 1]; col[3 * j + 2] = colour[3 * (g0 + j) + 2]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const float cr = col[3 * j], cg = col[3 * j + 1], cb = col[3 * j + 2];
+        sr += w[j] * cr; sgn += w[j] * cg; sb += w[j] * cb;
+        sdep += w[j] * z[j];
+        sacc += w[j];
+        float m = fmaxf(fabsf(cr), fmaxf(fabsf(cg), fabsf(cb)));
+        m = m == m ? m : INFINITY;
+        cm = fmaxf(cm, m);
+    }
+    sr = dsn_row_sum_to_last(sr); sgn = dsn_row_sum_to_last(sgn); sb = dsn_row_sum_to_last(sb);
+    sdep = dsn_row_sum_to_last(sdep); sacc = dsn_row_sum_to_last(sacc);
+    if (colour_max) {
+        cm = fmaxf(cm, dsn_row_shr(0.f, cm, 1)); cm = fmaxf(cm, dsn_row_shr(0.f, cm, 2));
+        cm = fmaxf(cm, dsn_row_shr(0.f, cm, 4)); cm = fmaxf(cm, dsn_row_shr(0.f, cm, 8));
+        // one candidate per wave, checked against a FRESH copy of the running maximum (a plain load may be served by this CU's L1 for
+        // the whole kernel, and then every row of the frame queues an atomic on the one address: that was most of this kernel's time)
+        cm = fmaxf(cm, __shfl_xor(cm, 16));
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        if (lane == 63 && __float_as_int(cm) > __hip_atomic_load(colour_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(colour_max, __float_as_int(cm));
+    }
+    if (sub == 15 && rgb_map && ok) {
+        rgb_map[3 * r] = sr; rgb_map[3 * r + 1] = sgn; rgb_map[3 * r + 2] = sb;
+        depth_map[r] = sdep;
+        acc_map[r] = sacc;
+        float q = dsn_div(sdep, sacc);          // NaN when acc == 0, like the reference
+        float m = (1e-10f > q) ? 1e-10f : q;    // torch.max propagates NaN
+        if (q != q) m = q;
+        disp_map[r] = dsn_div(1.0f, m);
+    }
+}
+
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour, int32_t* colour_max) {
+    // 16 lanes per ray where the ray length allows 16-byte loads per lane (S = 64 / 128) and the arrays are 16-byte aligned;
+    // DSN_COMPOSITE=wave (A/B, tests) keeps the one-wave-per-ray form
+    static const bool wave_form = [] { const char* e = getenv("DSN_COMPOSITE"); return e && e[0] == 'w'; }();
+    const bool aligned = (((uintptr_t)z_vals | (uintptr_t)sigma | (uintptr_t)weights | (uintptr_t)noise | (uintptr_t)colour) & 15) == 0 &&
+                         (((uintptr_t)transparent) & 3) == 0;
+    if (!wave_form && aligned && (S == 64 || S == 128)) {
+        const dim3 grid((unsigned)((R + 15) / 16)), block(256);
+        const bool wo = !colour && !rgb_map;
+        int32_t* cmx = colour ? colour_max : nullptr;
+#define DSN_C16(W, C) hipLaunchKernelGGL((k_composite16<W, C>), grid, block, 0, st, colour, sigma, transparent, z_vals, ray_d, noise, R, rgb_map, \
+                                         disp_map, acc_map, weights, depth_map, lazy_colour ? 1 : 0, cmx)
+        if (S == 64) { if (wo) DSN_C16(true, 4); else DSN_C16(false, 4); }
+        else { if (wo) DSN_C16(true, 8); else DSN_C16(false, 8); }
+#undef DSN_C16
+        return;
+    }
     if (!colour && !rgb_map)
         hipLaunchKernelGGL(k_composite<true>, dim3((R + 3) / 4), dim3(256), 0, st, colour, sigma, transparent, z_vals, ray_d,
                            noise, R, S, rgb_map, disp_map, acc_map, weights, depth_map, 0, (int32_t*)nullptr);

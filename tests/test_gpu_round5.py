@@ -454,3 +454,47 @@ def test_host_pool_fit_is_undone_with_the_last_renderer():
     del r2
     gc.collect()
     assert torch.get_num_threads() == caller
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [64, 128])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_sixteen_lane_compositor_agrees_with_the_wave_form(S, noisy):
+    """S = 64 / 128 composite with 16 lanes per ray (k_composite16); arrays that are not 16-byte aligned fall back to the one-wave-per-ray
+    kernel.  The two differ only in the ORDER of the transmittance products and of the five sums; both stay within the golden tolerance
+    of the reference's cumprod (the oracle's composite)."""
+    from importlib import import_module
+    L = import_module("dual-space-nerf_amd._lib")
+    dev = torch.device("cuda:0")
+    gen = np.random.default_rng(5)
+    R = 1003                                  # not a multiple of 16: the last workgroup's last rows are empty
+    z = np.sort(gen.uniform(2.0, 6.0, (R, S)).astype(np.float32), axis=1)
+    sigma = (gen.normal(0.0, 30.0, (R, S))).astype(np.float32)
+    sigma[gen.random((R, S)) < 0.5] = -1.0
+    sigma[:7] = -1.0                          # empty rays: acc == 0, disp NaN
+    colour = gen.uniform(0.0, 1.0, (R, S, 3)).astype(np.float32)
+    tr = (gen.random((R, S)) < 0.2).astype(np.uint8)
+    ray_d = gen.normal(size=(R, 3)).astype(np.float32)
+    noise = gen.normal(0.0, 1.0, (R, S)).astype(np.float32) if noisy else None
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def off4(a):                              # the same values, 4 bytes past a 16-byte boundary
+        flat = torch.empty(a.size + 1, dtype=torch.float32, device=dev)
+        flat[1:] = T(a).reshape(-1)
+        return flat[1:].view(*a.shape)
+
+    fast = L.composite(T(colour), T(sigma), T(tr), T(z), T(ray_d), None if noise is None else T(noise))
+    wave = L.composite(T(colour), T(sigma), T(tr), off4(z), T(ray_d), None if noise is None else T(noise))
+    raw = np.concatenate([colour, np.where(tr != 0, 0.0, sigma).astype(np.float32)[..., None]], -1)
+    ref = O.composite(raw, z, ray_d, noise)
+    names = ["rgb_map", "disp_map", "acc_map", "weights", "depth_map"]
+    for a, b, k in zip(fast, wave, names):
+        a, b, e = a.cpu().numpy(), b.cpu().numpy(), np.asarray(ref[k])
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isnan(a), np.isnan(e)), k
+        ok = np.isfinite(e)
+        if k == "disp_map":
+            assert np.allclose(a[ok], b[ok], rtol=2e-5) and np.allclose(a[ok], e[ok], rtol=2e-5)
+        else:
+            tol = 5e-6 if k == "depth_map" else 2e-6
+            assert maxdiff(a[ok], b[ok]) < tol and maxdiff(a[ok], e[ok]) < tol, k
+    assert not torch.equal(fast[3], wave[3])      # different kernels, different product order: bit-equal weights would mean the fallback was not taken
