@@ -161,14 +161,18 @@ def ray_costs(_lib, args, frame, slots, screen):
     return cost.cpu()
 
 
-def make_partition(args, _lib, rp, frame, slots, world, screen, log=None):
-    """-> (kind, plan builder (device -> plan), info dict).  world = ranks of the (real or emulated) job."""
+def make_partition(args, _lib, rp, frame, slots, world, screen, log=None, agree=None):
+    """-> (kind, plan builder (device -> plan), info dict).  world = ranks of the (real or emulated) job.
+    agree(bounds) -> bounds: a real multi-rank job passes rank 0's block bounds through here (one broadcast), so that the slab size of
+    the gather cannot depend on a borderline comparison falling differently on two GPUs."""
     R = frame.R
     if args.partition == "tiles":
         tile = auto_tile(R, world, args.tile)
         return "tiles", (lambda dev, rank=None: _tile_plan(rp, R, tile, dev, world, rank)), {"partition": "tiles", "tile_rays": tile}
     cost = ray_costs(_lib, args, frame, slots, screen)
     bounds = rp.balanced_bounds(cost, world)
+    if agree is not None:
+        bounds = agree(bounds)
     info = {"partition": "blocks", "bounds": bounds, "cost_share_of_blocks": [float(cost[bounds[r]:bounds[r + 1]].sum() / cost.sum())
                                                                                 for r in range(world)]}
     return "blocks", (lambda dev, rank=None: _block_plan(rp, R, bounds, dev, rank)), info
@@ -199,8 +203,15 @@ def strong_bench(args, dsnerf_amd, _lib, synth, dev, world, rank, use_dist, rk):
     rp = dsnerf_amd.RayParallel()
     slots.scenes[0].set_frame(frame.packed, frame.d_xyz, frame.d_poses, 5, False, None, None, None)
     info = frame.packed.calibrate_screen(slots.scenes[0]) if args.screen else {"usable": False, "note": "density screen not opted in (--screen)"}
-    # (every rank computes the same partition from the same synthetic frame: deterministic inputs, no collective needed)
-    kind, plan_of, part_info = make_partition(args, _lib, rp, frame, slots, world, info["usable"])
+    # (every rank computes the partition from the same synthetic frame; rank 0's block bounds are the ones used - one 8-byte-per-rank
+    #  broadcast outside the timed region, so that no rank can disagree about the slab size of the gather)
+    def agree(bounds):
+        if not use_dist:
+            return bounds
+        t_ = torch.tensor(bounds, dtype=torch.int64, device=dev)
+        dist.broadcast(t_, src=0)
+        return [int(x) for x in t_.cpu()]
+    kind, plan_of, part_info = make_partition(args, _lib, rp, frame, slots, world, info["usable"], agree=agree)
     plan = plan_of(dev)
     slab = plan["slab"]
     share = Share(_lib, args, frame, slots, plan["mine"].cpu().numpy(), slab=slab, screen=info["usable"])
