@@ -841,6 +841,8 @@ __device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest pow
 #ifndef W16D_VALU
 #define W16D_VALU 5           // k_t_wgrad16d: VALU instructions the scheduler places behind each MFMA of a pipelined step
 #endif
+// the optional second operand pair of a split-fp16 weight-gradient launch (jobs = 1: none), see k_t_wgrad16d
+struct WgradOps { const float* dY2; const float* sy2; const float* X2; const float* sx2; int jobs; };
 __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
@@ -1035,7 +1037,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
 __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
-                                                     float* __restrict__ dbias, Rows rw, float* __restrict__ part) {
+                                                     float* __restrict__ dbias, Rows rw, float* __restrict__ part, WgradOps ops) {
     constexpr int OT = 4, IT = 4, WI = 2;
     __shared__ __attribute__((aligned(16))) float ring[W16D_STAGES][2][16][256];
     __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][2][256];      // [buffer][operand][hi | lo][8-sample group][feature]
@@ -1052,8 +1054,14 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
     const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
     const bool tail = n0 + 16 * (int64_t)full < n1;
     float bsum = 0.0f;                                   // column sum of dY feature tid (bias gradient)
-    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
-    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    // TWO operand pairs into the same accumulators (dY2 != NULL; round 5): the pairs run one after the other over this workgroup's rows;
+    // between them the accumulators change units by the ratio of the pairs' scales - powers of two, so exactly.  One partial tile,
+    // one reduction for both products of a layer.  The bias gradient (column sums of dY) belongs to the LAST pair.
+    const float* jY = dY;
+    const float* jX = X;
+    float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    float iy = 1.0f / sy, ix = 1.0f / sx;
+    bool bias_job = ops.jobs == 1;
     t_f32x16 acc[OT][IT];
 #pragma unroll
     for (int a = 0; a < OT; ++a)
@@ -1078,20 +1086,20 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
             if (ids[3] - ids[0] != 3) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const char* ga = reinterpret_cast<const char*>(dY + (int64_t)ids[j] * 256) + lane * 16;
+                    const char* ga = reinterpret_cast<const char*>(jY + (int64_t)ids[j] * 256) + lane * 16;
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const char* gb = reinterpret_cast<const char*>(X + (int64_t)ids[j] * 256) + lane * 16;
+                    const char* gb = reinterpret_cast<const char*>(jX + (int64_t)ids[j] * 256) + lane * 16;
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db + 1024u * j) : "memory", "m0");
                 }
                 return;
             }
             r0 = (int64_t)ids[0];                        // a run of four consecutive rows: the one-address form
         }
-        const char* ga = reinterpret_cast<const char*>(dY + r0 * 256) + lane * 16;
-        const char* gb = reinterpret_cast<const char*>(X + r0 * 256) + lane * 16;
+        const char* ga = reinterpret_cast<const char*>(jY + r0 * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(jX + r0 * 256) + lane * 16;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
@@ -1110,7 +1118,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
     // split the 16 values v[op][row] of feature tid and publish them in operand buffer `buf`
     auto publish = [&](const float (&v)[2][16], int buf) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bsum += v[0][j];
+        for (int j = 0; j < 16; ++j) bsum += bias_job ? v[0][j] : 0.0f;
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
             const float inv = op == 0 ? iy : ix;
@@ -1151,6 +1159,26 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
             }
     };
+#pragma nounroll
+    for (int job = 0; job < ops.jobs; ++job) {
+    if (job == 1) {
+        // the second pair: same rows, its own operands and scales; the accumulators go from units of (sy sx) to units of (sy2 sx2)
+        const float* const sy2_ptr = ops.sy2;
+        const float* const sx2_ptr = ops.sx2;
+        const float sy2 = sy2_ptr ? t_pow2_at_least(*sy2_ptr) : 1.0f, sx2 = sx2_ptr ? t_pow2_at_least(*sx2_ptr) : 1.0f;
+        const float ratio = (sy * sx) / (sy2 * sx2);
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int b = 0; b < IT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= ratio;
+        jY = ops.dY2; jX = ops.X2;
+        sy = sy2; sx = sx2;
+        iy = 1.0f / sy; ix = 1.0f / sx;
+        bias_job = true;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has fetched the first pair's last operands
+    }
     if (full > 0) {
         const int pre = full < W16D_STAGES ? full : W16D_STAGES;
         for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
@@ -1212,8 +1240,8 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
             const int64_t lrow = n0 + 16 * (int64_t)full + j;
             const bool ok = lrow < n1;
             const int64_t row = ok ? rows_at(rw, lrow) : 0;
-            v[0][j] = ok ? dY[row * 256 + tid] : 0.0f;
-            v[1][j] = ok ? X[row * 256 + tid] : 0.0f;
+            v[0][j] = ok ? jY[row * 256 + tid] : 0.0f;
+            v[1][j] = ok ? jX[row * 256 + tid] : 0.0f;
         }
         publish(v, full & 1);                                                   // (that buffer's readers are behind the loop's last barrier)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1221,6 +1249,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
         operands(full & 1, ah, al, bh, bl);
         mfmas(ah, al, bh, bl);
     }
+    }       // pairs
     const float back = sy * sx;
     if (part) {
         // this workgroup's partial tile (unscaled) + its column sums, plain coalesced stores: k_t_wgrad_reduce adds the workgroups up in
@@ -1333,7 +1362,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce(const float* __restrict_
 __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
-                                                        float* __restrict__ dbias, Rows rw, float* __restrict__ part) {
+                                                        float* __restrict__ dbias, Rows rw, float* __restrict__ part, WgradOps ops) {
     __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
     __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
     __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
@@ -1350,8 +1379,12 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
     const int full = n1 > n0 ? (int)((n1 - n0) >> 4) : 0;
     const bool tail = n0 + 16 * (int64_t)full < n1;
     float bsum = 0.0f;
-    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
-    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    // (two operand pairs into the same accumulators when dY2 != NULL: see k_t_wgrad16d)
+    const float* jY = dY;
+    const float* jX = X;
+    float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    float iy = 1.0f / sy, ix = 1.0f / sx;
+    bool bias_job = ops.jobs == 1;
     t_f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1378,17 +1411,17 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
             const int rr[4] = {ids[0], ids[1], ids[2], ids[3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const char* ga = reinterpret_cast<const char*>(dY + (int64_t)rr[j] * 256) + lane * 16;
+                const char* ga = reinterpret_cast<const char*>(jY + (int64_t)rr[j] * 256) + lane * 16;
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
             }
             const int q = lane >> 4;
             const int64_t rx = q == 0 ? rr[0] : (q == 1 ? rr[1] : (q == 2 ? rr[2] : rr[3]));
-            const char* gb = reinterpret_cast<const char*>(X + rx * 64) + (lane & 15) * 16;
+            const char* gb = reinterpret_cast<const char*>(jX + rx * 64) + (lane & 15) * 16;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db) : "memory", "m0");
             return;
         }
-        const char* ga = reinterpret_cast<const char*>(dY + (row + 4 * wave) * 256) + lane * 16;
-        const char* gb = reinterpret_cast<const char*>(X + row * 64) + wave * 1024 + lane * 16;
+        const char* ga = reinterpret_cast<const char*>(jY + (row + 4 * wave) * 256) + lane * 16;
+        const char* gb = reinterpret_cast<const char*>(jX + row * 64) + wave * 1024 + lane * 16;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
@@ -1407,7 +1440,7 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
     // thread f splits feature f of dY (16 rows); threads 0..127 split feature f & 63 of X for the 8-row group f >> 6
     auto publish = [&](const float (&vy)[16], const float (&vx)[8]) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bsum += vy[j];
+        for (int j = 0; j < 16; ++j) bsum += bias_job ? vy[j] : 0.0f;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             t_half8 hi, lo;
@@ -1443,6 +1476,25 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
             }
     };
+#pragma nounroll
+    for (int job = 0; job < ops.jobs; ++job) {
+    if (job == 1) {
+        const float* const sy2_ptr = ops.sy2;
+        const float* const sx2_ptr = ops.sx2;
+        const float sy2 = sy2_ptr ? t_pow2_at_least(*sy2_ptr) : 1.0f, sx2 = sx2_ptr ? t_pow2_at_least(*sx2_ptr) : 1.0f;
+        const float ratio = (sy * sx) / (sy2 * sx2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= ratio;
+        jY = ops.dY2; jX = ops.X2;
+        sy = sy2; sx = sx2;
+        iy = 1.0f / sy; ix = 1.0f / sx;
+        bias_job = true;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     const int pre = full < W16P_STAGES - 1 ? full : W16P_STAGES - 1;
     for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
     if (pre < full) fetch_ids(pre);
@@ -1470,18 +1522,19 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int64_t lrow = n0 + 16 * (int64_t)full + j;
-            vy[j] = lrow < n1 ? dY[rows_at(rw, lrow) * 256 + tid] : 0.0f;
+            vy[j] = lrow < n1 ? jY[rows_at(rw, lrow) * 256 + tid] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t lrow = n0 + 16 * (int64_t)full + 8 * ((tid >> 6) & 1) + j;
-            vx[j] = lrow < n1 ? X[rows_at(rw, lrow) * 64 + (tid & 63)] : 0.0f;
+            vx[j] = lrow < n1 ? jX[rows_at(rw, lrow) * 64 + (tid & 63)] : 0.0f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         publish(vy, vx);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         multiply();
     }
+    }       // pairs
     const float back = sy * sx;
     if (part) {      // two-stage form: see k_t_wgrad16d / k_t_wgrad_reduce
         float4* const mine = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * W16_PART(64));
@@ -1519,24 +1572,33 @@ static bool wgrad_two_stage() {
     static const bool v = [] { const char* e = getenv("DSN_WGRAD_REDUCE"); return !(e && e[0] == 'a'); }();
     return v;
 }
+// A second operand pair (X2, sx2, dY2, sy2) of the same shape adds its product into the same accumulators - ONE launch, one partial
+// tile and one reduction for the two weight-gradient products of a layer (tangent pair first, adjoint pair second; the bias gradient
+// is the second pair's).  VERDICT r04 #3 (c): 12 + 4 launches -> 6 + 2, half the 64 MB partial bursts and half of k_t_wgrad_reduce.
+struct WgradPair { const float* X; const float* sx; const float* dY; const float* sy; };
 void wgrad_mfma16p(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, int in_valid,
-                   hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr) {
+                   hipStream_t st, float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr,
+                   WgradPair second = WgradPair{nullptr, nullptr, nullptr, nullptr}) {
     int groups = W16_PART_GROUPS;     // two workgroups per CU
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
     rows = (rows + 15) & ~15;
     groups = (int)((N + rows - 1) / rows);
     if (!wgrad_two_stage()) part = nullptr;
-    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias, rw, part);
+    hipLaunchKernelGGL(k_t_wgrad16p, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, in_valid, dbias, rw, part,
+                       WgradOps{second.dY, second.sy, second.X, second.sx, second.dY ? 2 : 1});
+    const float* const ry = second.dY ? second.sy : sy;      // the partial tiles are in the LAST pair's units
+    const float* const rx = second.dY ? second.sx : sx;
     if (part)
-        hipLaunchKernelGGL(k_t_wgrad_reduce<64>, dim3(256 * 64 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, sy, sx, dW, ldw,
+        hipLaunchKernelGGL(k_t_wgrad_reduce<64>, dim3(256 * 64 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, ry, rx, dW, ldw,
                            in_valid, dbias);
 }
 
 // dW [256,256] (ldw) += dY[N,256]^T X[N,256], operands scaled by the device scalars sy / sx (NULL = O(1) operand);
 // dbias (optional) [256] += column sums of dY
 void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
-                  float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr) {
+                  float* dbias = nullptr, Rows rw = Rows{nullptr, nullptr}, float* part = nullptr,
+                  WgradPair second = WgradPair{nullptr, nullptr, nullptr, nullptr}) {
     int groups = 256;                 // one workgroup per CU, one round (with 512 the launch ran 0.33 instead of 0.28 ms)
     int rows = (int)((N + groups - 1) / groups);
     if (rows < 64) rows = 64;
@@ -1544,10 +1606,19 @@ void wgrad_mfma16(int64_t N, const float* X, const float* sx, const float* dY, c
     groups = (int)((N + rows - 1) / rows);
     static const bool old_kernel = [] { const char* e = getenv("DSN_WGRAD16"); return e && e[0] == 'c'; }();
     if (old_kernel || !wgrad_two_stage()) part = nullptr;
-    if (old_kernel) hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw);
-    else hipLaunchKernelGGL(k_t_wgrad16d, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw, part);
+    if (old_kernel) {      // (round 3's kernel knows one pair: two launches)
+        hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, second.dY ? nullptr : dbias, rw);
+        if (second.dY)
+            hipLaunchKernelGGL(k_t_wgrad16c, dim3((unsigned)groups), dim3(256), 0, st, second.dY, second.sy, second.X, second.sx, N, rows, dW, ldw,
+                               dbias, rw);
+        return;
+    }
+    hipLaunchKernelGGL(k_t_wgrad16d, dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, dW, ldw, dbias, rw, part,
+                       WgradOps{second.dY, second.sy, second.X, second.sx, second.dY ? 2 : 1});
+    const float* const ry = second.dY ? second.sy : sy;
+    const float* const rx = second.dY ? second.sx : sx;
     if (part)
-        hipLaunchKernelGGL(k_t_wgrad_reduce<256>, dim3(256 * 256 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, sy, sx, dW,
+        hipLaunchKernelGGL(k_t_wgrad_reduce<256>, dim3(256 * 256 / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, ry, rx, dW,
                            ldw, 256, dbias);
 }
 
@@ -1671,7 +1742,7 @@ void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
-    float *x_c, *pe, *h[7], *ap[7], *tn[7], *rr, *ess, *sig, *g, *t0, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
+    float *x_c, *pe, *h[7], *ap[7], *tn[7], *an[7], *rr, *ess, *sig, *g, *t0, *tpe, *n_w, *xl, *hl1, *hl2, *pre, *wl, *col;
     void* masks;
     float *d_sig, *d_col, *d_ess, *d_pre, *d_hl2, *d_hl1, *d_xl, *d_rr, *u, *scratch_t, *small;
     float* wg_part;                // the workgroups' partial tiles of one split-fp16 weight-gradient product (k_t_wgrad_reduce)
@@ -1694,6 +1765,9 @@ TrainWs carve(void* base, int64_t N) {
     for (int l = 0; l < 7; ++l) w.h[l] = (float*)take(1024 * n);
     for (int l = 0; l < 7; ++l) w.ap[l] = (float*)take(1024 * n);
     for (int l = 0; l < 7; ++l) w.tn[l] = (float*)take(1024 * n);
+    // (the adjoint pass's outputs: buffers of their own since round 5 - a layer's two weight-gradient products run as ONE launch, which
+    //  reads the tangent array hdot_{l-1} and the adjoint array ahat_l side by side; rounds 1-4 wrote the adjoints over the tangents)
+    for (int l = 0; l < 7; ++l) w.an[l] = (float*)take(1024 * n);
     w.masks = (void*)take(224 * n);
     w.rr = (float*)take(512 * n);
     w.ess = (float*)take(12 * n);
@@ -1877,10 +1951,15 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* const g_adj = w.small + 301;
     int32_t* const range_cnt = (int32_t*)(w.small + 303);      // samples whose tangent / adjoint left the fp16 range (zeroed with w.small)
     dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt, R2.list, R2.cnt);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st, nullptr, R2, w.wg_part);
-    for (int l = 1; l < 7; ++l)
-        wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, nullptr, R2, w.wg_part);
-    wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
+    // DSN_WGRAD_PAIRS=0 (A/B, cross-check): rounds 1-4's form - a launch per product, the adjoints written over the tangent arrays
+    static const bool pairs = [] { const char* e = getenv("DSN_WGRAD_PAIRS"); return !(e && e[0] == '0'); }();
+    if (!pairs) {
+        wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[P_S1_0W] + W0_PE_COL, 87, PE_K, st, nullptr, R2, w.wg_part);
+        for (int l = 1; l < 7; ++l)
+            wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, nullptr, R2, w.wg_part);
+        wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
+    }
+    // (default: the products  dW_l += a_l^T hdot_{l-1}  wait for the adjoint pass and run in ONE launch per layer with  ahat_l^T h_{l-1})
     colsum(w.tn[6], 256, N64, grd[P_DEN_W], st, R2);   // d (w_d . hdot_6) / d w_d
     float* cur = w.t0;
 
@@ -1894,15 +1973,28 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
-    float* const* an = w.tn;
+    float* const* an = pairs ? w.an : w.tn;
     dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt, R2.list, R2.cnt);
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
+        if (pairs) {
+            // tangent pair (a_l, hdot_{l-1}) first, adjoint pair (ahat_l, h_{l-1}) second: one launch, one reduction
+            wgrad_mfma16(N64, w.tn[l - 1], g_tan, w.ap[l], nullptr, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2, w.wg_part,
+                         WgradPair{w.h[l - 1], nullptr, A, g_adj});
+            if (l == 4)
+                wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part,
+                              WgradPair{w.pe, nullptr, A, g_adj});
+            continue;
+        }
         wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2, w.wg_part);
         if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
     }
     // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
-    wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part);
+    if (pairs)
+        wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part,
+                      WgradPair{w.pe, nullptr, an[0], g_adj});
+    else
+        wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part);
     // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
     if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
     hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,

@@ -498,3 +498,29 @@ def test_sixteen_lane_compositor_agrees_with_the_wave_form(S, noisy):
             tol = 5e-6 if k == "depth_map" else 2e-6
             assert maxdiff(a[ok], b[ok]) < tol and maxdiff(a[ok], e[ok]) < tol, k
     assert not torch.equal(fast[3], wave[3])      # different kernels, different product order: bit-equal weights would mean the fallback was not taken
+
+
+@pytest.mark.gpu
+def test_paired_weight_gradient_launches_match_the_single_ones(tmp_path):
+    """Round 5: the two weight-gradient products of a trunk layer (a_l^T hdot_{l-1} and ahat_l^T h_{l-1}) run as ONE launch that changes
+    the accumulators' units between the pairs by a power of two.  DSN_WGRAD_PAIRS=0 keeps a launch per product (the switch is read once
+    per process: sub-processes).  Same sums up to the order of two additions; and the paired form's trunk gradients are bit-reproducible from run to run."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for tag, env_extra in (("pairs", {}), ("pairs_again", {}), ("single", {"DSN_WGRAD_PAIRS": "0"})):
+        env = dict(os.environ, **env_extra)
+        path = str(tmp_path / (tag + ".npz"))
+        p = subprocess.run([sys.executable, os.path.join(here, "_grads_dump.py"), "full_train_grads_w4", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[tag] = dict(np.load(path))
+    # (bit-reproducible: what the two-stage split-fp16 products make - the trunk; the heads' exact-fp32 products and column sums still
+    #  end in float atomics)
+    differ = [k for k, a in outs["pairs"].items() if not np.array_equal(a, outs["pairs_again"][k])]
+    assert differ == [k for k in differ if "stage" not in k] and any("stage" in k for k in outs["pairs"]), differ
+    for k, a in outs["pairs"].items():
+        b = outs["single"][k].astype(np.float64)
+        err = np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+        assert err < 2e-6, (k, err)
