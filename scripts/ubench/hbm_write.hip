@@ -19,6 +19,12 @@
 //     AND stores in issue order, so waiting for that load waits for every store issued before it (what the field kernels' waits for
 //     their LDS-DMA weight ring do to the activation stores issued in front of them)
 //  12 the same load issued BEFORE the 8 stores and consumed behind them (the wait leaves the 8 younger stores in flight)
+//  13-16 a MODEL of k_field16<train>'s memory behaviour: one four-wave workgroup per CU; per "chunk" (one 32-feature output block of one
+//     layer): s_waitcnt vmcnt(0) + barrier, LDS-DMA of the next 32 KB weight chunk from a 7 MB L2-resident image (8 x 1 KB per wave),
+//     ~1500 cycles of dependent FMAs (the chunk's 48 MFMAs), then the block's 4 stores (32 rows x 128 B per wave).
+//     13 = all three; 14 = no stores; 15 = no DMA; 16 = no FMAs; 17 = all three with the wait leaving the 4 younger stores in flight
+//     (vmcnt(4)); 18 = FMAs + barriers alone; 19 / 20 = 16 / 13 with every instruction writing WHOLE 128-byte lines (8 lanes per row, 8 rows per
+//     instruction); 21 / 22 = the same with 64-byte segments (lane quads).  Do stores + weight stream + compute add up or overlap?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +100,76 @@ __global__ void __launch_bounds__(256) k_rows32_ringwait(float4* __restrict__ p,
     }
     if (x == 123.456f) sink[0] = x;
 }
+template <bool STORES, bool DMA, int SPIN, bool LAG = false, int SEG = 32, bool DEEP = false, int SMOD = 0, int LMOD = 0, bool SPREAD = false>
+__global__ void __launch_bounds__(256) k_train_model(float4* __restrict__ p, size_t rows, size_t layer_stride, const char* __restrict__ wimg,
+                                                     float* sink) {
+    __shared__ __attribute__((aligned(16))) char ring[3 * 32768];
+    __shared__ float pad[4 * 256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    if (threadIdx.x == 0) pad[0] = 1.0f;
+    __syncthreads();
+    float x = pad[0] + (float)lane;
+    const unsigned ring_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int chunk = 0;
+    for (size_t t = blockIdx.x; t * 128 < rows; t += gridDim.x) {
+        const size_t row = t * 128 + wave * 32 + (lane & 31);
+        const f4 v = {x, 2.f, 3.f, (float)t};
+        for (int L = 0; L < 7; ++L) {
+            float4* q = p + L * layer_stride + (row < rows ? row : 0) * 64 + half;
+#pragma unroll 1
+            for (int m = 0; m < 8; ++m, ++chunk) {
+                // DEEP: the DMA runs TWO chunks ahead (three ring slots).  In issue order: ... DMA(c+1) stores DMA(c+2) stores | boundary c+1
+                // needs DMA(c+1): 4 + 8 + 4 younger operations may stay in flight - a store then has 3 chunk periods to be acknowledged
+                if (DEEP && chunk > 1) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else if (LAG && chunk > 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (DMA) {
+                    const char* src = wimg + (size_t)(chunk % 218) * 32768 + wave * 8192 + 4096 + lane * 16;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_off + (DEEP ? chunk % 3 : (chunk & 1)) * 32768 + wave * 8192 + 4096);
+if (LMOD == 0) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072\n\tglobal_load_lds_dwordx4 %0, off offset:-4096\n\tglobal_load_lds_dwordx4 %0, off offset:-3072\n\tglobal_load_lds_dwordx4 %0, off offset:-2048\n\tglobal_load_lds_dwordx4 %0, off offset:-1024" : : "v"(src), "s"(dst) : "memory", "m0");
+                    if (LMOD == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt\n\tglobal_load_lds_dwordx4 %0, off offset:1024 nt\n\tglobal_load_lds_dwordx4 %0, off offset:2048 nt\n\tglobal_load_lds_dwordx4 %0, off offset:3072 nt\n\tglobal_load_lds_dwordx4 %0, off offset:-4096 nt\n\tglobal_load_lds_dwordx4 %0, off offset:-3072 nt\n\tglobal_load_lds_dwordx4 %0, off offset:-2048 nt\n\tglobal_load_lds_dwordx4 %0, off offset:-1024 nt" : : "v"(src), "s"(dst) : "memory", "m0");
+                    if (LMOD == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1\n\tglobal_load_lds_dwordx4 %0, off offset:1024 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:2048 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:3072 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-4096 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-3072 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-2048 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-1024 sc1" : : "v"(src), "s"(dst) : "memory", "m0");
+                    if (LMOD == 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:1024 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:2048 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:3072 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-4096 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-3072 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-2048 sc0 sc1\n\tglobal_load_lds_dwordx4 %0, off offset:-1024 sc0 sc1" : : "v"(src), "s"(dst) : "memory", "m0");
+                }
+                if (SPREAD) {      // one store behind each quarter of the chunk's arithmetic (with LAG: the wait leaves these four in flight)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll 1
+                        for (int i = 0; i < SPIN / 4; ++i) x = __builtin_fmaf(x, 1.0000001f, 1e-9f);
+                        float4* a = p + L * layer_stride + (t * 128 + wave * 32 + (lane & 31)) * 64 + 8 * m + 2 * c + half;
+                        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(a), "v"(v) : "memory");
+                    }
+                    continue;
+                }
+                if (STORES) {      // (the previous block's values: issued right behind the boundary, a whole chunk period before the next wait)
+                    // the wave's block = 32 rows x 128 B (8 pieces of 16 B per row), written by 4 instructions of 64 pieces.  SEG = bytes of a
+                    // row one instruction writes contiguously: 32 (the kernels: lane = (half, row), 2 pieces per row), 64 (lane quads),
+                    // 128 (8 lanes = one row's whole line, 8 rows per instruction)
+                    constexpr int PPR = SEG / 16;                 // pieces per row per instruction
+                    constexpr int RPI = 64 / PPR;                 // rows per instruction
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = SEG == 32 ? (lane & 31) : (c * RPI + lane / PPR) % 32;
+                        const int piece = SEG == 32 ? (2 * c + half) : (SEG == 128 ? lane % 8 : (lane % PPR) + PPR * (c / (4 * PPR / 8)) % 8);
+                        float4* a = p + L * layer_stride + (t * 128 + wave * 32 + r) * 64 + 8 * m + piece;
+                        if (SMOD == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(a), "v"(v) : "memory");
+                        if (SMOD == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(a), "v"(v) : "memory");
+                        if (SMOD == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(a), "v"(v) : "memory");
+                        if (SMOD == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(a), "v"(v) : "memory");
+                        if (SMOD == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(a), "v"(v) : "memory");
+                    }
+                }
+                if (SPIN) {
+#pragma unroll 1
+                    for (int i = 0; i < SPIN; ++i) x = __builtin_fmaf(x, 1.0000001f, 1e-9f);
+                }
+            }
+        }
+    }
+    if (x == 123.456f) sink[0] = x + ring[lane];
+}
 template <int LDS_KB, int SPIN>
 __global__ void __launch_bounds__(256) k_rows32_persistent(float4* __restrict__ p, size_t rows, size_t layer_stride, int layers, float* sink) {
     __shared__ float pad[LDS_KB * 256];
@@ -136,7 +212,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float* sink; hipMalloc(&sink, 64);
     float* sink2; hipMalloc(&sink2, 4096); hipMemset(sink2, 0, 4096);
-    for (int pat = 0; pat < 13; ++pat) {
+    char* wimg; hipMalloc(&wimg, 218 * 32768); hipMemset(wimg, 0, 218 * 32768);
+    for (int pat = 0; pat < 42; ++pat) {
         auto launch = [&]() {
             switch (pat) {
                 case 0: hipLaunchKernelGGL(k_stride, dim3(cus * 8), dim3(256), 0, 0, p, n); break;
@@ -151,6 +228,35 @@ int main(int argc, char** argv) {
                 case 9: hipLaunchKernelGGL((k_rows32_persistent<100, 500>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, 7, sink); break;
                 case 11: hipLaunchKernelGGL((k_rows32_ringwait<11>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, 7, (const float*)sink2, sink); break;
                 case 12: hipLaunchKernelGGL((k_rows32_ringwait<12>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, 7, (const float*)sink2, sink); break;
+                case 13: hipLaunchKernelGGL((k_train_model<true, true, 48>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 14: hipLaunchKernelGGL((k_train_model<false, true, 48>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 15: hipLaunchKernelGGL((k_train_model<true, false, 48>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 16: hipLaunchKernelGGL((k_train_model<true, true, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 17: hipLaunchKernelGGL((k_train_model<true, true, 48, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 18: hipLaunchKernelGGL((k_train_model<false, false, 48>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 19: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 128>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 20: hipLaunchKernelGGL((k_train_model<true, true, 48, false, 128>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 21: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 64>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 22: hipLaunchKernelGGL((k_train_model<true, true, 48, false, 64>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 23: hipLaunchKernelGGL((k_train_model<true, true, 48, false, 32, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 24: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 25: hipLaunchKernelGGL((k_train_model<false, true, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 26: hipLaunchKernelGGL((k_train_model<true, false, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 27: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 1, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 28: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 2, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 29: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 3, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 30: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 4, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 31: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 0, 1>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 32: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 0, 2>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 33: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 0, 3>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 34: hipLaunchKernelGGL((k_train_model<true, true, 0, false, 32, false, 1, 1>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 35: hipLaunchKernelGGL((k_train_model<true, true, 48, false, 32, false, 1, 0>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 36: hipLaunchKernelGGL((k_train_model<true, true, 92>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 37: hipLaunchKernelGGL((k_train_model<false, true, 92>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 38: hipLaunchKernelGGL((k_train_model<false, false, 92>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 39: hipLaunchKernelGGL((k_train_model<true, true, 92, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 40: hipLaunchKernelGGL((k_train_model<true, true, 92, true, 32, false, 0, 0, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
+                case 41: hipLaunchKernelGGL((k_train_model<true, true, 92, false, 32, false, 0, 0, true>), dim3(cus), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, (const char*)wimg, sink); break;
                 case 10: hipLaunchKernelGGL((k_rows32_persistent<24, 0>), dim3(cus * 4), dim3(256), 0, 0, p, rows / 7, (rows / 7) * 64, 7, sink); break;
             }
         };
