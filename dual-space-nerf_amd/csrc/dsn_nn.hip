@@ -321,7 +321,11 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
     // samples visit (dsn_launch_build_nn_visited, behind the sampler's classification)
     // dense_fine (the canonical mesh: built once, queried by a per-lane list scan in k_normal): as many fine cells as the level
     // holds - shorter lists per query; the posed mesh's lists are rebuilt per frame and stay at 3 F cells
-    const int t_fine = dense_fine ? dsn_clampi(5 * F, 512, 62000) : dsn_clampi(3 * F, 512, 44000);
+    int t_fine = dense_fine ? dsn_clampi(5 * F, 512, 62000) : dsn_clampi(3 * F, 512, 44000);
+    if (!dense_fine) {      // DSN_NN_FINE_TARGET (tuning): cells of the posed mesh's fine level (lists stay exact for any cell size)
+        static const long long tgt = [] { const char* e = getenv("DSN_NN_FINE_TARGET"); return e ? atoll(e) : 0ll; }();
+        if (tgt > 0) t_fine = dsn_clampi((int)tgt, 512, 62000);
+    }
     const int t_coarse = dsn_clampi(F / 3, 64, 5000);
     // DSN_NN_FINE_CAP (tests): a smaller LOGICAL capacity of the fine level - provokes the overflow path (level unusable, queries fall
     // through to the coarse level / the sweep, the host mirror warns) on a mesh that fits the real one
