@@ -345,6 +345,22 @@ __device__ __forceinline__ void track16(float& ovf, const f32x16& v) {
 }
 __device__ __forceinline__ float dsn_nan_flag() { return __uint_as_float(0x7fc00000u); }
 
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 256)
+// timing emulation (WRONG data, right access pattern) of WHOLE-LINE stores: instruction j writes rows 8 j .. 8 j + 7 of the wave's 32, eight
+// lanes per row = the row's whole 128-byte line of this output block (instead of every lane two 16-byte pieces of its own row: 32
+// partial-line requests per instruction).  The row pointers come from the rows' own lanes by two shuffles per instruction.
+__device__ __forceinline__ void store16_lines_emul(float* st, const float (&o)[16]) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long me = (unsigned long long)(uintptr_t)st;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int src = 8 * j + (lane >> 3);      // the half-0 lane of row 8 j + lane / 8
+        const unsigned lo = __shfl((unsigned)me, src), hi = __shfl((unsigned)(me >> 32), src);
+        float* pj = reinterpret_cast<float*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+        if (pj) *reinterpret_cast<float4*>(pj + 4 * (lane & 7)) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+    }
+}
+#endif
 // Deferred epilogue, two accumulator registers at a time.  With one wave per SIMD nothing else can cover the VALU
 // work of an epilogue (fold, relu / mask, hi-lo split, pack: ~12 instructions per element), so the epilogue of output
 // block m-1 is cut into 8 slices of two elements and slice kb is issued right behind the MFMAs of block (m, kb):
@@ -422,6 +438,19 @@ __device__ __forceinline__ void epi_slice(const f32x16& pM, const f32x16& pC, in
     // store in flight, and it sits right in front of slice 7 (blocks per output tile = blocks per chunk).  Stores issued slice
     // by slice were 1-3 blocks old at that wait and cost a full write latency per chunk (3.84 ms vs 2.34 ms without stores);
     // issued together on slice 7 they have a whole chunk to drain.  The 16 values are recomputed from the accumulators.
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 256)
+    if (ST && kb == 7) {
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = FWD ? (pM[r] + pC[r]) * F16_FWD_INV : fmaf(pC[r], DSN_LO_INV, pM[r]);
+            v = FWD ? fmaxf(v, 0.0f) : dsn_keep_active(v, mword, r);
+            o[r] = v * stscale;
+        }
+        store16_lines_emul(st, o);
+        return;
+    }
+#endif
     if (ST && kb == 7 && st) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -458,6 +487,15 @@ __device__ __forceinline__ void store16(float* st, const f32x16& v, float stscal
             if (pj) *reinterpret_cast<float4*>(pj - 4 * hf + 16 * hf + 4 * i) =
                 make_float4(v[4 * j] * stscale, v[4 * j + 1] * stscale, v[4 * j + 2] * stscale, v[4 * j + 3] * stscale);
         }
+        return;
+    }
+#endif
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 256)
+    {
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = v[r] * stscale;
+        store16_lines_emul(st, o);
         return;
     }
 #endif
@@ -1003,6 +1041,15 @@ __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC
         yl[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, v);
     }
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(vv[0]), "v"(vv[1]));      // range guard (see k_tangent16)
+#if defined(DSN_EXPERIMENTS) && defined(F16_TRAIN_ABL) && (F16_TRAIN_ABL & 256)
+    if (kb == 7) {
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = dsn_keep_active((pM[r] + pC[r]) * F16_FWD_INV, mword, r) * stscale;
+        store16_lines_emul(st, o);
+        return;
+    }
+#endif
     if (st && kb == 7) {      // the block's 16 values again, stored together as four 16-byte pieces (see epi_slice; 8-byte pieces slice by
                               // slice: 1.18 -> 1.09 ms)
 #pragma unroll
