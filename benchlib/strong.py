@@ -360,8 +360,10 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(args.steps, depth, depth > 1)
+        t_enq = time.perf_counter()                   # the host is done enqueueing: what a frame costs the host thread (Python + launches)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / max(1, args.steps)
+        host_ms = 1e3 * (t_enq - t0) / max(1, args.steps)
         alone = []
         for i in range(2 + max(3, min(args.steps, 8))):
             torch.cuda.synchronize()
@@ -373,7 +375,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
                 alone.append(1e3 * (time.perf_counter() - t0))
         cnt = sh.counters(0)
         st = _lib.read_stop_stats(slots.wss[0])
-        rec = {"rays": sh.Rl, "ms": ms, "ms_alone": float(np.mean(alone)), "non_transparent": int(cnt[_lib.CNT_ACTIVE]),
+        rec = {"rays": sh.Rl, "ms": ms, "host_enqueue_ms": host_ms, "ms_alone": float(np.mean(alone)), "non_transparent": int(cnt[_lib.CNT_ACTIVE]),
                "skipped_by_termination": st["skipped"] if sh.stop_on else 0, "shaded": int(cnt[_lib.CNT_LIT]) if sh.stop_on else int(cnt[_lib.CNT_POS]),
                "slice_lengths": sh.schedule}
         return rec, sh
@@ -430,6 +432,7 @@ def strong_emulated(args, dsnerf_amd, _lib, synth, dev):
         ag_ms = gather_ms_priced(R, nw)
         step_ms = float(t.max()) + undeal_ms + ag_ms
         sweeps[nw] = {"world": nw, "partition": part_info, "shares": shares, "share_ms_max": float(t.max()), "share_ms_mean": float(t.mean()),
+                      "host_enqueue_ms_max": float(max(s_["host_enqueue_ms"] for s_ in shares)),
                       "share_ms_min": float(t.min()), "max_over_mean": float(t.max() / t.mean()),
                       "share_ms_alone_max": float(ta.max()), "undeal_ms": undeal_ms, "all_gather_ms_PRICED_not_measured": ag_ms,
                       "sum_of_shares_over_whole_frame": float(t.sum() / whole["ms"]),

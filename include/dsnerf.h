@@ -240,7 +240,7 @@ DSN_EXPORT int dsn_debug_screen(const void* scene, int V, int F, const void* pac
  * are HOST arrays of 33 device pointers in state_dict order with torch Linear layouts; every gradient is overwritten.
  * Includes the second-order path through d sigma/dx -> normal -> lighting (model/spacenet.py:251-265) as a forward
  * tangent pass.  `packed` = dsn_pack_params image of the same parameters.  Activations stay resident in `workspace`
- * (dsn_grad_workspace_bytes(R,S), 22 KB per sample). */
+ * (dsn_grad_workspace_bytes(R,S), 34 KB per sample). */
 DSN_EXPORT size_t dsn_grad_workspace_bytes(int R, int S);
 /* Renderer.render in train mode (can_render.py:137-168 with net.training): dsn_render_rays (dense evaluation, jitter / noise
  * as given) that also leaves what its backward needs in `grad_workspace` (dsn_grad_workspace_bytes(R,S)): canonical points,

@@ -65,8 +65,8 @@ import json, sys
 d = json.load(open(sys.argv[1])); c = d['config']
 w = c['whole_frame_one_gpu']; print('whole frame: %.3f ms pipelined, %.3f alone' % (w['ms'], w['ms_alone']))
 for n, v in sorted(c['worlds'].items(), key=lambda kv: int(kv[0])):
-    print(' N=%s  share max %.3f mean %.3f (alone max %.3f)  max/mean %.3f  sum/whole %.3f  -> %.3f ms/frame, speed-up %.2f (eff %.2f; one at a time %.2f)  %s' % (
-        n, v['share_ms_max'], v['share_ms_mean'], v['share_ms_alone_max'], v['max_over_mean'], v['sum_of_shares_over_whole_frame'], v['predicted_ms_per_frame'],
+    print(' N=%s  share max %.3f mean %.3f (alone max %.3f; host enqueue %.3f)  max/mean %.3f  sum/whole %.3f  -> %.3f ms/frame, speed-up %.2f (eff %.2f; one at a time %.2f)  %s' % (
+        n, v['share_ms_max'], v['share_ms_mean'], v['share_ms_alone_max'], v.get('host_enqueue_ms_max', 0), v['max_over_mean'], v['sum_of_shares_over_whole_frame'], v['predicted_ms_per_frame'],
         v['predicted_speedup'], v['predicted_strong_scaling_efficiency'], v['predicted_speedup_one_frame_at_a_time'], v['partition'].get('bounds', v['partition'].get('tile_rays'))))
 PY
              ;;
