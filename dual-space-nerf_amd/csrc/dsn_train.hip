@@ -160,8 +160,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe(const float* __restrict__ x_
 // tangent of the encoding along u: [u, 2^j cos(2^j x) u, -2^j sin(2^j x) u]
 // (gmax: batch-wide max |tpe| as float bits, for the split-fp16 weight-gradient product; zeroed by the caller.  Grid-stride
 // loop: one look-before-atomicMax per BLOCK - half a million waves reading the same word serialise on its L2 channel)
+// pe (optional, round 5): the encoding itself rides along (same sinf / cosf of the same argument as k_t_pe: one launch and one sweep less)
 __global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restrict__ x_c, const float* __restrict__ u,
-                                                             int64_t N, float* __restrict__ tpe, unsigned* __restrict__ gmax, Rows rw) {
+                                                             int64_t N, float* __restrict__ tpe, unsigned* __restrict__ gmax, Rows rw,
+                                                             float* __restrict__ pe) {
     __shared__ float s_m[T_THREADS / 64];
     float m = 0.0f;
     const int64_t total = rows_n(rw, N) * PE_LD, stride = (int64_t)gridDim.x * T_THREADS;
@@ -169,15 +171,18 @@ __global__ void __launch_bounds__(T_THREADS) k_t_pe_tangent(const float* __restr
         const int64_t n = rows_at(rw, tl >> 6);
         const int c = (int)(tl & 63);
         const int64_t t = n * PE_LD + c;
-        float v = 0.0f;
-        if (c < 3) v = u[3 * n + c];
+        float v = 0.0f, e = 0.0f;
+        if (c < 3) { v = u[3 * n + c]; if (pe) e = x_c[3 * n + c]; }
         else if (c < PE_K) {
             const int j = (c - 3) / 6, r = (c - 3) % 6, a = r % 3;
             const float f = (float)(1 << j);
             const float arg = x_c[3 * n + a] * f;
-            v = (r < 3 ? cosf(arg) : -sinf(arg)) * f * u[3 * n + a];
+            const float sn = (r >= 3 || pe) ? sinf(arg) : 0.0f, cs = (r < 3 || pe) ? cosf(arg) : 0.0f;
+            v = (r < 3 ? cs : -sn) * f * u[3 * n + a];
+            e = r < 3 ? sn : cs;
         }
         tpe[t] = v;
+        if (pe) pe[t] = e;
         const float av = fabsf(v);
         if (av < 3.0e38f) m = fmaxf(m, av);      // non-finite values do not set the scale
     }
@@ -308,9 +313,13 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
 
 // Weight gradient of a layer with 1 or 3 outputs: dW[o][c] += sum_n dY[n,o] X[n,c] (C = 128 or 256), and its bias gradient
 // db[o] += sum_n dY[n,o] - a weighted column sum at the HBM rate (rocBLAS runs these K = 524 288, M <= 3 shapes at 0.23 ms)
+// dX (optional, round 5): the layer's DATA gradient behind the relu that made X rides along in the same sweep,
+//   dX[n,c] = X[n,c] > 0 ? sum_o dY[n,o] W[o,c] : 0
+// - what k_t_seed (OUT = 1) / k_t_rgb_hidden_adjoint (OUT = 3) did in a second pass over X (the same products in the same order)
 template <int OUT>
 __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict__ X, int C, const float* __restrict__ dY, int64_t N,
-                                                          int rows_per_block, float* __restrict__ dW, float* __restrict__ db, Rows rw) {
+                                                          int rows_per_block, float* __restrict__ dW, float* __restrict__ db, Rows rw,
+                                                          const float* __restrict__ W, float* __restrict__ dX) {
     __shared__ float s[OUT][T_THREADS];
     // (C is 128 or 256: wave-uniform row numbers, fetched a step ahead with scalar loads - see k_t_colsum)
     const int c = threadIdx.x % C, r0 = __builtin_amdgcn_readfirstlane(threadIdx.x / C), rs = T_THREADS / C;
@@ -318,9 +327,15 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     int64_t end = base + rows_per_block;
     if (end > NL) end = NL;
-    float acc[OUT], bs[OUT];
+    float acc[OUT], bs[OUT], wv[OUT];
 #pragma unroll
-    for (int o = 0; o < OUT; ++o) { acc[o] = 0.0f; bs[o] = 0.0f; }
+    for (int o = 0; o < OUT; ++o) { acc[o] = 0.0f; bs[o] = 0.0f; wv[o] = dX ? W[o * C + c] : 0.0f; }
+    auto data_grad = [&](int64_t row, float x, const float (&y)[OUT]) {
+        float v = y[0] * wv[0];
+#pragma unroll
+        for (int o = 1; o < OUT; ++o) v = v + y[o] * wv[o];
+        dX[row * C + c] = x > 0.0f ? v : 0.0f;
+    };
     int64_t n = base + r0;
     int64_t id[4];
     auto fetch = [&](int64_t n_) {
@@ -330,6 +345,7 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
     if (n < end) fetch(n);
     for (; n + 3 * (int64_t)rs < end; n += 4 * (int64_t)rs) {            // four rows in flight per thread
         float x[4], y[4][OUT];
+        const int64_t id4[4] = {id[0], id[1], id[2], id[3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t row = id[k];
@@ -342,12 +358,19 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int o = 0; o < OUT; ++o) { acc[o] = fmaf(x[k], y[k][o], acc[o]); bs[o] += y[k][o]; }
+        if (dX) {
+            const int64_t rid[4] = {id4[0], id4[1], id4[2], id4[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) data_grad(rid[k], x[k], y[k]);
+        }
     }
     for (; n < end; n += rs) {
         const int64_t row = rows_at_u(rw, n);
         const float x = X[row * C + c];
+        float yy[OUT];
 #pragma unroll
-        for (int o = 0; o < OUT; ++o) { const float y = dY[row * OUT + o]; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
+        for (int o = 0; o < OUT; ++o) { const float y = dY[row * OUT + o]; yy[o] = y; acc[o] = fmaf(x, y, acc[o]); bs[o] += y; }
+        if (dX) data_grad(row, x, yy);
     }
 #pragma unroll
     for (int o = 0; o < OUT; ++o) s[o][threadIdx.x] = acc[o];
@@ -1815,9 +1838,10 @@ void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st, Rows r
 }
 
 template <int OUT>
-void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st, Rows rw = Rows{nullptr, nullptr}) {
+void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st, Rows rw = Rows{nullptr, nullptr},
+             const float* W = nullptr, float* dX = nullptr) {
     const int rows = 256;
-    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw);
+    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw, W, dX);
 }
 
 }  // namespace
@@ -1922,14 +1946,20 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     if (module) hipLaunchKernelGGL(k_t_flag_cotangent, grid_for(N64), dim3(T_THREADS), 0, st, d_col, d_sig, N64, w.live);
     dsn_train_build_rows(w.live, N64, w.bcnt, w.list2, w.rowcnt + 1, st);
     const Rows R2 = {w.list2, w.rowcnt + 1};
-    hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe, R2);
+    // (the encoding of the backward's rows is written by k_t_pe_tangent below, beside its tangent; DSN_TRAIN_UNFUSED_HEADS=1: by k_t_pe here)
+    static const bool two_pass_heads = [] { const char* e = getenv("DSN_TRAIN_UNFUSED_HEADS"); return e && e[0] == '1'; }();
+    if (two_pass_heads) hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe, R2);
     hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
                        w.d_pre, R2);
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
-    wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2);
-    hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
-                       w.d_hl2, R2);
+    // (the heads' weight gradients and the data gradients behind their relus in ONE sweep over hl2 / rr; DSN_TRAIN_UNFUSED_HEADS=1: two)
+    if (two_pass_heads) {
+        wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2);
+        hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
+                           w.d_hl2, R2);
+    } else
+        wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2, prm[P_L4_W], w.d_hl2);
     T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
     lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2));
@@ -1943,7 +1973,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     {
         const int64_t nb = (N64 * PE_LD + T_THREADS - 1) / T_THREADS;
         hipLaunchKernelGGL(k_t_pe_tangent, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(T_THREADS), 0, st, w.x_c, w.u, N64, w.tpe,
-                           (unsigned*)g_tpe, R2);
+                           (unsigned*)g_tpe, R2, two_pass_heads ? nullptr : w.pe);
     }
     // all seven tangent layers in one fused split-fp16 launch (k_tangent16, relu patterns from the training forward's records),
     // then the weight-gradient products  dW_l += a_l^T hdot_{l-1}
@@ -1964,9 +1994,12 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* cur = w.t0;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------
-    wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2);
-    hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
-                       w.d_rr, R2);
+    if (two_pass_heads) {
+        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2);
+        hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
+                           w.d_rr, R2);
+    } else
+        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2, prm[P_RGB3_W], w.d_rr);
     T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
     wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st, R2);
     // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in

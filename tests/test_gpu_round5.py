@@ -509,7 +509,7 @@ def test_paired_weight_gradient_launches_match_the_single_ones(tmp_path):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}
-    for tag, env_extra in (("pairs", {}), ("pairs_again", {}), ("single", {"DSN_WGRAD_PAIRS": "0"})):
+    for tag, env_extra in (("pairs", {}), ("pairs_again", {}), ("single", {"DSN_WGRAD_PAIRS": "0"}), ("two_pass_heads", {"DSN_TRAIN_UNFUSED_HEADS": "1"})):
         env = dict(os.environ, **env_extra)
         path = str(tmp_path / (tag + ".npz"))
         p = subprocess.run([sys.executable, os.path.join(here, "_grads_dump.py"), "full_train_grads_w4", path], env=env, capture_output=True,
@@ -524,3 +524,10 @@ def test_paired_weight_gradient_launches_match_the_single_ones(tmp_path):
         b = outs["single"][k].astype(np.float64)
         err = np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
         assert err < 2e-6, (k, err)
+        # the heads' data gradients and the backward's encoding written inside the sweeps that read their inputs (default) or by
+        # kernels of their own (DSN_TRAIN_UNFUSED_HEADS=1): the same values, so the trunk's gradients agree bit for bit
+        c = outs["two_pass_heads"][k]
+        if "stage" in k:
+            assert np.array_equal(a, c), k
+        else:
+            assert np.linalg.norm(a.astype(np.float64) - c) / max(np.linalg.norm(c.astype(np.float64)), 1e-30) < 2e-6, k
