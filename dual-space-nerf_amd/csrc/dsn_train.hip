@@ -1962,6 +1962,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2, prm[P_L4_W], w.d_hl2);
     T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
     lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
+    // (the first lighting layer keeps its two passes over d_hl1: a VALU kernel that also accumulates dW0 takes 0.39 ms against
+    //  0.107 for the exact-fp32 MFMA product + 0.129 for the data gradient - tried in round 5)
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2));
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
                        w.d_xl, R2);
