@@ -636,8 +636,9 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     const bool fused_nn = cellmajor && !getenv("DSN_NN_UNFUSED");
     const bool lazy = (flags & DSN_LAZY_LISTS) != 0;
     // a lazily set frame (DSN_FRAME_LAZY_LISTS) outside the fused cell-major path: every cell's lists, here, before anything reads them
-    // (small ray batches, DSN_NN_UNFUSED, the exhaustive cross-check)
-    if (lazy && !fused_nn) dsn_launch_build_nn(s.cent_world, F, s.nn_world, 0.12f, 0.7f, st, true);
+    // (small ray batches, DSN_NN_UNFUSED, the exhaustive cross-check) - ONCE per frame: the device header says whether the level is
+    // still lazy, the chunks after the first find it complete (round 5 rebuilt everything per call)
+    if (lazy && !fused_nn) dsn_launch_build_nn_complete(s.cent_world, F, s.nn_world, st);
     if (fused_nn) {
         // the sampler classifies the samples by fine cell while it writes their z (the first step of the cell-major search)
         int32_t *counts = nullptr, *outside0 = nullptr;

@@ -49,7 +49,7 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
 void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
                                   int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
                                   uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
-                                  int32_t** outside, hipStream_t st, bool classified = false, bool force_ranked = false);
+                                  int32_t** outside, hipStream_t st, bool classified = false, bool lazy_call = false);
 void dsn_launch_lbs_warp(const DsnSceneView& s, const float* pts, int64_t N, const float* smpl_w, const float* A, int bw_type,
                          int32_t* face_idx, float* weights, uint8_t* transparent, float* pts_zero, bool exhaustive, hipStream_t st);
 void dsn_launch_normal(const DsnSceneView& s, const float* x_c, const float* grad, int64_t N,
@@ -60,6 +60,8 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
                          bool fine_only = false, bool dense_fine = false, bool lazy = false);
 // the lists of a lazy fine level for the cells with visited[cell] > 0 (no-op on a level that holds every cell's lists)
 void dsn_launch_build_nn_visited(const float4* cent, int F, const DsnNNView& nn, const int32_t* visited, hipStream_t st);
+// a lazily set fine level completed for every cell - decided on the device: no-op sweeps once the level is complete
+void dsn_launch_build_nn_complete(const float4* cent, int F, const DsnNNView& nn, hipStream_t st);
 void dsn_launch_composite(const float* colour, const float* sigma, const uint8_t* transparent, const float* z_vals,
                           const float* ray_d, const float* noise, int R, int S, float* rgb_map, float* disp_map,
                           float* acc_map, float* weights, float* depth_map, hipStream_t st, bool lazy_colour = false,

@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(1024) k_grid_scan(DsnGrid* __restrict__ g, int
     if (t == 0) {
         offsets[0] = 0; g->total = carry;
         // lazy build: `ok` stays 0 - the lists cover the visited cells only, good for the frame's own fused search and nothing else
-        if (lazy_build) g->lazy = (carry <= g->cap) ? 2 : 1;
+        // (lazy_build = 2, the COMPLETING build of a lazily set level - every cell, dsn_launch_build_nn_complete: 3 = "fits, being
+        //  filled"; k_grid_complete turns that into lazy = 0 / ok = 1 behind the fill)
+        if (lazy_build) g->lazy = (carry <= g->cap) ? (lazy_build == 2 ? 3 : 2) : 1;
         else g->ok = (carry <= g->cap) ? 1 : 0;
     }
 }
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ ce
                                                     void* __restrict__ list, int maxsuper, const int32_t* __restrict__ super_cnt,
                                                     const float4* __restrict__ super_list, const int32_t* __restrict__ visited, int lazy_build) {
     const DsnGrid g = *gp;
-    if (lazy_build ? g.lazy != 2 : !g.ok) return;
+    if (lazy_build ? g.lazy != (lazy_build == 2 ? 3 : 2) : !g.ok) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
@@ -307,6 +309,29 @@ void dsn_launch_build_nn_visited(const float4* cent, int F, const DsnNNView& nn,
                        maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1);
 }
 
+// A lazily set level completed for EVERY cell (a lazily set frame rendered outside the fused cell-major path: small ray batches,
+// DSN_NN_UNFUSED, the exhaustive cross-check).  The device header decides: the sweeps run while it says lazy != 0 and leave a complete
+// level (lazy = 0, ok = 1) behind, so the second chunk of a chunked frame finds nothing to do (round 5 re-ran a full
+// dsn_launch_build_nn - grid parameters, coarse level switched off again - on every such call).  The coarse level is not touched.
+__global__ void k_grid_complete(DsnGrid* __restrict__ g) {
+    if (g->lazy == 3) { g->lazy = 0; g->ok = 1; }
+}
+void dsn_launch_build_nn_complete(const float4* cent, int F, const DsnNNView& nn, hipStream_t st) {
+    const DsnGridView& v = nn.fine;
+    const int maxcell = DSN_NN_FINE_MAXCELL, maxsuper = dsn_grid_maxsuper(maxcell);
+    DsnGridView vv = v;
+    if (getenv("DSN_NN_NO_SUPER")) vv.super_cnt = nullptr;
+    const int32_t* none = nullptr;
+    if (vv.super_cnt)
+        hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none, 2);
+    hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2);
+    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, v.g, v.offsets, 2);
+    hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
+                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2);
+    hipLaunchKernelGGL(k_grid_complete, dim3(1), dim3(1), 0, st, v.g);
+}
+
 static int dsn_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // a level that is not built: dsn_grid_cell() answers -1 for every point (ok = 0), queries go on to the next level / the sweep
@@ -365,6 +390,16 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
                                                               int32_t* __restrict__ cell_of, int32_t* __restrict__ nn,
                                                               int32_t* __restrict__ counts, int32_t* __restrict__ outside) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    if (gf->lazy) {
+        // a lazily set level (DSN_FRAME_LAZY_LISTS) that nobody completed for this call - the two-kernel form is never the one the
+        // visited cells' lists were built for: every sample goes to the pass behind it (k_warp: next level / exhaustive sweep, exact)
+        if (i < N) { cell_of[i] = -1; if (nn) nn[i] = -1; }
+        if (outside) {
+            const unsigned long long om = __ballot(i < N);
+            if (om && (threadIdx.x & 63) == 0) atomicAdd(outside, __popcll(om));
+        }
+        return;
+    }
     float p[3] = {0.f, 0.f, 0.f};
     if (i < N) nns_point(pts, ray_o, ray_d, z_vals, i, S, p);
     const int c = dsn_nns_classify_one(gf, i, i < N, p[0], p[1], p[2], nullptr, cell_of, counts, outside);
@@ -373,12 +408,17 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
 
 // exclusive scans over the cells: sample offsets and wave offsets (ceil(count / NNS_PER) waves per cell); counts are
 // cleared for their second life as scatter cursors.  Single workgroup, LDS-staged tiles (see k_grid_scan).
+// lazy_call: THIS render call ran dsn_launch_build_nn_visited on the level (DSN_LAZY_LISTS).  Only then do lists in state lazy = 2
+// belong to the samples being searched: a level left in that state by an EARLIER call holds the lists of the cells that call's rays
+// visited - a later call without the flag must not walk them (cells only the new rays visit have empty lists, their
+// samples came back with a wrong face and no error); it gets no waves here and k_nns_scatter* hands its samples to the exhaustive pass.
+__device__ __forceinline__ bool nns_lists_usable(const DsnGrid* __restrict__ gf, int lazy_call) { return gf->ok || (lazy_call && gf->lazy == 2); }
 __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
-                                                    int32_t* __restrict__ totals, int keep_counts) {
+                                                    int32_t* __restrict__ totals, int keep_counts, int lazy_call) {
     __shared__ int s_n[1024 * SCAN_PER];
     __shared__ int s_w[16];
-    const int ncell = (gf->ok || gf->lazy == 2) ? gf->ncell : 0;      // (lazy = 2: lists of the visited cells, built for this very search)
+    const int ncell = nns_lists_usable(gf, lazy_call) ? gf->ncell : 0;      // (lazy = 2: lists of the visited cells, built for this very search)
     const int t = threadIdx.x;
     int carry_a = 0, carry_b = 0;
     for (int base = 0; base < ncell; base += 1024 * SCAN_PER) {
@@ -408,9 +448,9 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
 
 // wave w -> its cell (cells with many samples own several consecutive waves)
 __global__ void __launch_bounds__(NNS_THREADS) k_nns_expand(const DsnGrid* __restrict__ gf, const int32_t* __restrict__ wave_offs,
-                                                            const int32_t* __restrict__ totals, int32_t* __restrict__ wave_cell) {
+                                                            const int32_t* __restrict__ totals, int32_t* __restrict__ wave_cell, int lazy_call) {
     const int c = blockIdx.x * NNS_THREADS + threadIdx.x;
-    const int ncell = (gf->ok || gf->lazy == 2) ? gf->ncell : 0;
+    const int ncell = nns_lists_usable(gf, lazy_call) ? gf->ncell : 0;
     if (c >= ncell) return;
     const int w0 = wave_offs[c], w1 = (c + 1 < ncell) ? wave_offs[c + 1] : totals[0];
     for (int w = w0; w < w1; ++w) wave_cell[w] = c;
@@ -421,9 +461,18 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter(const int32_t* __re
                                                              const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                              const float* __restrict__ z_vals, int64_t N, int S,
                                                              const int32_t* __restrict__ offs, int32_t* __restrict__ cursor,
-                                                             float4* __restrict__ sorted) {
+                                                             float4* __restrict__ sorted, const DsnGrid* __restrict__ gf = nullptr,
+                                                             int32_t* __restrict__ cell_rw = nullptr, int32_t* __restrict__ outside = nullptr,
+                                                             int lazy_call = 0) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (gf && gf->lazy && !nns_lists_usable(gf, lazy_call)) {      // (a lazy level without usable lists: see k_nns_scatter_ranked)
+        const bool mine = i < N && cell_rw[i] >= 0;
+        if (mine) cell_rw[i] = -1;
+        const unsigned long long m = __ballot(mine);
+        if (m && lane == 0) atomicAdd(outside, __popcll(m));
+        return;
+    }
     const int c = i < N ? cell_of[i] : -1;
     const NnsRun r = nns_run(c, lane);
     int base = 0;
@@ -442,11 +491,12 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_scatter_ranked(int32_t* __r
                                                                     const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                                     const float* __restrict__ z_vals, int64_t N, int S,
                                                                     const int32_t* __restrict__ offs, float4* __restrict__ sorted,
-                                                                    const DsnGrid* __restrict__ gf, int32_t* __restrict__ outside) {
+                                                                    const DsnGrid* __restrict__ gf, int32_t* __restrict__ outside, int lazy_call) {
     const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
-    if (gf->lazy == 1) {
+    if (gf->lazy && !nns_lists_usable(gf, lazy_call)) {
         // a lazy level whose visited cells' lists did not fit the capacity (k_grid_scan left lazy = 1; the host mirror sees
-        // total > cap in the header and warns): the cell-major search has nothing to walk - every sample is handed to the k_warp
+        // total > cap in the header and warns), or whose lists are another call's (lazy = 2 without DSN_LAZY_LISTS in this call): the
+        // cell-major search has nothing to walk - every sample is handed to the k_warp
         // pass behind it as "outside the fine grid", which sweeps all centroids: the same index, slowly
         const bool mine = i < N && cell_of[i] >= 0;
         if (mine) cell_of[i] = -1;
@@ -655,7 +705,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
 void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const float* ray_d, const float* z_vals, int64_t N, int S,
                                   int32_t* cell_of, void* sorted, void* small, const DsnFaceRec* face_world, const DsnFaceRec* face_canon,
                                   uint8_t* transparent, float* x_c, int32_t* active_list, int32_t* active_count, bool lazy_canon,
-                                  int32_t** outside, hipStream_t st, bool classified, bool force_ranked) {
+                                  int32_t** outside, hipStream_t st, bool classified, bool lazy_call) {
     // classified: the sampler has filled cell_of / counts / the outside counter already (dsn_nn_cellmajor_begin + dsn_launch_sample_gg)
     char* q = (char*)small;
     int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
@@ -674,14 +724,16 @@ void dsn_launch_nn_cellmajor_warp(const DsnNNView& v, const float* ray_o, const 
     // classified by the sampler: it also kept every sample's rank inside its cell (cell_of + N) - the scatter places by rank
     // (DSN_NN_ATOMIC_SCATTER: A/B switch, round 3's scatter with atomic cursors; a lazily built level always takes the ranked form - it
     //  is the one that hands the samples over when the visited cells' lists did not fit)
-    const bool ranked = classified && (force_ranked || !getenv("DSN_NN_ATOMIC_SCATTER"));
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, ranked ? 1 : 0);
-    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
+    const bool ranked = classified && (lazy_call || !getenv("DSN_NN_ATOMIC_SCATTER"));
+    const int lc = lazy_call ? 1 : 0;
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, ranked ? 1 : 0, lc);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell, lc);
     if (ranked)
         hipLaunchKernelGGL(k_nns_scatter_ranked, gN, b, 0, st, cell_of, (const int32_t*)(cell_of + N), ray_o, ray_d, z_vals, N, S, offs,
-                           (float4*)sorted, (const DsnGrid*)v.fine.g, totals + 2);
+                           (float4*)sorted, (const DsnGrid*)v.fine.g, totals + 2, lc);
     else
-        hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
+        hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, (const float*)nullptr, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted,
+                           (const DsnGrid*)v.fine.g, cell_of, totals + 2, lc);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     const NnsWarp wp = {face_world, face_canon, transparent, x_c, active_list, active_count, lazy_canon ? 1 : 0};
     hipLaunchKernelGGL(k_nns_search<true>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
@@ -715,8 +767,8 @@ void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* 
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_FINE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify, gN, b, 0, st, v.fine.g, pts, ray_o, ray_d, z_vals, N, S, cell_of, nn, counts, (int32_t*)nullptr);
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, 0);
-    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.fine.g, counts, offs, wave_offs, totals, 0, 0);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_FINE_MAXCELL / NNS_THREADS), b, 0, st, v.fine.g, wave_offs, totals, wave_cell, 0);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, ray_o, ray_d, z_vals, N, S, offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_FINE_MAXCELL + 1;
     hipLaunchKernelGGL(k_nns_search<false>, dim3((unsigned)((max_waves + 3) / 4)), b, 0, st, v.fine.offsets, (const float4*)v.fine.list,
@@ -755,8 +807,8 @@ void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, cons
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_COARSE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify_coarse, gN, b, 0, st, v.fine.g, v.coarse.g, pts, live, N, cell_of, nn, counts);
-    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 0);
-    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell);
+    hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 0, 0);
+    hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell, 0);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,
                        offs, counts, (float4*)sorted);
     const int64_t max_waves = N / NNS_PER + DSN_NN_COARSE_MAXCELL + 1;

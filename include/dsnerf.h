@@ -346,8 +346,11 @@ DSN_EXPORT int dsn_set_early_stop_colour_scale(void* packed, float colour_scale,
  * flight, +3 to +6 % for a frame that runs alone (profiles/r03_frames_in_flight.txt) - set it only when frames overlap.  Same values. */
 #define DSN_SHARE_CUS 2048
 /* the scene's frame was set with DSN_FRAME_LAZY_LISTS: this call's geometry phase completes the posed mesh's fine lists - for the
- * cells its samples visit (frames of >= 1 M samples: the cell-major search), for every cell otherwise.  Without the flag a lazily set
- * frame still renders exactly (every sample takes the exhaustive sweep); with the flag on a fully built level nothing is rebuilt. */
+ * cells its samples visit (frames of >= 1 M samples: the cell-major search; those lists belong to THIS call: the next call with the
+ * flag builds its own, the next call without it does not walk them), for every cell otherwise (once: the level is an ordinary,
+ * fully built one afterwards and later calls find nothing to do).  Without the flag a lazily set frame still renders exactly (every
+ * sample takes the exhaustive sweep - also after an earlier call with the flag); with the flag on a fully built level nothing is
+ * rebuilt. */
 #define DSN_LAZY_LISTS 4096
 /* (The test override DSN_STOP_SLICE changes the workspace layout and is read at every call: set it before the workspace is sized
  *  and leave it alone while it is in use.) */

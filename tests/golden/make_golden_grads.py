@@ -63,7 +63,11 @@ def grads_of(render, batch, seed, loss_fn, dtype):
     return fwd, out
 
 
-def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, seed=233):
+def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, seed=233, config2=False):
+    """config2: BASELINE configs[2]'s own size (8192 rays x 64 samples).  float32 reference only (its float64 twin does not fit the
+    build container's memory), and the fixture keeps what cannot be regenerated: the loss, the 33 norms / sums / sub-sampled
+    gradients and the per-ray outputs - rays, body, draws and targets are functions of the seeds (tests/test_gpu_train.py rebuilds
+    them the same way)."""
     import torch
     rh.install_shims()
     from utils.loss import make_loss            # the reference's loss module (torch only)
@@ -78,7 +82,7 @@ def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, see
     torch.manual_seed(seed)                     # the draws the reference will make (pts_utils.py:12, nerf_net_utils.py:31)
     arrs["jitter"] = torch.rand(1, R, S).numpy()[0]
     arrs["noise"] = (torch.randn(R, S) * raw_noise_std).numpy()
-    for dtype in ("float32", "float64"):
+    for dtype in (("float32",) if config2 else ("float32", "float64")):
         render = rh.build_reference(canon, faces, state, S, dtype=dtype)
         render.cfg.MODEL.raw_noise_std = raw_noise_std
         render.cfg.MODEL.LOSSwMask = True
@@ -94,6 +98,14 @@ def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, see
         for k, v in out.items():
             arrs[k + sfx] = v
     path = os.path.join(HERE, name + ".npz")
+    if config2:
+        keep = ("S", "frame", "Th", "raw_noise_std", "seed", "render:color", "render:acc_map", "render:depth_map")
+        arrs = {k: v for k, v in arrs.items() if k in keep or k.split(":")[0] in ("loss", "norm", "sum", "grad")}
+        arrs["rays"] = np.int64(R)
+        arrs["z_vals_sum"] = np.float64(fwd["z_vals"].astype(np.float64).sum())
+        np.savez_compressed(path, **arrs)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB; loss {arrs['loss']:.6f}")
+        return
     np.savez_compressed(path, **arrs)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB; loss {arrs['loss']:.6f} (f64 {arrs['loss_f64']:.6f})")
     for k in ("nerf.stage1.0.weight", "nerf.stage2.4.weight", "lighting_mlp.lights_encoding.0.weight", "pose_mlp.0.weight",
@@ -104,6 +116,21 @@ def case(name, canon, faces, xyz, poses, rays, sel, S, state, raw_noise_std, see
 def main():
     import torch
     torch.set_num_threads(8)
+    if "--config2" in sys.argv:                  # BASELINE configs[2] at its own size: 8192 rays x 64 samples of the 512 x 512 view
+        tag = ([a for a in sys.argv[sys.argv.index("--config2") + 1:] if not a.startswith("-")] or ["default"])[0]
+        if tag == "default":
+            state = synth.make_state_dict()
+        else:
+            z = np.load(os.path.join(HERE, f"weights_{tag}.npz"))
+            state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+        poses = synth.make_poses()
+        canon, faces = synth.make_body()
+        xyz = synth.pose_body(canon)
+        rays = synth.make_rays(512, 512, xyz, fit_box=True)
+        sel = np.linspace(0, 512 * 512 - 1, 8192).astype(np.int64)
+        case("full_train_grads_8192" + ("" if tag == "default" else "_" + tag), canon, faces, xyz, poses, rays, sel, 64, state,
+             raw_noise_std=1.0, config2=True)
+        return
     if "--nonuniform" in sys.argv:               # the SMPL-like body (synth.make_body(nonuniform=True)): dense caps at head / hands / feet
         state = synth.make_state_dict()
         poses = synth.make_poses()
