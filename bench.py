@@ -15,8 +15,10 @@ Prints ONE JSON line on rank 0.  Extra objects:
                  separate stage-by-stage pass over the same frame; algorithmic FLOPs = evaluated samples
                  x 0.91776 MFLOP (2 x 458 880 MAC: trunk + heads); the reverse kernel (analytic d sigma/dx,
                  2 x 425 728 MAC per sigma > 0 sample) is reported beside it.
-  cpu_baseline - the C oracle (oracle/dsn_oracle.c, a port of the reference algorithm) timed on the host
-                 cores on a bounded sample of the same frame (rank 0, N=1 only).
+                 + whole_frame_frac (field FLOPs executed per frame / frame time / ceiling) and mfma_busy (committed PMC passes).
+  cpu_baseline - the torch restatement of the reference's op sequence (oracle/train_oracle.py; north_star's "reference CPU
+                 PyTorch path", which itself cannot travel) timed on the host cores on one 3072-ray chunk of the same frame
+                 (rank 0, N=1 only); cpu_baseline_c: the OpenMP C port of the same algorithm (oracle/dsn_oracle.c) beside it.
 """
 from __future__ import annotations
 

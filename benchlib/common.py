@@ -155,7 +155,7 @@ def launch_ranks(args):
 
 
 def _profile_file(stem):
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
         if os.path.exists(path):
             return path
@@ -185,6 +185,20 @@ def measured_traffic(kern, args):
     return rec["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                          f"`bench.py --steps 5 --warmup 2 --pipeline 1 --no-roofline`, average over the kernel's launches; "
                                          f"not collected in this run)")
+
+
+def measured_mfma_busy(kern, args):
+    """share of the kernel's SIMD cycles with the matrix pipe busy, from the committed PMC passes of this command
+    (SQ_VALU_MFMA_BUSY_CYCLES over per-XCD GRBM_GUI_ACTIVE x the chip's 1024 SIMDs; scripts/pmc_summary.py) - not collected in this run"""
+    tag = _profile_tag(args)
+    path = None if tag is None else _profile_file(tag + "pmc.json")
+    if path is None:
+        return None, None
+    with open(path) as f:
+        rec = json.load(f).get(kern)
+    if rec is None or rec.get("mfma_busy_frac") is None:
+        return None, None
+    return rec["mfma_busy_frac"], os.path.relpath(path, ROOT)
 
 
 def rocprof_kernel_ms(mangled_part, args, drop_largest=0):

@@ -842,11 +842,21 @@ bool wgrad_mfma(int64_t N, int in, int in_valid, int out, const float* X, int ld
 typedef _Float16 t_half8 __attribute__((ext_vector_type(8)));
 typedef int t_i32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) t_i32x4* t_cptr4;
-__device__ __forceinline__ float t_pow2_at_least(float s) {      // smallest power of two >= s (1 for s <= 0 or non-finite)
+// smallest power of two >= s (1 for s <= 0 or non-finite), never below 2^-40: the product of two operand scales and the ratio of two
+// such products (t_pair_ratio) stay normal floats when an operand's batch-wide magnitude has all but vanished (two
+// tiny maxima multiplied to 0, the paired launches' ratio to inf / NaN, 0 x inf poisoned dW where the single launches gave 0)
+__device__ __forceinline__ float t_pow2_at_least(float s) {
     if (!(s > 0.0f) || !(s < 3.0e38f)) return 1.0f;
     int e;
     const float m = frexpf(s, &e);                                // s = m 2^e, m in [0.5, 1)
-    return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+    e = m == 0.5f ? e - 1 : e;
+    return ldexpf(1.0f, e < -40 ? -40 : e);
+}
+// factor that takes accumulators from the units of one operand pair (s1 = sy sx) to those of the next (s2): both powers of two with
+// s2 >= 2^-80, so the quotient is exact; capped at 2^126 (reached only by operands 2^46 times apart in both factors), never inf
+__device__ __forceinline__ float t_pair_ratio(float s1, float s2) {
+    const float r = s1 / s2;
+    return r < 8.5e37f ? r : 8.507059e37f;
 }
 // The kernel: operand rows are staged through LDS by the DMA engine (global_load_lds_dwordx4, one 1 KB row per
 // wave-instruction, no staging registers; W16S_STAGES - 1 steps of 16 rows x 2 operands = 32 KB each in flight per CU, every
@@ -1189,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
         const float* const sy2_ptr = ops.sy2;
         const float* const sx2_ptr = ops.sx2;
         const float sy2 = sy2_ptr ? t_pow2_at_least(*sy2_ptr) : 1.0f, sx2 = sx2_ptr ? t_pow2_at_least(*sx2_ptr) : 1.0f;
-        const float ratio = (sy * sx) / (sy2 * sx2);
+        const float ratio = t_pair_ratio(sy * sx, sy2 * sx2);
 #pragma unroll
         for (int a = 0; a < OT; ++a)
 #pragma unroll
@@ -1505,7 +1515,7 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
         const float* const sy2_ptr = ops.sy2;
         const float* const sx2_ptr = ops.sx2;
         const float sy2 = sy2_ptr ? t_pow2_at_least(*sy2_ptr) : 1.0f, sx2 = sx2_ptr ? t_pow2_at_least(*sx2_ptr) : 1.0f;
-        const float ratio = (sy * sx) / (sy2 * sx2);
+        const float ratio = t_pair_ratio(sy * sx, sy2 * sx2);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -174,11 +174,31 @@ class RayParallel:
         origin for the whole batch (utils/pts_utils.py:31), so this is meant for rays of one camera."""
         return self.render_partitioned(render_fn, ray_o, ray_d, near, far, self.tile_plan(ray_o.shape[0], tile, ray_o.device))
 
+    def agreed_bounds(self, bounds):
+        """rank 0's cut points on every rank: ONE broadcast of world + 1 integers on the group's device.  The gather of
+        render_partitioned() exchanges equal slabs whose size follows from the cuts - ranks that cut differently (a cost measured on
+        their own GPU, a borderline comparison falling differently) would post mismatched collectives: a hang or corrupt pixels."""
+        if self.world == 1:
+            return [int(b) for b in bounds]
+        t = torch.tensor([int(b) for b in bounds], dtype=torch.int64, device=self._group_device())
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return [int(b) for b in t.cpu()]
+
     def render_blocks(self, render_fn, ray_o, ray_d, near, far, cost=None):
         """like render(), with contiguous blocks cut for equal cost (cost [R]: any per-ray estimate, e.g. the evaluated samples of a
-        previous frame of the sequence; None = equal ray counts).  Every rank must pass the same cost."""
+        previous frame of the sequence; None = equal ray counts).  The ranks need NOT pass identical costs: rank 0's cuts are
+        broadcast (one small collective per NEW cost - the cuts of a cost tensor seen before, same object and same
+        version, are reused, so a sequence rendered with one estimate pays for it once)."""
         R = ray_o.shape[0]
-        bounds = self.balanced_bounds(torch.ones(R) if cost is None else cost, self.world)
+        key = None if cost is None else (id(cost), getattr(cost, "_version", None), R)
+        cached = getattr(self, "_agreed", None)
+        if cached is not None and cached[0] == key and cached[1] == R:
+            bounds = cached[2]
+        else:
+            bounds = self.balanced_bounds(torch.ones(R) if cost is None else cost, self.world)
+            if cost is not None:                     # (equal ray counts are a function of R and the world size alone)
+                bounds = self.agreed_bounds(bounds)
+            self._agreed = (key, R, bounds)
         return self.render_partitioned(render_fn, ray_o, ray_d, near, far, self.block_plan(R, bounds, ray_o.device))
 
     def render_partitioned(self, render_fn, ray_o, ray_d, near, far, plan: dict):

@@ -42,6 +42,9 @@ def install_shims():
             assert K == 1
             f32 = p1.dtype == torch.float32
             outs_d, outs_i = [], []
+            # (no autograd graph through the distances: the reference uses the INDEX only - utils/render_utils.py:95-99 gathers the
+            #  face by idx, `dist` is dropped - and a graph over [N, F] chunks does not fit the container at 8192 x 64 samples)
+            p1, p2 = p1.detach(), p2.detach()
             for b in range(p1.shape[0]):
                 dd, ii = [], []
                 for s in range(0, p1.shape[1], 2048):

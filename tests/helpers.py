@@ -1,10 +1,12 @@
 """Shared helpers for the test-suite (test infrastructure only)."""
 import os
+import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+if os.path.join(ROOT, "oracle") not in sys.path:      # (conftest.py does this for pytest; the probe scripts import helpers directly)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
 CASES = ["small_eval", "small_train", "small_novel", "small_rot", "full_eval"]
 # the same stage / end-to-end cases on two more parameter sets (tests/golden/make_golden.py --other-weights):
 #   _w2: TRAINED by the real reference (tests/golden/make_weights_w2.py; weights_w2.npz) - larger, non-uniform layer scales
@@ -19,26 +21,7 @@ NU_CASES = ["full_eval_nu", "full_eval_nu_w4"]
 ALL_CASES = CASES + W_CASES + NU_CASES
 
 
-def load(name):
-    return np.load(os.path.join(GOLDEN, name + ".npz"))
-
-
-_STATE = {}
-
-
-def state(name=None):
-    """the 33 parameters a golden case was generated with (by case name; default set when the name carries no tag)"""
-    import dsnerf_amd.synth as synth
-    tag = next((t for t in ("w2", "w3", "w4") if name and "_" + t in name), "")
-    if tag not in _STATE:
-        if tag in ("w2", "w4"):
-            z = np.load(os.path.join(GOLDEN, f"weights_{tag}.npz"))
-            _STATE[tag] = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
-        elif tag == "w3":
-            _STATE[tag] = synth.make_state_dict(seed=7, gain=3.5)
-        else:
-            _STATE[tag] = synth.make_state_dict()
-    return _STATE[tag]
+from cases import GOLDEN, code_for, load, state  # noqa: E402,F401  (oracle/cases.py: shared with __graft_entry__.smoke())
 
 
 def ref_tol(g, key, base, rel=4e-6):
@@ -49,11 +32,6 @@ def ref_tol(g, key, base, rel=4e-6):
     companions of the fixtures are NOT a usable floor here, they differ in the canonical points themselves."""
     m = float(np.abs(g[key]).max())
     return base if m <= 100.0 else max(base, rel * m)     # the bar itself wherever the magnitudes leave float32 room for it
-
-
-def code_for(g, sd, name):
-    c = sd["nerf.embedding.weight"][int(g["frame"])]
-    return c * 0 if name.startswith("small_novel") else c   # test.py:193-196 sets net.nerf.w = 0
 
 
 def light_kw(g):

@@ -7,7 +7,9 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05_bench.json")
+LINE = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_bench.json") for r in ("r06", "r05")) if os.path.exists(p)),
+            os.path.join(ROOT, "profiles", "r05_bench.json"))
+ROUND6 = os.path.basename(LINE).startswith("r06")
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +33,13 @@ def test_contract_keys(line):
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    if ROUND6:
+        # the torch restatement (north_star's "reference CPU PyTorch path") is THE cpu_baseline, the C port beside it;
+        # the roofline block carries the whole frame's fraction and the matrix pipe's busy share next to the kernel's
+        assert "torch" in cb["sample"] and line["cpu_baseline_c"]["kind"] == "port" and "OpenMP" in line["cpu_baseline_c"]["sample"]
+        assert abs(rf["whole_frame_frac"] - line["whole_frame"]["frac"]) < 1e-12 and 0.0 < rf["whole_frame_frac"] < rf["frac"]
+        assert rf["mfma_busy"] is None or 0.3 < rf["mfma_busy"] < 1.0
+        assert "4e-6" in line["dtype"] and "1e-4" in line["dtype"]
 
 
 def test_sample_fractions_say_what_each_stage_ran_on(line):

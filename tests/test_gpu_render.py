@@ -11,40 +11,7 @@ from helpers import ALL_CASES, CASES, code_for, light_kw, load, maxdiff, ref_tol
 pytestmark = pytest.mark.gpu
 
 
-def make_cfg(S):
-    return SimpleNamespace(DATASETS=SimpleNamespace(SMPL_PATH="<synthetic>"),
-                           MODEL=SimpleNamespace(sample_points_mode="GG", COARSE_RAY_SAMPLING=S, perturb=1.0,
-                                                 raw_noise_std=1.0, TYPE="nerf", FINE_RAY_SAMPLING=-1))
-
-
-def make_renderer(g, name=None, density_screen=True):
-    """(density_screen: the product default is OFF since round 4 - test_density_screen_is_opt_in; the suite opts in wherever it builds
-    a Renderer, so every parity test also covers the harder configuration: the screen runs whenever its calibration lets it)"""
-    import dsnerf_amd
-    S = int(g["S"])
-    net = dsnerf_amd.DualSpaceNeRF(make_cfg(S))
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in state(name).items()})
-    net.cuda()
-    r = dsnerf_amd.Renderer(net, None, make_cfg(S), torch.from_numpy(g["canonical_vertex"]),
-                            body_data={"f": g["faces"]})
-    assert r.density_screen is False
-    r.density_screen = bool(density_screen)
-    if name == "small_novel":
-        r.net.set_light_center(torch.from_numpy(g["light_center"]))
-        r.net.nerf.w = 0
-    if name == "small_rot":
-        r.net.set_rot_center(torch.from_numpy(g["rot_center"]))
-        r.net.set_rot(torch.from_numpy(g["rot"]))
-    return r
-
-
-def make_batch(g):
-    return {
-        "ray_o": torch.from_numpy(g["ray_o"])[None], "ray_d": torch.from_numpy(g["ray_d"])[None],
-        "near": torch.from_numpy(g["near"].copy())[None], "far": torch.from_numpy(g["far"].copy())[None],
-        "xyz": torch.from_numpy(g["xyz"])[None], "poses": torch.from_numpy(g["poses"])[None],
-        "Th": torch.from_numpy(g["Th"]).reshape(1, 1, 3), "frame": torch.tensor([int(g["frame"])]),
-    }
+from cases import make_batch, make_cfg, make_renderer  # noqa: E402,F401  (oracle/cases.py: shared with __graft_entry__.smoke())
 
 
 @pytest.mark.parametrize("name", ALL_CASES)

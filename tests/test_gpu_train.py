@@ -1,12 +1,15 @@
 """GPU parity of the training row: parameter gradients of Renderer.render through the C ABI
 (dsn_render_rays_grad) against (a) gradients captured from the reference's own loss.backward()
 (tests/golden/*_grads.npz) and (b) the differentiable CPU oracle (oracle/train_oracle.py)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import train_oracle as TO
-from helpers import load, state
+from helpers import load, maxdiff, state
 from test_gpu_render import make_batch, make_renderer
 
 pytestmark = pytest.mark.gpu
@@ -14,29 +17,36 @@ pytestmark = pytest.mark.gpu
 GRAD_CASES = ["small_train_grads", "small_train_grads_nonoise", "full_train_grads", "small_train_grads_w2", "full_train_grads_w2",
               "small_train_grads_w4", "full_train_grads_w4",
               "full_train_grads_nu"]        # the SMPL-like body (dense caps at head / hands / feet): make_golden_grads.py --nonuniform
-FULL_LIMIT, SAMPLE = 20000, 4096
+from cases import FULL_LIMIT, SAMPLE, reference_loss, rel, sample_index  # noqa: E402,F401
 
 
-def sample_index(n):                         # the sub-sampling rule of tests/golden/make_golden_grads.py
-    return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n
+# ---- what the kernels ACHIEVE, and the bars derived from it ---------------------------------------------------
+# tests/golden/achieved_grad_errors.json holds, per case and per parameter tensor, the relative L2 error measured on the MI355X
+# (scripts/record_grad_errors.py; the numbers are in the file, with the commit and the box they come from).  A test passes when
+# every tensor stays within HEADROOM x its recorded error (or the float32 floor below, for tensors whose error is already there):
+# a regression of one order of magnitude fails - rounds 3-5 accepted 2e-3 / 5e-3 where 3e-7 ... 3e-5 were achieved.
+ACHIEVED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "achieved_grad_errors.json")
+HEADROOM = 10.0
+FLOOR = 2e-6          # relative L2 below which two float32 summation orders differ anyway (atomics in the small head products)
 
 
-def rel(a, b):
-    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+def achieved(kind, case):
+    if not os.path.exists(ACHIEVED):
+        pytest.fail("tests/golden/achieved_grad_errors.json is missing: run scripts/record_grad_errors.py on the GPU box and commit it")
+    with open(ACHIEVED) as f:
+        rec = json.load(f)
+    if case not in rec.get(kind, {}):
+        pytest.fail(f"no recorded errors for {kind} / {case}: run scripts/record_grad_errors.py on the GPU box and commit the file")
+    return rec[kind][case]
 
 
-def reference_loss(out, target, occ):
-    """utils/loss.py:11-30 with LOSSwMask: MSE on colour + 0.1 * L1(acc with occupied rays forced to 1, occupancy);
-    trainer.py:73-76 sums the terms."""
-    loss = torch.nn.functional.mse_loss(out["color"], target)
-    acc = out["acc_map"]
-    acc[occ == 1] = 1                         # in place, as the reference does on the renderer's output
-    return loss + 0.1 * torch.nn.functional.l1_loss(acc, occ)
+def bar(recorded):
+    return max(HEADROOM * float(recorded), FLOOR)
 
 
-@pytest.mark.parametrize("name", GRAD_CASES)
-def test_backward_matches_reference_autograd(name):
+def reference_case_errors(name):
+    """one training forward + backward of a golden gradient case -> (loss, reference loss, {tensor: rel. L2 vs the reference's float32
+    autograd on the stored elements}, {tensor: |norm - reference norm| / reference norm}, {tensor: the reference's own f32-vs-f64 spread})"""
     g = load(name)
     r = make_renderer(g, name)
     r.cfg.MODEL.raw_noise_std = float(g["raw_noise_std"])
@@ -45,34 +55,43 @@ def test_backward_matches_reference_autograd(name):
     out = r.render(make_batch(g))["coarse"]
     assert np.array_equal(out["z_vals"].cpu().numpy(), g["render:z_vals"])
     loss = reference_loss(out, torch.from_numpy(g["target_rgb"]).cuda(), torch.from_numpy(g["occupancy"]).cuda())
-    ref = float(g["loss"])
-    assert abs(float(loss) - ref) < 2e-6 * max(1.0, abs(ref)), (float(loss), ref)
     r.net.zero_grad()
     loss.backward()
-    worst = {}
+    err, nerr, spread = {}, {}, {}
     for k, p in r.net.named_parameters():
         assert p.grad is not None, k
-        a = p.grad.detach().cpu().numpy().reshape(-1)
-        a = a if a.size <= FULL_LIMIT else a[sample_index(a.size)]
+        full = p.grad.detach().cpu().numpy().reshape(-1)
+        a = full if full.size <= FULL_LIMIT else full[sample_index(full.size)]
         b32, b64 = g["grad:" + k], g["grad:" + k + "_f64"]
-        # the reference's float32 and float64 runs differ by 1e-3 .. 4e-2 per tensor (ReLU-kink flips, PE x512):
-        # stay within twice that spread of the float32 reference, and within 2e-3 where the spread is smaller
-        tol = max(2e-3, 2.0 * rel(b32, b64))
-        worst[k] = (rel(a, b32), tol)
-        assert rel(a, b32) < tol, (k, rel(a, b32), tol)
-        assert abs(np.linalg.norm(p.grad.detach().cpu().numpy().astype(np.float64)) - float(g["norm:" + k])) \
-            < tol * float(g["norm:" + k]) + 1e-12, k
-    print({k: "%.1e" % v[0] for k, v in worst.items()})
+        err[k] = rel(a, b32)
+        spread[k] = rel(b32, b64)
+        nerr[k] = abs(float(np.linalg.norm(full.astype(np.float64))) - float(g["norm:" + k])) / max(float(g["norm:" + k]), 1e-30)
+    assert r.range_overflow_count() == 0
+    return float(loss), float(g["loss"]), err, nerr, spread
 
 
-@pytest.mark.parametrize("name,nrays,nsamp", [("small_train_grads", None, None), ("full_train_grads", None, None),
-                                              ("full_train_grads", 37, None), ("full_train_grads", 37, 21),
-                                              ("small_train_grads_w2", None, None), ("full_train_grads_w2", None, None),
-                                              ("small_train_grads_w4", None, None), ("full_train_grads_w4", None, None),
-                                              ("full_train_grads_nu", None, None)])
-def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
-    """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) == autograd of the
-    CPU oracle on the same inputs, full tensors."""
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_backward_matches_reference_autograd(name):
+    loss, ref, err, nerr, spread = reference_case_errors(name)
+    assert abs(loss - ref) < 2e-6 * max(1.0, abs(ref)), (loss, ref)
+    rec = achieved("reference", name)
+    for k in err:
+        # within 10 x the error recorded for this tensor (3e-7 ... 3e-5; the reference's own float32 and float64 runs differ by
+        # 1e-3 ... 4e-2 per tensor - ReLU-kink flips, PE x512 - which is how far ANY float32 implementation is from the truth)
+        assert err[k] <= bar(rec[k]), (k, err[k], rec[k])
+        assert err[k] < max(2e-3, 2.0 * spread[k]), (k, err[k], spread[k])        # (and never beyond rounds 3-5's bound)
+        assert nerr[k] <= bar(rec[k]), (k, nerr[k], rec[k])
+    print({k: "%.1e" % v for k, v in err.items()})
+
+
+ORACLE_CASES = [("small_train_grads", None, None), ("full_train_grads", None, None), ("full_train_grads", 37, None),
+                ("full_train_grads", 37, 21), ("small_train_grads_w2", None, None), ("full_train_grads_w2", None, None),
+                ("small_train_grads_w4", None, None), ("full_train_grads_w4", None, None), ("full_train_grads_nu", None, None)]
+
+
+def oracle_case_errors(name, nrays, nsamp):
+    """dsn_render_rays_grad with cotangents on every output (colour, disp, acc, depth, weights) against autograd of the CPU oracle on
+    the same inputs, full tensors -> {tensor: rel. L2}"""
     from dsnerf_amd import _lib
     g = dict(load(name).items())
     if nrays is not None:                      # a ray count that is no multiple of the 32-point wave tiles / 128-point blocks
@@ -104,10 +123,80 @@ def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
     grads = _lib.render_rays_grad(r.scene, {k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, T(g["poses"]),
                                   int(g["frame"]), False, T(g["ray_o"]), T(g["ray_d"]), T(z), T(noise), T(cot["color"]),
                                   T(cot["disp_map"]), T(cot["acc_map"]), T(cot["depth_map"]), T(cot["weights"]))
+    err = {}
     for k, gr in zip(_lib.PARAM_ORDER, grads):
         want = params[k].grad.numpy() if params[k].grad is not None else np.zeros_like(sd[k])
-        e = rel(gr.cpu().numpy(), want)
+        err[k] = rel(gr.cpu().numpy(), want)
+    return err
+
+
+def oracle_case_key(name, nrays, nsamp):
+    return f"{name}|{nrays}|{nsamp}"
+
+
+@pytest.mark.parametrize("name,nrays,nsamp", ORACLE_CASES)
+def test_backward_matches_oracle_all_cotangents(name, nrays, nsamp):
+    err = oracle_case_errors(name, nrays, nsamp)
+    rec = achieved("oracle", oracle_case_key(name, nrays, nsamp))
+    for k, e in err.items():
+        assert e <= bar(rec[k]), (k, e, rec[k])
         assert e < 5e-3, (k, e)
+
+
+def config2_batch(R=8192, S=64, hw=512):
+    """BASELINE configs[2]'s own batch, as tests/golden/make_golden_grads.py --config2 builds it for the reference: 8192 rays spread
+    over the 512 x 512 view of the synthetic body, hash-generated targets / occupancy (nothing but seeds is stored)"""
+    from dsnerf_amd import synth
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(hw, hw, xyz, fit_box=True)
+    sel = np.linspace(0, hw * hw - 1, R).astype(np.int64)
+    g = {"canonical_vertex": canon, "faces": faces.astype(np.int32), "xyz": xyz, "poses": synth.make_poses(),
+         "Th": np.asarray((0.2, -0.1, 1.0), np.float32), "frame": np.int64(5), "S": np.int64(S),
+         "ray_o": rays["ray_o"][sel], "ray_d": rays["ray_d"][sel], "near": rays["near"][sel], "far": rays["far"][sel],
+         "target_rgb": synth.hash_uniform(R * 3, 91).reshape(R, 3).astype(np.float32),
+         "occupancy": (synth.hash_uniform(R, 92) > 0.5).astype(np.float32)}
+    return g
+
+
+def config2_errors(name="full_train_grads_8192"):
+    g = load(name)
+    R, S = int(g["rays"]), int(g["S"])
+    b = config2_batch(R, S)
+    r = make_renderer(b, name)
+    r.cfg.MODEL.raw_noise_std = float(g["raw_noise_std"])
+    r.train()
+    torch.manual_seed(int(g["seed"]))
+    out = r.render(make_batch(b))["coarse"]
+    fwd = {k: maxdiff(out[k].detach().cpu().numpy(), g["render:" + k]) for k in ("color", "acc_map", "depth_map")}
+    zsum = float(out["z_vals"].double().sum())
+    loss = reference_loss(out, torch.from_numpy(b["target_rgb"]).cuda(), torch.from_numpy(b["occupancy"]).cuda())
+    r.net.zero_grad()
+    loss.backward()
+    err, nerr = {}, {}
+    for k, p in r.net.named_parameters():
+        full = p.grad.detach().cpu().numpy().reshape(-1)
+        a = full if full.size <= FULL_LIMIT else full[sample_index(full.size)]
+        err[k] = rel(a, g["grad:" + k])
+        nerr[k] = abs(float(np.linalg.norm(full.astype(np.float64))) - float(g["norm:" + k])) / max(float(g["norm:" + k]), 1e-30)
+    assert r.range_overflow_count() == 0
+    return float(loss), float(g["loss"]), fwd, (zsum, float(g["z_vals_sum"])), err, nerr
+
+
+def test_full_batch_matches_the_reference_at_8192x64():
+    """BASELINE configs[2] AT ITS OWN SIZE against the real reference (rounds 3-5 pinned the training step by
+    the reference at 64 / 128 rays and checked 8192 x 64 through additivity / linearity only).  The fixture is the reference's
+    float32 loss.backward() on the 8192-ray batch, run in the build container (tests/golden/make_golden_grads.py --config2: loss,
+    per-ray outputs, 33 norms and sub-sampled gradients; its float64 twin does not fit the container's memory)."""
+    loss, ref, fwd, (zsum, zref), err, nerr = config2_errors()
+    assert abs(zsum - zref) <= 1e-9 * abs(zref), (zsum, zref)             # the sampler (jitter included) is bit-exact: same sum
+    assert fwd["color"] < 1e-4 and fwd["acc_map"] < 1e-4 and fwd["depth_map"] < 5e-4, fwd
+    assert abs(loss - ref) < 2e-6 * max(1.0, abs(ref)), (loss, ref)
+    rec = achieved("reference", "full_train_grads_8192")
+    for k in err:
+        assert err[k] <= bar(rec[k]), (k, err[k], rec[k])
+        assert nerr[k] <= bar(rec[k]), (k, nerr[k], rec[k])
+    print({k: "%.1e" % v for k, v in err.items()})
 
 
 def test_training_steps_reduce_the_loss():

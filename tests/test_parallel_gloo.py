@@ -49,6 +49,16 @@ def _worker(rank, world, port, R, q):
     builds = rp.plan_builds
     rp.render_blocks(_fake_render, o, d, n, f, cost=None)
     ok = ok and rp.plan_builds == builds
+    # ranks that bring DIFFERENT costs (each measured its own) still exchange matching slabs: rank 0's cuts are broadcast inside
+    # render_blocks; the same cost object a second time costs no collective and no plan
+    mine = torch.arange(R).float() * (1.0 + 3.0 * rank) + (R - torch.arange(R)).float() * (3.0 - 2.0 * rank)
+    out4 = rp.render_blocks(_fake_render, o, d, n, f, cost=mine)
+    ok = ok and all(torch.equal(out4[k], ref[k]) for k in ref)
+    want = rp.balanced_bounds(torch.arange(R).float() + (R - torch.arange(R)).float() * 3.0, world)      # rank 0's cost
+    ok = ok and rp._agreed[2] == want
+    builds = rp.plan_builds
+    rp.render_blocks(_fake_render, o, d, n, f, cost=mine)
+    ok = ok and rp.plan_builds == builds
     # (measured re-balancing: the block that took twice as long gives rays away)
     if R >= 8:
         b0 = rp.balanced_bounds(torch.ones(R), 2, align=1)
