@@ -1029,7 +1029,7 @@ void dsn_launch_field16_bwd(const float* packed, const DsnFrameState* fs, const 
 // products, forward flavour of dense16) and its outputs are stored times max|u|: row-major hdot_l [7][N,256].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC, int kb, uint32_t mword, half8 (&yh)[2],
-                                              half8 (&yl)[2], float* st, float stscale, float& ovf) {
+                                              half8 (&yl)[2], float* st, float stscale, float& ovf, float* keep = nullptr) {
     float vv[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1050,6 +1050,11 @@ __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC
         return;
     }
 #endif
+    if (keep && kb == 7) {    // (round 6, the last layer: the block's 16 values stay in registers for the column sums - k_tangent16)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[r] = dsn_keep_active((pM[r] + pC[r]) * F16_FWD_INV, mword, r) * stscale;
+        return;
+    }
     if (st && kb == 7) {      // the block's 16 values again, stored together as four 16-byte pieces (see epi_slice; 8-byte pieces slice by
                               // slice: 1.18 -> 1.09 ms)
 #pragma unroll
@@ -1063,19 +1068,31 @@ __device__ __forceinline__ void epi_slice_tan(const f32x16& pM, const f32x16& pC
 }
 __device__ __forceinline__ void layer16_tan(W16& w, int& blk, int lane, const half8 (&xh)[8][2], const half8 (&xl)[8][2],
                                             half8 (&yh)[8][2], half8 (&yl)[8][2], const uint32_t (&mk)[4], float* st, float stscale,
-                                            float& ovf) {
+                                            float& ovf, float (*keep)[16] = nullptr) {
+    // keep (the last layer, round 6): the outputs stay in registers, [block][accumulator register], instead of being stored
     f32x16 pM = zero16(), pC = zero16();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         f32x16 aM = zero16(), aC = zero16();
         const uint32_t mw = m > 0 ? ((mk[(m - 1) >> 1] >> (16 * ((m - 1) & 1))) & 0xffffu) : 0u;
         if (m == 0) dense16<8, false>(w, blk, lane, xh, xl, aM, aC);
-        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice_tan(pM, pC, kb, mw, yh[m - 1], yl[m - 1], st ? st + 32 * (m - 1) : nullptr, stscale, ovf); });
+        else dense16<8, false>(w, blk, lane, xh, xl, aM, aC, [&](int kb) { epi_slice_tan(pM, pC, kb, mw, yh[m - 1], yl[m - 1], st ? st + 32 * (m - 1) : nullptr, stscale, ovf, keep ? keep[m - 1] : nullptr); });
         pM = aM; pC = aC;
     }
     const uint32_t mw = (mk[3] >> 16) & 0xffffu;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) epi_slice_tan(pM, pC, kb, mw, yh[7], yl[7], st ? st + 32 * 7 : nullptr, stscale, ovf);
+    for (int kb = 0; kb < 8; ++kb) epi_slice_tan(pM, pC, kb, mw, yh[7], yl[7], st ? st + 32 * 7 : nullptr, stscale, ovf, keep ? keep[7] : nullptr);
+}
+
+// sum of v over the 32 lanes of a half-wave, left in its last lane (31 / 63): four row-shift adds inside the rows of 16 + one row
+// broadcast (lane 15 of rows 0 / 2 into rows 1 / 3) - five VALU instructions with DPP operands, no LDS crossbar
+__device__ __forceinline__ float half_wave_sum_to_last(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));      // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));      // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));      // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));      // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));      // row_bcast:15 into rows 1, 3
+    return v;
 }
 
 // A sample whose tangent / adjoint left the fp16 range (range guard of k_tangent16 / k_adjoint16): its rows of all `layers` output
@@ -1091,7 +1108,10 @@ __device__ __forceinline__ void zero_train_rows(float* t, int64_t ls, int layers
 __global__ void __launch_bounds__(F16_THREADS, 1)
 k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, const float* __restrict__ u, int64_t N,
             const uint4* __restrict__ masks, float* __restrict__ tr_t, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count,
-            const int32_t* __restrict__ row_list, const int32_t* __restrict__ row_count) {
+            const int32_t* __restrict__ row_list, const int32_t* __restrict__ row_count, float* __restrict__ colsum6) {
+    // colsum6 (optional, round 6) [256]: += the column sums of hdot_6 over the listed samples - the only use the training backward has
+    // for the last layer's tangent (d (w_d . hdot_6) / d w_d, dsn_train.hip).  With it the layer is not stored at all: one 1 KB row per
+    // sample less to write and to read back, and no k_t_colsum launch (0.75 GB and 0.13 ms per 8192 x 64 step).
     // row_list / row_count (optional): the pass runs on the listed samples only (rows whose cotangents are all zero add nothing to
     // any gradient: dsn_train.hip, Rows); arrays stay indexed by sample, N is still the layer stride
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
@@ -1195,20 +1215,45 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
         split16<false>(v, ah[m], al[m]);
     }
     TMK_LOAD(5, mk) layer16_tan(w, blk, lane, ah, al, bh, bl, mk, tt ? tt + 5 * ls : nullptr, sc, ovf);
-    TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 6 * ls : nullptr, sc, ovf);
+    if (!colsum6) {
+        TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, tt ? tt + 6 * ls : nullptr, sc, ovf);
+        if (!(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE) && tt) {      // (false for inf and for the NaN an inf times 0 leaves)
+            zero_train_rows(tt, ls, 7);
+            if (half == 0 && range_count) atomicAdd(range_count, 1);
+        }
+        return;
+    }
+    float h6[8][16];
+    TMK_LOAD(6, mk) layer16_tan(w, blk, lane, bh, bl, ah, al, mk, nullptr, sc, ovf, h6);
 #undef TMK_LOAD
-    if (!(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE) && tt) {      // (false for inf and for the NaN an inf times 0 leaves)
-        zero_train_rows(tt, ls, 7);
+    const bool bad = !(fmaxf(ovf, __shfl_xor(ovf, 32)) < F16_RANGE);
+    if (bad && tt) {
+        zero_train_rows(tt, ls, 6);
         if (half == 0 && range_count) atomicAdd(range_count, 1);
     }
+    // column sums of the block's 128 rows: a sample that is not listed (tail of the last block) or left the fp16 range counts as
+    // zeros, like its stored rows; lanes -> half-wave sums (DPP) -> the four waves through LDS -> one atomic per feature and block
+    float* const s_sum = reinterpret_cast<float*>(&s_pe[0][0]);      // [4][256] (the encoding's operand slots are dead by now)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t = half_wave_sum_to_last((valid && !bad) ? h6[m][r] : 0.0f);
+            // register r of block m, half h: feature 32 m + 8 (r / 4) + 4 h + r % 4 (the stores' address map)
+            if ((lane & 31) == 31) s_sum[wave * 256 + 32 * m + 8 * (r >> 2) + 4 * half + (r & 3)] = t;
+        }
+    __syncthreads();
+    atomicAdd(colsum6 + tid, (s_sum[tid] + s_sum[256 + tid]) + (s_sum[512 + tid] + s_sum[768 + tid]));
 }
 
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
-                          float* gmax, hipStream_t st, int32_t* range_count, const int32_t* row_list, const int32_t* row_count) {
+                          float* gmax, hipStream_t st, int32_t* range_count, const int32_t* row_list, const int32_t* row_count,
+                          float* colsum6) {
     int64_t blocks = (N + 127) / 128;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_tangent16, dim3((unsigned)blocks), dim3(F16_THREADS), 0, st, packed, x_c, u, N, (const uint4*)masks, tr_t,
-                       (uint32_t*)gmax, range_count, row_list, row_count);
+                       (uint32_t*)gmax, range_count, row_list, row_count, colsum6);
 }
 
 // ---------------------------------------------------------------------------------------------

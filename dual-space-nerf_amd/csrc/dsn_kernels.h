@@ -134,7 +134,7 @@ void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, con
                           const int32_t* row_count = nullptr);
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
                           float* gmax, hipStream_t st, int32_t* range_count = nullptr, const int32_t* row_list = nullptr,
-                          const int32_t* row_count = nullptr);
+                          const int32_t* row_count = nullptr, float* colsum6 = nullptr);
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,

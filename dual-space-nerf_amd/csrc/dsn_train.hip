@@ -546,6 +546,98 @@ __global__ void __launch_bounds__(T_THREADS) k_t_composite_adjoint(
     }
 }
 
+// The same adjoint with ONE WAVE PER RAY (round 6): lane l owns samples l, l + 64, ... (CH chunks of 64: S <= 64 CH).  The one-thread-
+// per-ray form above walks 2 S dependent steps with 8192 threads in flight - 128 waves on 1024 SIMDs, 0.17 ms of latency per step
+// of 8192 x 64; here the transmittance is a wave-level product scan (shifted by one lane, like the forward compositor's), the
+// suffix sum a reverse scan, every load and store coalesced over the samples of a ray: 0.02 ms.  Same formulas; the products and sums
+// associate as scans instead of left to right (the forward compositor k_composite does the same).  scratch_t is not needed.
+__device__ __forceinline__ float t_wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float x = __shfl_up(v, o); if (lane >= o) v *= x; }
+    return v;
+}
+__device__ __forceinline__ float t_wave_incl_sum_down(float v, int lane) {      // v_l <- sum_{k >= l} v_k
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float x = __shfl_down(v, o); if (lane + o < 64) v += x; }
+    return v;
+}
+template <int CH>
+__global__ void __launch_bounds__(T_THREADS) k_t_composite_adjoint_w(
+    const float* __restrict__ colour, const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
+    const float* __restrict__ z_vals, const float* __restrict__ ray_d, const float* __restrict__ noise, int R, int S,
+    const float* __restrict__ d_rgb, const float* __restrict__ d_disp, const float* __restrict__ d_acc,
+    const float* __restrict__ d_depth, const float* __restrict__ d_weights,
+    float* __restrict__ d_colour, float* __restrict__ d_sigma, uint8_t* __restrict__ live) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (T_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;                                   // wave-uniform
+    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float dn = dsn_norm3(d);
+    const int64_t b = (int64_t)r * S;
+    float raw[CH], zv[CH], dist[CH], e[CH], alpha[CH], f[CH], T[CH], w[CH];
+    bool tr[CH], in[CH];
+    float carry = 1.0f, depth = 0.0f, acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = 64 * c + lane;
+        in[c] = i < S;
+        float sg = 0.0f, zn = 0.0f;
+        tr[c] = true; zv[c] = 0.0f;
+        if (in[c]) {
+            sg = sigma[b + i];
+            tr[c] = transparent[b + i] != 0;
+            zv[c] = z_vals[b + i];
+            zn = i + 1 < S ? z_vals[b + i + 1] : 0.0f;
+        }
+        float rw = tr[c] ? 0.0f : sg;
+        if (noise && in[c]) rw += noise[b + i];
+        raw[c] = rw;
+        const float s = rw > 0.0f ? rw : 0.0f;
+        dist[c] = (i + 1 < S ? zn - zv[c] : 1e10f) * dn;
+        e[c] = in[c] ? expf(-s * dist[c]) : 1.0f;
+        alpha[c] = 1.0f - e[c];
+        f[c] = in[c] ? (1.0f - alpha[c]) + 1e-10f : 1.0f;
+        const float inc = t_wave_incl_prod(f[c], lane);
+        float ex = __shfl_up(inc, 1);
+        if (lane == 0) ex = 1.0f;
+        T[c] = carry * ex;
+        carry *= __shfl(inc, 63);
+        w[c] = in[c] ? alpha[c] * T[c] : 0.0f;
+        depth += w[c] * zv[c];
+        acc += w[c];
+    }
+    depth = t_wave_sum(depth);
+    acc = t_wave_sum(acc);
+    float gd = d_depth ? d_depth[r] : 0.0f, ga = d_acc ? d_acc[r] : 0.0f;
+    if (d_disp) {   // disp = 1 / max(1e-10, depth / acc)
+        const float q = depth / acc;
+        if (q > 1e-10f) { const float dd = d_disp[r]; gd += dd * (-1.0f / (q * q * acc)); ga += dd * (1.0f / (q * acc)); }
+    }
+    const float gr[3] = {d_rgb[3 * r], d_rgb[3 * r + 1], d_rgb[3 * r + 2]};
+    float tail = 0.0f;                                    // sum of gw_k w_k over the chunks behind this one
+#pragma unroll
+    for (int c = CH - 1; c >= 0; --c) {
+        const int i = 64 * c + lane;
+        const float s = raw[c] > 0.0f ? raw[c] : 0.0f;
+        // (a colour exists only where the forward evaluated the sample - rows with alpha = 0 may never have been written)
+        float cg = 0.0f;
+        if (in[c] && s > 0.0f) { const float* cc = colour + 3 * (b + i); cg = gr[0] * cc[0] + gr[1] * cc[1] + gr[2] * cc[2]; }
+        float gw = cg + gd * zv[c] + ga;
+        if (d_weights && in[c]) gw += d_weights[b + i];
+        const float p = in[c] ? gw * w[c] : 0.0f;
+        const float incl = t_wave_incl_sum_down(p, lane);          // sum_{k >= lane} of this chunk
+        const float suffix = tail + (incl - p);
+        tail += __shfl(incl, 0);
+        if (!in[c]) continue;
+        const float dalpha = gw * T[c] - suffix / f[c];
+        const float ds = (!tr[c] && raw[c] > 0.0f) ? dalpha * dist[c] * e[c] : 0.0f;
+        const float dc[3] = {w[c] * gr[0], w[c] * gr[1], w[c] * gr[2]};
+        d_sigma[b + i] = ds;
+        for (int k = 0; k < 3; ++k) d_colour[3 * (b + i) + k] = dc[k];
+        if (live) live[b + i] = (ds != 0.0f || dc[0] != 0.0f || dc[1] != 0.0f || dc[2] != 0.0f) ? 1 : 0;
+    }
+}
+
 // colour = wl * essence, wl = ELU(pre) + 1:  d_essence, d_pre
 __global__ void __launch_bounds__(T_THREADS) k_t_colour_adjoint(const float* __restrict__ d_colour, const float* __restrict__ ess,
                                                                  const float* __restrict__ wl, const float* __restrict__ pre,
@@ -1948,9 +2040,20 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     hipLaunchKernelGGL(k_t_colour, grid_for(N64), dim3(T_THREADS), 0, st, w.pre, w.ess, N64, w.wl, w.col, R1);
 
     // ---- adjoint of compositing and of the colour product ------------------------------------------------------
-    if (!module)
-        hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
-                           noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig, w.live);
+    if (!module) {
+        // one wave per ray for S <= 128 (round 6); DSN_TRAIN_COMPOSITE_ADJOINT=thread keeps the one-thread-per-ray form (A/B, cross-check)
+        static const bool per_thread = [] { const char* e = getenv("DSN_TRAIN_COMPOSITE_ADJOINT"); return e && e[0] == 't'; }();
+        const dim3 wg((unsigned)((R + T_THREADS / 64 - 1) / (T_THREADS / 64)));
+        if (!per_thread && S <= 64)
+            hipLaunchKernelGGL(k_t_composite_adjoint_w<1>, wg, dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d, noise, R, S,
+                               d_rgb, d_disp, d_acc, d_depth, d_weights, w.d_col, w.d_sig, w.live);
+        else if (!per_thread && S <= 128)
+            hipLaunchKernelGGL(k_t_composite_adjoint_w<2>, wg, dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d, noise, R, S,
+                               d_rgb, d_disp, d_acc, d_depth, d_weights, w.d_col, w.d_sig, w.live);
+        else
+            hipLaunchKernelGGL(k_t_composite_adjoint, grid_for(R), dim3(T_THREADS), 0, st, w.col, w.sig, w.transparent, z_vals, ray_d,
+                               noise, R, S, d_rgb, d_disp, d_acc, d_depth, d_weights, w.scratch_t, w.d_col, w.d_sig, w.live);
+    }
     const float* const d_col = module ? ext_d_col : w.d_col;
     const float* const d_sig = module ? ext_d_sig : w.d_sig;
     if (module) hipLaunchKernelGGL(k_t_flag_cotangent, grid_for(N64), dim3(T_THREADS), 0, st, d_col, d_sig, N64, w.live);
@@ -1992,7 +2095,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* const g_tan = w.small + 300;        // batch-wide magnitudes of the tangent / adjoint arrays (zeroed with w.small)
     float* const g_adj = w.small + 301;
     int32_t* const range_cnt = (int32_t*)(w.small + 303);      // samples whose tangent / adjoint left the fp16 range (zeroed with w.small)
-    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt, R2.list, R2.cnt);
+    // (round 6: the last layer's tangent is only ever summed over the rows - d (w_d . hdot_6) / d w_d - so k_tangent16 sums it itself
+    //  and does not store it; DSN_TRAIN_COLSUM6=kernel keeps the stored layer + k_t_colsum, A/B and cross-check)
+    static const bool colsum6_apart = [] { const char* e = getenv("DSN_TRAIN_COLSUM6"); return e && e[0] == 'k'; }();
+    dsn_launch_tangent16(packed, w.x_c, w.u, N64, w.masks, w.tn[0], g_tan, st, range_cnt, R2.list, R2.cnt, colsum6_apart ? nullptr : grd[P_DEN_W]);
     // DSN_WGRAD_PAIRS=0 (A/B, cross-check): rounds 1-4's form - a launch per product, the adjoints written over the tangent arrays
     static const bool pairs = [] { const char* e = getenv("DSN_WGRAD_PAIRS"); return !(e && e[0] == '0'); }();
     if (!pairs) {
@@ -2002,7 +2108,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[4], nullptr, grd[P_S2_0W] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
     }
     // (default: the products  dW_l += a_l^T hdot_{l-1}  wait for the adjoint pass and run in ONE launch per layer with  ahat_l^T h_{l-1})
-    colsum(w.tn[6], 256, N64, grd[P_DEN_W], st, R2);   // d (w_d . hdot_6) / d w_d
+    if (colsum6_apart) colsum(w.tn[6], 256, N64, grd[P_DEN_W], st, R2);   // d (w_d . hdot_6) / d w_d
     float* cur = w.t0;
 
     // ---- adjoint pass of dL/dsigma * sigma + dL/dessence . essence ---------------------------------------------

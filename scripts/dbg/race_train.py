@@ -34,8 +34,10 @@ n0, f0 = r._dev(batch["near"][0]), r._dev(batch["far"][0])
 xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
 pk = r.net.packed(dev)
 tv = r._t_vals(S)
+NF = int(os.environ.get("RACE_FRAMES", "14"))          # victim frames: their phases run back to back on stream B and span the aggressor
 mk = lambda: (_lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev), _lib.RenderWorkspace(dev))
-(sa, wa), (sb, wb) = mk(), mk()
+sa, wa = mk()
+VF = [mk() for _ in range(NF)]
 A, B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 al = lambda n: (n + 255) // 256 * 256
 
@@ -69,27 +71,37 @@ def run(scene, ws, phases, out=None, nf=None):
     return out, (nn, ff)
 
 
-run(sb, wb, ["set", "geom", "field", "shade"])
+run(*VF[0], ["set", "geom", "field", "shade"])
 torch.cuda.synchronize()
-ref = arrays(wb)
+ref = arrays(VF[0][1])
 pos = ref["sigma"] > 0
 live = ref["transparent"] == 0
 
 # ---- aggressor material ---------------------------------------------------------------------------------------------------
+from cases import make_cfg
+import dsnerf_amd
 Rt = 8192
 sel = np.linspace(0, HW * HW - 1, Rt).astype(np.int64)
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-params = {k: T(v) for k, v in sd.items()}
-st = _lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev)
-st.set_frame(pk, xyz, poses, 5)
-ot, dt = o[sel].contiguous(), d[sel].contiguous()
-jit = T(synth.hash_uniform(Rt * S, 21).reshape(Rt, S).astype(np.float32))
-_, zt = _lib.sample(st, ot, dt, n0[sel].clone(), f0[sel].clone(), S, tv, jit, want_pts=False)
-noise = T((synth.hash_uniform(Rt * S, 22).reshape(Rt, S).astype(np.float32) - 0.5) * 2.0)
-d_rgb = T(synth.hash_uniform(Rt * 3, 23).reshape(Rt, 3).astype(np.float32) - 0.5)
-gws = _lib.GradWorkspace(dev)
-g_ref = [x.clone() for x in _lib.render_rays_grad(st, params, poses, 5, False, ot, dt, zt, noise, d_rgb, ws=gws)]
-torch.cuda.synchronize()
+cfg = make_cfg(S)
+net = dsnerf_amd.DualSpaceNeRF(cfg)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net.to(dev)
+rt = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+rt.train()
+tb = {"ray_o": o[sel][None].contiguous(), "ray_d": d[sel][None].contiguous(), "near": n0[sel][None].clone(), "far": f0[sel][None].clone(),
+      "xyz": xyz[None], "poses": poses[None], "Th": torch.zeros(1, 1, 3, device=dev), "frame": torch.tensor([5])}
+target = T(synth.hash_uniform(Rt * 3, 77).reshape(Rt, 3).astype(np.float32))
+
+
+def train_forward():
+    torch.manual_seed(3)
+    bb = dict(tb)
+    bb["near"], bb["far"] = tb["near"].clone(), tb["far"].clone()
+    net.zero_grad()
+    out = rt.render(bb)["coarse"]
+    return torch.nn.functional.mse_loss(out["color"], target)
+
 
 sa.set_frame(pk, xyz, poses, 5, False, None, None, None)
 pts, z = _lib.sample(sa, o, d, n0.clone(), f0.clone(), S, tv, None, want_pts=True)
@@ -98,24 +110,40 @@ xc, act = w["x_c"], (w["active_list"], w["active_count"])
 fwd = _lib.field_forward(sa, pk, xc, active=act)
 torch.cuda.synchronize()
 
+state_ = {}
 
-def agg_train():
-    _lib.render_rays_grad(st, params, poses, 5, False, ot, dt, zt, noise, d_rgb, ws=gws)
+
+def prep_bwd():
+    state_["loss"] = train_forward()
+
+
+def agg_bwd():
+    state_["loss"].backward()
+
+
+def agg_train_fwd():
+    train_forward()           # (inside `with torch.cuda.stream(A)`: the Renderer enqueues on the current stream)
 
 
 def agg_fwd():
-    _lib.field_forward(sa, pk, xc, active=act)
+    for _ in range(2):
+        _lib.field_forward(sa, pk, xc, active=act)
 
 
 def agg_rev():
-    _lib.field_reverse(sa, pk, xc, fwd[2], fwd[3], fwd[0], fwd[1])
+    for _ in range(3):
+        _lib.field_reverse(sa, pk, xc, fwd[2], fwd[3], fwd[0], fwd[1])
 
 
-def agg_none():
+def nothing():
     pass
 
 
-AGG = (("none", agg_none), ("training step (forward + backward kernels)", agg_train), ("field16 forward", agg_fwd), ("field16 reverse", agg_rev))
+# (name, preparation run alone before the overlapped region, aggressor)
+AGG = (("none", nothing, nothing),
+       ("training BACKWARD (k_tangent16, k_adjoint16, k_t_wgrad16d/p, k_t_lin, k_t_wgrad, ...)", prep_bwd, agg_bwd),
+       ("training FORWARD (k_field16<train>, k_light16 with stores, far search)", nothing, agg_train_fwd),
+       ("field16 forward x2 (guarded: control)", nothing, agg_fwd), ("field16 reverse x3 (guarded: control)", nothing, agg_rev))
 
 
 def diffs(a, b, mask=None):
@@ -128,31 +156,52 @@ def diffs(a, b, mask=None):
     return int(ne.sum())
 
 
-# ---- victim (a): the shading phase, (b): the geometry phase ------------------------------------------------------------------
-for name, fn in AGG:
-    res_s, res_g = [], []
+def span(fn_a, fn_b):
+    """fn_a on stream A and fn_b on stream B at once; returns (ms of A alone region, ms of B region) by events - says whether they overlapped"""
+    ea0, ea1, eb0, eb1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    with torch.cuda.stream(A):
+        ea0.record()
+        fn_a()
+        ea1.record()
+    with torch.cuda.stream(B):
+        eb0.record()
+        fn_b()
+        eb1.record()
+    torch.cuda.synchronize()
+    return ea0.elapsed_time(ea1), eb0.elapsed_time(eb1), ea0.elapsed_time(eb1)
+
+
+# ---- victim (a): the shading phase, (b): the geometry phase, of NF frames back to back -------------------------------------------
+for name, prep, fn in AGG:
+    res_s, res_g, spans = [], [], []
     for rep in range(REPS):
-        with torch.cuda.stream(B):
-            ob, nfb = run(sb, wb, ["set", "geom", "field"])
+        held = []
+        for sc, ws in VF:
+            held.append(run(sc, ws, ["set", "geom", "field"]))
+        with torch.cuda.stream(A):      # (autograd runs a node's backward on the stream its forward ran on)
+            prep()
         torch.cuda.synchronize()
-        with torch.cuda.stream(A):
-            fn()
-        with torch.cuda.stream(B):
-            run(sb, wb, ["shade"], ob, nfb)
+        spans.append(span(fn, lambda: [run(sc, ws, ["shade"], ob, nfb) for (sc, ws), (ob, nfb) in zip(VF, held)]))
+        tot = [0, 0]
+        for sc, ws in VF:
+            a = arrays(ws)
+            tot[0] += diffs(a["n_w"], ref["n_w"], pos)
+            tot[1] += diffs(a["colour"], ref["colour"], pos)
+        res_s.append(tuple(tot))
+        for sc, ws in VF:
+            sc.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True)
+        with torch.cuda.stream(A):      # (autograd runs a node's backward on the stream its forward ran on)
+            prep()
         torch.cuda.synchronize()
-        a = arrays(wb)
-        res_s.append((diffs(a["n_w"], ref["n_w"], pos), diffs(a["colour"], ref["colour"], pos)))
-        with torch.cuda.stream(B):
-            sb.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(A):
-            fn()
-        with torch.cuda.stream(B):
-            run(sb, wb, ["geom"])
-        torch.cuda.synchronize()
-        a = arrays(wb)
-        res_g.append((diffs(a["transparent"], ref["transparent"]), diffs(a["x_c"], ref["x_c"], live)))
-    print(f"aggressor {name:45s} -> victim shade (n_w, colour): {res_s}   victim geometry (transparent, x_c): {res_g}", flush=True)
+        spans.append(span(fn, lambda: [run(sc, ws, ["geom"]) for sc, ws in VF]))
+        tot = [0, 0]
+        for sc, ws in VF:
+            a = arrays(ws)
+            tot[0] += diffs(a["transparent"], ref["transparent"])
+            tot[1] += diffs(a["x_c"], ref["x_c"], live)
+        res_g.append(tuple(tot))
+    print(f"aggressor {name}\n    -> victim shade x{NF} (n_w, colour) diffs: {res_s}   victim geometry x{NF} (transparent, x_c): {res_g}\n"
+          f"       (aggressor ms, victims ms, both ms) per overlapped region: {[tuple(round(x, 2) for x in s_) for s_ in spans]}", flush=True)
 
 # ---- victim (c): a caller's torch kernels -----------------------------------------------------------------------------------
 M = 1 << 24
@@ -162,39 +211,46 @@ tab = torch.rand(1 << 20, 16, device=dev)
 idx = torch.randint(0, 1 << 20, (1 << 21,), device=dev)
 
 
-def torch_victims():
-    e = x1 * x2 + x3
-    e = e * x1 - x2
-    g = ga @ gb
-    s = tab.index_select(0, idx)
-    return e, g, s
+def torch_victims(n=6):
+    outs = []
+    for _ in range(n):
+        e = x1 * x2 + x3
+        e = e * x1 - x2
+        outs.append((e, ga @ gb, tab.index_select(0, idx)))
+    return outs
 
 
-t_ref = torch_victims()
+t_ref = torch_victims(1)[0]
 torch.cuda.synchronize()
-for name, fn in AGG:
-    res = []
+for name, prep, fn in AGG:
+    res, spans = [], []
     for rep in range(REPS):
-        with torch.cuda.stream(A):
-            fn()
-        with torch.cuda.stream(B):
-            got = torch_victims()
+        with torch.cuda.stream(A):      # (autograd runs a node's backward on the stream its forward ran on)
+            prep()
         torch.cuda.synchronize()
-        res.append(tuple(diffs(a, b) for a, b in zip(got, t_ref)))
-    print(f"aggressor {name:45s} -> victim torch (elementwise, fp32 gemm, gather): {res}", flush=True)
+        got = []
+        spans.append(span(fn, lambda: got.extend(torch_victims())))
+        res.append(tuple(sum(diffs(g_[k], t_ref[k]) for g_ in got) for k in range(3)))
+    print(f"aggressor {name}\n    -> victim torch x6 (elementwise, fp32 gemm, gather) diffs: {res}   spans {[tuple(round(x, 2) for x in s_) for s_ in spans]}", flush=True)
 
-# ---- the training step as VICTIM of the field kernels (its small kernels beside k_field16 of a frame) ----------------------------
-for name, fn in AGG:
-    if fn is agg_train:
-        continue
+# ---- the training step as VICTIM of the (guarded) field kernels; only the tensors that are bit-stable from run to run count ------
+def grads_now():
+    train_forward().backward()
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+g0, g1 = grads_now(), grads_now()
+stable = [k for k in g0 if torch.equal(g0[k], g1[k])]
+print(f"training step alone, twice: {len(stable)} of {len(g0)} gradient tensors bit-identical (the others are sums with float atomics)")
+for name, prep, fn in AGG[3:]:
     res = []
     for rep in range(REPS):
-        with torch.cuda.stream(A):
-            fn()
-            fn()
-        with torch.cuda.stream(B):
-            g = _lib.render_rays_grad(st, params, poses, 5, False, ot, dt, zt, noise, d_rgb, ws=gws)
-        torch.cuda.synchronize()
-        # (the lighting / colour-head gradients are sums with float atomics: compare with a tolerance, the trunk bit for bit)
-        res.append(sum(int(not torch.equal(a, b)) for a, b in zip(g, g_ref)))
-    print(f"aggressor {name:45s} -> victim training step: tensors (of 33) not bit-identical {res}", flush=True)
+        got = {}
+
+        def victim():
+            train_forward().backward()
+        span(lambda: [fn() for _ in range(3)], victim)
+        got = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        res.append(sum(int(not torch.equal(got[k], g0[k])) for k in stable))
+    print(f"aggressor {name}\n    -> victim training step: bit-stable tensors that changed: {res}", flush=True)
