@@ -263,6 +263,19 @@ __host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) 
 // (v255 AND a255: 256 architectural + 256 accumulation registers whatever the kernel itself needs - a255 alone sits behind the kernel's own
 //  VGPR count, rounded to 4)
 #define DSN_OWN_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
+// The training backward's matrix kernels (round 6, scripts/dbg/race_train.py + race_bisect.sh, profiles/r06_coresidency.txt): beside the
+// backward of an 8192 x 64 step, 14 frames' shading phases came out with 900 - 2700 differing normals, their geometry phases with 6 - 190
+// differing canonical points.  Bisected with builds that leave ONE kernel unguarded: k_tangent16 and k_adjoint16 are aggressors - the
+// two kernels built on the same dense16 weight-ring pipeline as k_field16 - and carry the guard (bits 1, 2; free inside a step, where
+// nothing overlaps).  k_t_wgrad16d (256 + 256 registers: owns its SIMD as it is), k_t_wgrad16p, k_t_lin, k_t_wgrad: 0 differing samples
+// unguarded, 3 repetitions each - they stay as they are (k_t_wgrad16p would drop from two workgroups per CU to one).
+// Experiment builds (-DDSN_EXPERIMENTS -DDSN_TRAIN_UNGUARDED=bits) leave the kernels of the given bits without the guard and guard all others.
+#define DSN_TRAIN_AGGRESSORS 3
+#if defined(DSN_EXPERIMENTS) && defined(DSN_TRAIN_UNGUARDED)
+#define DSN_OWN_SIMD_T(bit) do { if (!((DSN_TRAIN_UNGUARDED) & (bit))) DSN_OWN_SIMD(); } while (0)
+#else
+#define DSN_OWN_SIMD_T(bit) do { if ((DSN_TRAIN_AGGRESSORS) & (bit)) DSN_OWN_SIMD(); } while (0)
+#endif
 #define DSN_SCREEN_MARGIN_DEFAULT 0.01f          // conservative margin of the density screen until it has been calibrated
 #define DSN_LO_SCALE 4096.0f                      // lo = (x - hi) * 2^12, products accumulated apart, folded at the end
 #define DSN_LO_INV (1.0f / 4096.0f)

@@ -489,12 +489,15 @@ void dsn_launch_field_fix(const float* packed, const DsnFrameState* fs, const fl
 // ---------------------------------------------------------------------------------------------
 // k_light : model/spacenet.py:254-265 (rotation / light-centre edits) + :174-188 LightingMLP
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FIELD_THREADS, 2)
+__global__ void __launch_bounds__(FIELD_THREADS, 1)
 k_light(const float* __restrict__ packed, const DsnFrameState* __restrict__ fs, const float* __restrict__ n_w,
         const float* __restrict__ x_w_pts, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
         const float* __restrict__ z_vals, const float* essence, int64_t N, int S,
         const int32_t* __restrict__ active_list, const int32_t* __restrict__ active_count,
         float* colour) {      // (essence and colour may be the same array: see k_light16)
+    // (round 6: the exact-fp32 twin of k_light16 was the one matrix kernel nobody had measured beside other streams'
+    //  kernels - tests/test_guard_coverage.py; it is the calibration / fallback path, so it simply takes the guard)
+    DSN_OWN_SIMD();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;

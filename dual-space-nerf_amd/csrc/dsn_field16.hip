@@ -120,9 +120,23 @@ struct W16 {                 // weight stream state of one wave
 // Issued through inline asm: the compiler-visible builtin makes hipcc put s_waitcnt vmcnt(0) in front of the next ds_read
 // (it cannot prove the ring slots differ), which serialises the prefetch.  M0 is declared clobbered (nothing else in these
 // kernels lives in it).  Completion is waited for by w16_boundary's own vmcnt(0) + barrier.
+#ifndef F16_POS_OFFS
+#define F16_POS_OFFS 0        // 1 (experiment, same values): the LDS-DMA pieces with non-negative immediate offsets only (two M0 / address bases)
+#endif
 __device__ __forceinline__ void w16_stage(const W16& w, int c) {
     const char* src = w.g + (size_t)c * 32768;
     const unsigned dst = w.ring_off + (c & 1) * 32768 + w.wave * 8192 + 4096;
+#if F16_POS_OFFS
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                 : : "v"(src - 4096), "s"(dst - 4096) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                 : : "v"(src), "s"(dst) : "memory", "m0");
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, off offset:-4096\n\tglobal_load_lds_dwordx4 %0, off offset:-3072\n\t"
                  "global_load_lds_dwordx4 %0, off offset:-2048\n\tglobal_load_lds_dwordx4 %0, off offset:-1024\n\t"
@@ -137,6 +151,15 @@ template <int I>
 __device__ __forceinline__ void w16_stage_part(const W16& w, int c) {
     const char* src = w.g + (size_t)c * 32768;
     const unsigned dst = w.ring_off + (c & 1) * 32768 + w.wave * 8192 + 4096;
+#if F16_POS_OFFS
+    {
+        const int back = I < 2 ? 4096 : 0;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:%2\n\tglobal_load_lds_dwordx4 %0, off offset:%3"
+                     : : "v"(src - back), "s"(dst - back), "n"(2048 * (I & 1)), "n"(2048 * (I & 1) + 1024) : "memory", "m0");
+        return;
+    }
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, off offset:%2\n\tglobal_load_lds_dwordx4 %0, off offset:%3"
                  : : "v"(src), "s"(dst), "n"(-4096 + 2048 * I), "n"(-3072 + 2048 * I) : "memory", "m0");
@@ -1117,6 +1140,7 @@ k_tangent16(const float* __restrict__ packed, const float* __restrict__ x_c, con
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     __shared__ __attribute__((aligned(16))) half8 s_pe[8][F16_THREADS];
+    DSN_OWN_SIMD_T(1);
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1266,6 +1290,7 @@ __global__ void __launch_bounds__(F16_THREADS, 1)
 k_adjoint16(const float* __restrict__ packed, int64_t N, const uint4* __restrict__ masks, const float* __restrict__ a_in,
             float* __restrict__ tr_a, uint32_t* __restrict__ gmax, int32_t* __restrict__ range_count,
             const int32_t* __restrict__ row_list, const int32_t* __restrict__ row_count) {
+    DSN_OWN_SIMD_T(2);
     __shared__ __attribute__((aligned(16))) char ring[F16_RING_SLOTS * 4096];
     __shared__ uint32_t s_mask[7][4][F16_THREADS];
     const int tid = threadIdx.x;

@@ -809,6 +809,7 @@ template <int OT, int IT, int WO, int WI>
 __global__ void __launch_bounds__(256) k_t_wgrad(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                                                   int64_t N, int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
                                                   float* __restrict__ dbias, Rows rw) {
+    DSN_OWN_SIMD_T(32);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wo = wave / WI, wi = wave % WI;
@@ -972,6 +973,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16c(const float* __restrict__ dY
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
                                                      float* __restrict__ dbias, Rows rw) {
+    DSN_OWN_SIMD_T(64);
     constexpr int OT = 4, IT = 4, WI = 2;
     __shared__ __attribute__((aligned(16))) float ring[W16S_STAGES][2][16][256];
     __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][256];
@@ -1163,6 +1165,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad16d(const float* __restrict__ dY
                                                      const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                      int rows_per_wg, float* __restrict__ dW, int ldw,
                                                      float* __restrict__ dbias, Rows rw, float* __restrict__ part, WgradOps ops) {
+    DSN_OWN_SIMD_T(4);
     constexpr int OT = 4, IT = 4, WI = 2;
     __shared__ __attribute__((aligned(16))) float ring[W16D_STAGES][2][16][256];
     __shared__ __attribute__((aligned(16))) t_half8 opbuf[2][2][2][2][256];      // [buffer][operand][hi | lo][8-sample group][feature]
@@ -1488,6 +1491,7 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
                                                         float* __restrict__ dbias, Rows rw, float* __restrict__ part, WgradOps ops) {
+    DSN_OWN_SIMD_T(8);
     __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
     __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
     __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
@@ -1767,6 +1771,7 @@ template <int K, int M, bool TRANS, int EPI>
 __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
                                                   int64_t N, const float* __restrict__ bias_or_wv, const float* __restrict__ msrc,
                                                   const float* __restrict__ sc, Rows rw) {
+    DSN_OWN_SIMD_T(16);
     constexpr int NT = M / 32, NQ = NT / 4;
     // B in LDS as [k][quad of column tiles][column in tile][tile in quad]: the 4 column tiles a lane feeds with one k come
     // back with ONE ds_read_b128 (lanes 16 bytes apart: conflict-free)

@@ -146,6 +146,11 @@ AGG = (("none", nothing, nothing),
        ("field16 forward x2 (guarded: control)", nothing, agg_fwd), ("field16 reverse x3 (guarded: control)", nothing, agg_rev))
 
 
+if os.environ.get("RACE_AGG"):          # e.g. RACE_AGG=none,BACKWARD : only the aggressors whose name contains one of these
+    AGG = tuple(a for a in AGG if any(t in a[0] for t in os.environ["RACE_AGG"].split(",")))
+QUICK = os.environ.get("RACE_QUICK") == "1"      # victims (a) and (b) only
+
+
 def diffs(a, b, mask=None):
     a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
     ne = a != b
@@ -203,6 +208,8 @@ for name, prep, fn in AGG:
     print(f"aggressor {name}\n    -> victim shade x{NF} (n_w, colour) diffs: {res_s}   victim geometry x{NF} (transparent, x_c): {res_g}\n"
           f"       (aggressor ms, victims ms, both ms) per overlapped region: {[tuple(round(x, 2) for x in s_) for s_ in spans]}", flush=True)
 
+if QUICK:
+    sys.exit(0)
 # ---- victim (c): a caller's torch kernels -----------------------------------------------------------------------------------
 M = 1 << 24
 x1, x2, x3 = (torch.rand(M, device=dev) for _ in range(3))
@@ -243,7 +250,7 @@ def grads_now():
 g0, g1 = grads_now(), grads_now()
 stable = [k for k in g0 if torch.equal(g0[k], g1[k])]
 print(f"training step alone, twice: {len(stable)} of {len(g0)} gradient tensors bit-identical (the others are sums with float atomics)")
-for name, prep, fn in AGG[3:]:
+for name, prep, fn in [a for a in AGG if "control" in a[0]]:
     res = []
     for rep in range(REPS):
         got = {}

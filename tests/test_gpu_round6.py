@@ -105,3 +105,116 @@ def test_lazily_set_frame_rendered_in_small_chunks_completes_its_lists_once():
     r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=False)
     wf = _lib.warp(r.scene, pts[:64], d[:64], S, want_dir=False)
     assert torch.equal(wl["x_c"], wf["x_c"]) and torch.equal(wl["transparent"], wf["transparent"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the co-residency hazard and the training kernels
+# ------------------------------------------------------------------------------------------------------------------------
+def test_training_backward_beside_frames_leaves_them_bit_identical():
+    """The backward of an 8192 x 64 training step on one stream, the shading and the geometry phases of 12 eval frames (256 x 256 x 64,
+    own scene + workspace each) back to back on another: every frame's normals, colours, transparency and canonical points equal the
+    frame rendered alone, bit for bit.  Round 6 found k_tangent16 and k_adjoint16 to be aggressors like k_field16 (900 - 2700 differing
+    normals per repetition in this very set-up, scripts/dbg/race_train.py); they carry DSN_OWN_SIMD since.  The frames are large
+    enough for the kernels to overlap (round 5's lesson: its 96 x 96 test never did) - the test checks that they did."""
+    import dsnerf_amd
+    from dsnerf_amd import _lib, synth
+    from cases import make_cfg
+    HW, S, NF = 256, 64, 12
+    N = HW * HW * S
+    canon, faces, batch = full_frame(hw=HW)
+    sd = state("x_w4")
+    r = renderer_with(sd, canon, faces, density_screen=False)
+    r.eval()
+    dev = r.device
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
+    pk = r.net.packed(dev)
+    tv = r._t_vals(S)
+    VF = [(_lib.Scene(torch.from_numpy(canon), torch.from_numpy(faces), dev), _lib.RenderWorkspace(dev)) for _ in range(NF)]
+    A, B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    al = lambda n: (n + 255) // 256 * 256
+
+    def arrays(ws):      # per-sample arrays of a render workspace (dsn_carve): transparent, x_c, sigma, n_w, colour
+        b = ws.buf
+        p = 8192 + al(4 * N)
+        out = {"transparent": b[p:p + N].clone()}
+        p += al(N) + al(4 * N)
+        out["x_c"] = b[p:p + 12 * N].view(torch.float32).reshape(N, 3).clone()
+        p += al(12 * N)
+        out["sigma"] = b[p:p + 4 * N].view(torch.float32).clone()
+        p += al(4 * N)
+        out["n_w"] = b[p:p + 12 * N].view(torch.float32).reshape(N, 3).clone()
+        p += 12 * N
+        out["colour"] = b[p:p + 12 * N].view(torch.float32).reshape(N, 3).clone()
+        return out
+
+    PH = {"geom": _lib.PHASE_GEOMETRY, "field": _lib.PHASE_FIELD, "shade": _lib.PHASE_SHADE}
+
+    def run(scene, ws, phases, out=None, nf=None):
+        nn, ff = nf if nf is not None else (n0.clone(), f0.clone())
+        for ph in phases:
+            if ph == "set":
+                scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True)
+            else:
+                out = _lib.render_rays(scene, pk, ws, o, d, nn, ff, S, tv, phases=PH[ph], out=out)
+        return out, (nn, ff)
+
+    run(*VF[0], ["set", "geom", "field", "shade"])
+    torch.cuda.synchronize()
+    ref = arrays(VF[0][1])
+    pos, live = ref["sigma"] > 0, ref["transparent"] == 0
+    assert int(pos.sum()) > 100000
+    # the aggressor: a training step's backward through the Renderer (forward alone, backward beside the victims)
+    Rt = 8192
+    sel = np.linspace(0, HW * HW - 1, Rt).astype(np.int64)
+    cfg = make_cfg(S)
+    net = dsnerf_amd.DualSpaceNeRF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(dev)
+    rt = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+    rt.train()
+    tb = {"ray_o": o[sel][None].contiguous(), "ray_d": d[sel][None].contiguous(), "xyz": xyz[None], "poses": poses[None],
+          "Th": torch.zeros(1, 1, 3, device=dev), "frame": torch.tensor([5])}
+    target = torch.from_numpy(synth.hash_uniform(Rt * 3, 77).reshape(Rt, 3).astype(np.float32)).to(dev)
+
+    def forward():
+        torch.manual_seed(3)
+        bb = dict(tb)
+        bb["near"], bb["far"] = n0[sel][None].clone(), f0[sel][None].clone()
+        net.zero_grad()
+        return torch.nn.functional.mse_loss(rt.render(bb)["coarse"]["color"], target)
+
+    def both(victims):
+        with torch.cuda.stream(A):      # (autograd runs a node's backward on the stream its forward ran on)
+            loss = forward()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        with torch.cuda.stream(A):
+            e[0].record()
+            loss.backward()
+            e[1].record()
+        with torch.cuda.stream(B):
+            e[2].record()
+            victims()
+            e[3].record()
+        torch.cuda.synchronize()
+        return e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3]), e[0].elapsed_time(e[3])
+
+    overlapped = 0
+    for rep in range(2):
+        held = [run(sc, ws, ["set", "geom", "field"]) for sc, ws in VF]
+        ta, tb_, tall = both(lambda: [run(sc, ws, ["shade"], ob, nfb) for (sc, ws), (ob, nfb) in zip(VF, held)])
+        overlapped += int(tall < 0.85 * (ta + tb_))
+        for sc, ws in VF:
+            a = arrays(ws)
+            assert torch.equal(torch.nan_to_num(a["n_w"][pos], nan=-7.0), torch.nan_to_num(ref["n_w"][pos], nan=-7.0))
+            assert torch.equal(torch.nan_to_num(a["colour"][pos], nan=-7.0), torch.nan_to_num(ref["colour"][pos], nan=-7.0))
+        for sc, ws in VF:
+            sc.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True)
+        ta, tb_, tall = both(lambda: [run(sc, ws, ["geom"]) for sc, ws in VF])
+        overlapped += int(tall < 0.85 * (ta + tb_))
+        for sc, ws in VF:
+            a = arrays(ws)
+            assert torch.equal(a["transparent"], ref["transparent"])
+            assert torch.equal(a["x_c"][live], ref["x_c"][live])
+    assert overlapped >= 2, "the aggressor and the victims did not run at the same time: the test proves nothing"
