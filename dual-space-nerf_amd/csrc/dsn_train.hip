@@ -319,8 +319,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_colsum(const float* __restrict_
 template <int OUT>
 __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict__ X, int C, const float* __restrict__ dY, int64_t N,
                                                           int rows_per_block, float* __restrict__ dW, float* __restrict__ db, Rows rw,
-                                                          const float* __restrict__ W, float* __restrict__ dX) {
+                                                          const float* __restrict__ W, float* __restrict__ dX, unsigned* __restrict__ gmax) {
+    // gmax (optional, round 6): batch-wide max |dX| as float bits - the operand scale of the split-fp16 product that reads dX next
     __shared__ float s[OUT][T_THREADS];
+    float dmax = 0.0f;
     // (C is 128 or 256: wave-uniform row numbers, fetched a step ahead with scalar loads - see k_t_colsum)
     const int c = threadIdx.x % C, r0 = __builtin_amdgcn_readfirstlane(threadIdx.x / C), rs = T_THREADS / C;
     const int64_t NL = rows_n(rw, N);
@@ -334,7 +336,10 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
         float v = y[0] * wv[0];
 #pragma unroll
         for (int o = 1; o < OUT; ++o) v = v + y[o] * wv[o];
-        dX[row * C + c] = x > 0.0f ? v : 0.0f;
+        v = x > 0.0f ? v : 0.0f;
+        dX[row * C + c] = v;
+        const float av = fabsf(v);
+        if (av < 3.0e38f) dmax = fmaxf(dmax, av);      // non-finite values do not set the scale
     };
     int64_t n = base + r0;
     int64_t id[4];
@@ -386,6 +391,12 @@ __global__ void __launch_bounds__(T_THREADS) k_t_wcolsum(const float* __restrict
     if (db && c == 0) {                  // one thread per row group saw every row of its group
 #pragma unroll
         for (int o = 0; o < OUT; ++o) atomicAdd(db + o, bs[o]);
+    }
+    if (gmax) {                          // (one look-before-atomicMax per wave: see k_t_pe_tangent)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if ((threadIdx.x & 63) == 0 && dmax > 0.0f && __float_as_uint(dmax) > __atomic_load_n(gmax, __ATOMIC_RELAXED))
+            atomicMax(gmax, __float_as_uint(dmax));
     }
 }
 
@@ -1693,6 +1704,230 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
     if (dbias) atomicAdd(dbias + tid, bsum);
 }
 
+// The 128-row siblings for the lighting MLP and the colour head (round 6): dW[128, XW] += dY[N,128]^T X[N,XW] with
+// XW = 256 (rgb_net.1: dY = d_rr, X = h_6) or 128 (lights_encoding.2: dY = d_hl2, X = hl1), + the bias gradient (column sums of dY).
+// These ran on the exact-fp32 MFMA kernel k_t_wgrad (0.32 + 0.17 ms per 8192 x 64 step at 57 TFLOP/s): the contraction over the
+// batch is the same as in the trunk, and so is the remedy - the split-fp16 machinery of k_t_wgrad16p with other tile shapes: wave w
+// owns output rows 32 w .. 32 w + 31 and all XW columns (1 x XW / 32 tiles); a step stages 16 rows of both operands through LDS
+// (2 + XW / 128 DMA instructions per wave), thread f splits feature f & 127 of dY for the 8-row group f >> 7 and feature(s) of X.
+// Two-stage only: every workgroup leaves its [128][XW] tile + 128 column sums in `part`, k_t_wgrad_reduce_q adds them in a fixed order.
+#define W16Q_STAGES 3
+template <int XW>
+__global__ void __launch_bounds__(256, 1) k_t_wgrad16q(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
+                                                        const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
+                                                        int rows_per_wg, Rows rw, float* __restrict__ part) {
+    constexpr int YW = 128, XB = XW / 32, XI = XW / 128;      // XI: DMA instructions of X per wave and step (1 KB = 256 / XW rows each)
+    constexpr int PIECES = 2 + XI;                             // DMA instructions per wave and step
+    constexpr int PART = YW * XW + 256;
+    __shared__ __attribute__((aligned(16))) float ringY[W16Q_STAGES][16][YW];
+    __shared__ __attribute__((aligned(16))) float ringX[W16Q_STAGES][16][XW];
+    __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][YW];
+    __shared__ __attribute__((aligned(16))) t_half8 opX[2][2][XW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t NL = rows_n(rw, N);
+    if (rw.cnt) rows_per_wg = (int)rows_share(NL, 16, 64);
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t n1 = n0 + rows_per_wg;
+    if (n1 > NL) n1 = NL;
+    if (n0 >= n1) return;                                // workgroup-uniform
+    const int full = (int)((n1 - n0) >> 4);
+    const bool tail = n0 + 16 * (int64_t)full < n1;
+    float bsum = 0.0f;
+    const float sy = sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f, sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f;
+    const float iy = 1.0f / sy, ix = 1.0f / sx;
+    t_f32x16 acc[XB];
+#pragma unroll
+    for (int b = 0; b < XB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+    const unsigned offY = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringY[0][0][0];
+    const unsigned offX = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ringX[0][0][0];
+    t_i32x4 ids = {0, 0, 0, 0};        // listed rows: this wave's four row numbers of the NEXT step (one scalar load, see k_t_wgrad16c)
+    auto fetch_ids = [&](int t) {
+        if (!rw.list) return;
+        ids = *reinterpret_cast<t_cptr4>((uintptr_t)(rw.list + (n0 + 16 * (int64_t)t + 4 * wave)));
+    };
+    // DMA of step t: the wave's rows 4 wave .. + 3 of both operands; a 1 KB instruction covers 2 rows of a 128-wide operand (lane ->
+    // row lane / 32, 16-byte piece lane % 32) and 1 row of a 256-wide one
+    auto stage = [&](int t) {
+        const int slot = t % W16Q_STAGES;
+        const int64_t row = n0 + 16 * (int64_t)t + 4 * wave;
+        const unsigned da = offY + (unsigned)((slot * 16 + 4 * wave) * (YW * 4));
+        const unsigned db = offX + (unsigned)((slot * 16 + 4 * wave) * (XW * 4));
+        const int hr = lane >> 5, pc = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t r = rw.list ? (int64_t)(hr ? ids[2 * j + 1] : ids[2 * j]) : row + 2 * j + hr;
+            const char* ga = reinterpret_cast<const char*>(dY + r * YW) + pc * 16;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ga), "s"(da + 1024u * j) : "memory", "m0");
+        }
+        if (XW == 128) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t r = rw.list ? (int64_t)(hr ? ids[2 * j + 1] : ids[2 * j]) : row + 2 * j + hr;
+                const char* gb = reinterpret_cast<const char*>(X + r * XW) + pc * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db + 1024u * j) : "memory", "m0");
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = rw.list ? (int64_t)ids[j] : row + j;
+                const char* gb = reinterpret_cast<const char*>(X + r * XW) + lane * 16;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gb), "s"(db + 1024u * j) : "memory", "m0");
+            }
+        }
+    };
+    auto split8 = [&](const float* v, float inv, t_half8& hi, t_half8& lo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j] * inv;
+            const _Float16 h = (_Float16)x;
+            hi[j] = h;
+            lo[j] = (_Float16)(x - (float)h);
+        }
+    };
+    constexpr int XG = XW == 128 ? 1 : 2;      // 8-row groups of X a thread splits (XW = 256: thread f takes feature f, both groups)
+    // thread f splits feature f & 127 of dY for the 8-row group f >> 7; of X: feature f & 127, group f >> 7 (XW = 128) or feature f, both groups
+    auto publish = [&](const float (&vy)[8], const float (&vx)[8 * XG]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += vy[j];
+        {
+            t_half8 hi, lo;
+            split8(vy, iy, hi, lo);
+            opY[0][tid >> 7][tid & 127] = hi;
+            opY[1][tid >> 7][tid & 127] = lo;
+        }
+#pragma unroll
+        for (int g = 0; g < XG; ++g) {
+            t_half8 hi, lo;
+            split8(vx + 8 * g, ix, hi, lo);
+            if (XW == 128) { opX[0][tid >> 7][tid & 127] = hi; opX[1][tid >> 7][tid & 127] = lo; }
+            else { opX[0][g][tid] = hi; opX[1][g][tid] = lo; }
+        }
+    };
+    auto multiply = [&]() {
+        const t_half8 ah = opY[0][half][32 * wave + col], al = opY[1][half][32 * wave + col];
+#pragma unroll
+        for (int b = 0; b < XB; ++b) {
+            const t_half8 bh = opX[0][half][32 * b + col], bl = opX[1][half][32 * b + col];
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+        }
+    };
+    const int pre = full < W16Q_STAGES - 1 ? full : W16Q_STAGES - 1;
+    for (int t = 0; t < pre; ++t) { fetch_ids(t); stage(t); }
+    if (pre < full) fetch_ids(pre);
+    for (int t = 0; t < full; ++t) {
+        const int issued = (t + W16Q_STAGES - 1 < full) ? t + W16Q_STAGES - 1 : full;
+        if (issued - (t + 1) >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES) : "memory");       // one later step may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + W16Q_STAGES - 1 < full) {
+            stage(t + W16Q_STAGES - 1);
+            if (t + W16Q_STAGES < full) fetch_ids(t + W16Q_STAGES);
+        }
+        const int slot = t % W16Q_STAGES;
+        float vy[8], vx[8 * XG];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vy[j] = ringY[slot][8 * (tid >> 7) + j][tid & 127];
+        if (XW == 128) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vx[j] = ringX[slot][8 * (tid >> 7) + j][tid & 127];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vx[j] = ringX[slot][j][tid & (XW - 1)];
+        }
+        publish(vy, vx);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        multiply();
+    }
+    if (tail) {
+        float vy[8], vx[8 * XG];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t lrow = n0 + 16 * (int64_t)full + 8 * (tid >> 7) + j;
+            vy[j] = lrow < n1 ? dY[rows_at(rw, lrow) * YW + (tid & 127)] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8 * XG; ++j) {
+            const int64_t lrow = n0 + 16 * (int64_t)full + (XW == 128 ? 8 * (tid >> 7) + j : j);
+            vx[j] = lrow < n1 ? X[rows_at(rw, lrow) * XW + (XW == 128 ? (tid & 127) : (tid & (XW - 1)))] : 0.0f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        publish(vy, vx);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        multiply();
+    }
+    // the workgroup's tile in the accumulators' own order: piece (wave, b, r / 4) = 64 lanes x 4 registers; then 256 column partial sums
+    float4* const mine = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * PART);
+#pragma unroll
+    for (int b = 0; b < XB; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            mine[((wave * XB + b) * 4 + r4) * 64 + lane] = make_float4(acc[b][4 * r4], acc[b][4 * r4 + 1], acc[b][4 * r4 + 2], acc[b][4 * r4 + 3]);
+    part[(size_t)blockIdx.x * PART + YW * XW + tid] = bsum;       // (feature tid & 127: the two 8-row groups' sums apart)
+}
+// second stage: dW[i][j] += back * sum_g part[g][i][j] in ascending g (bit-reproducible), dbias[i] += sum_g of both column partial sums
+template <int XW>
+__global__ void __launch_bounds__(256) k_t_wgrad_reduce_q(const float* __restrict__ part, int64_t N, int groups, int rows_per_wg, Rows rw,
+                                                           const float* __restrict__ sy_ptr, const float* __restrict__ sx_ptr,
+                                                           float* __restrict__ dW, int ldw, float* __restrict__ dbias) {
+    constexpr int YW = 128, XB = XW / 32, PART = YW * XW + 256;
+    __shared__ float4 s_sum[4][64];
+    __shared__ float s_b[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t NL = rows_n(rw, N);
+    const int64_t rows = rw.cnt ? rows_share_of(NL, groups, 16, 64) : (int64_t)rows_per_wg;      // stage one's share rule
+    const int active = (int)((NL + rows - 1) / rows);
+    const float* src = part + ((size_t)blockIdx.x * 64 + lane) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = q; g < active; g += 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * PART);
+        acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+    }
+    s_sum[q][lane] = acc;
+    const bool bias_block = dbias && blockIdx.x < 2;             // workgroup-uniform: block b adds up bias columns 64 b .. 64 b + 63
+    if (bias_block) {
+        float bs = 0.0f;
+        const float* bsrc = part + YW * XW + blockIdx.x * 64 + lane;
+        for (int gg = q; gg < active; gg += 4) bs += bsrc[(size_t)gg * PART] + bsrc[(size_t)gg * PART + 128];
+        s_b[q][lane] = bs;
+    }
+    __syncthreads();
+    if (q != 0) return;
+    const float back = (sy_ptr ? t_pow2_at_least(*sy_ptr) : 1.0f) * (sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f);
+    float4 t = s_sum[0][lane];
+    const float4 t1 = s_sum[1][lane], t2 = s_sum[2][lane], t3 = s_sum[3][lane];
+    t.x = ((t.x + t1.x) + t2.x) + t3.x; t.y = ((t.y + t1.y) + t2.y) + t3.y;
+    t.z = ((t.z + t1.z) + t2.z) + t3.z; t.w = ((t.w + t1.w) + t2.w) + t3.w;
+    // piece blockIdx.x = (wave * XB + b) * 4 + r4 of stage one: the lane's four values are rows i .. i + 3 of column j
+    const int r4 = blockIdx.x & 3, b = (blockIdx.x >> 2) % XB, wv = (blockIdx.x >> 2) / XB, half = lane >> 5, col = lane & 31;
+    const int i = 32 * wv + 8 * r4 + 4 * half, j = 32 * b + col;
+    float* out = dW + (int64_t)i * ldw + j;
+    out[0] += t.x * back;
+    out[(int64_t)ldw] += t.y * back;
+    out[2 * (int64_t)ldw] += t.z * back;
+    out[3 * (int64_t)ldw] += t.w * back;
+    if (bias_block) dbias[blockIdx.x * 64 + lane] += ((s_b[0][lane] + s_b[1][lane]) + s_b[2][lane]) + s_b[3][lane];
+}
+// dW [128, XW] (ldw) += dY[N,128]^T X[N,XW]; dbias [128] += column sums of dY; sy / sx: device scalars with the operands' batch-wide
+// magnitudes (NULL = O(1) operand)
+template <int XW>
+void wgrad_mfma16q(int64_t N, const float* X, const float* sx, const float* dY, const float* sy, float* dW, int ldw, hipStream_t st,
+                   float* dbias, Rows rw, float* part) {
+    int groups = 256;                 // one workgroup per CU (48 - 96 KB of LDS)
+    int rows = (int)((N + groups - 1) / groups);
+    if (rows < 64) rows = 64;
+    rows = (rows + 15) & ~15;
+    groups = (int)((N + rows - 1) / rows);
+    hipLaunchKernelGGL((k_t_wgrad16q<XW>), dim3((unsigned)groups), dim3(256), 0, st, dY, sy, X, sx, N, rows, rw, part);
+    hipLaunchKernelGGL((k_t_wgrad_reduce_q<XW>), dim3(128 * XW / 256), dim3(256), 0, st, (const float*)part, N, groups, rows, rw, sy, sx, dW, ldw,
+                       dbias);
+}
+
 // How the workgroups' partial products meet.  Default: two stages - every workgroup stores its tile into `part` (the training
 // workspace's W16_PART_GROUPS x W16_PART(256) floats), k_t_wgrad_reduce adds them in a fixed order: bit-reproducible gradients, and
 // 0.13 + 0.02 ms per 256 x 256 product instead of 0.22 (the 65 536 float atomics per workgroup were 40 % of the kernel).
@@ -1946,9 +2181,10 @@ void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st, Rows r
 
 template <int OUT>
 void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st, Rows rw = Rows{nullptr, nullptr},
-             const float* W = nullptr, float* dX = nullptr) {
+             const float* W = nullptr, float* dX = nullptr, float* gmax = nullptr) {
     const int rows = 256;
-    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw, W, dX);
+    hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw, W, dX,
+                       (unsigned*)gmax);
 }
 
 }  // namespace
@@ -2066,6 +2302,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     const Rows R2 = {w.list2, w.rowcnt + 1};
     // (the encoding of the backward's rows is written by k_t_pe_tangent below, beside its tangent; DSN_TRAIN_UNFUSED_HEADS=1: by k_t_pe here)
     static const bool two_pass_heads = [] { const char* e = getenv("DSN_TRAIN_UNFUSED_HEADS"); return e && e[0] == '1'; }();
+    static const bool heads_fp32 = [] { const char* e = getenv("DSN_TRAIN_HEADS"); return e && e[0] == 'f'; }();
+    const bool heads16 = !heads_fp32 && !two_pass_heads;      // (the scales ride in the fused sweeps)
+    float* const g_dhl2 = w.small + 304;      // batch-wide max |d_hl2|, |d_rr| (float bits; zeroed with w.small)
+    float* const g_drr = w.small + 305;
     if (two_pass_heads) hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe, R2);
     hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
                        w.d_pre, R2);
@@ -2077,8 +2317,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         hipLaunchKernelGGL(k_t_seed, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.hl2, prm[P_L4_W], w.d_pre, nullptr, 128, N64 * 128,
                            w.d_hl2, R2);
     } else
-        wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2, prm[P_L4_W], w.d_hl2);
-    T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
+        wcolsum<1>(w.hl2, 128, w.d_pre, N64, grd[P_L4_W], grd[P_L4_B], st, R2, prm[P_L4_W], w.d_hl2, g_dhl2);
+    // (round 6: the 128-wide products of the lighting MLP and the colour head on the split-fp16 kernel k_t_wgrad16q - scales: the batch-wide
+    //  magnitudes the sweeps above leave; DSN_TRAIN_HEADS=fp32 keeps the exact-fp32 MFMA kernel, A/B and cross-check)
+    if (heads16) wgrad_mfma16q<128>(N64, w.hl1, nullptr, w.d_hl2, g_dhl2, grd[P_L2_W], 128, st, grd[P_L2_B], R2, w.wg_part);
+    else T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
     lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
     // (the first lighting layer keeps its two passes over d_hl1: a VALU kernel that also accumulates dW0 takes 0.39 ms against
     //  0.107 for the exact-fp32 MFMA product + 0.129 for the data gradient - tried in round 5)
@@ -2122,8 +2365,9 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                            w.d_rr, R2);
     } else
-        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2, prm[P_RGB3_W], w.d_rr);
-    T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
+        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2, prm[P_RGB3_W], w.d_rr, g_drr);
+    if (heads16) wgrad_mfma16q<256>(N64, w.h[6], nullptr, w.d_rr, g_drr, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2, w.wg_part);
+    else T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
     wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st, R2);
     // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in
     lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2);
