@@ -268,9 +268,13 @@ __host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) 
 // differing canonical points.  Bisected with builds that leave ONE kernel unguarded: k_tangent16 and k_adjoint16 are aggressors - the
 // two kernels built on the same dense16 weight-ring pipeline as k_field16 - and carry the guard (bits 1, 2; free inside a step, where
 // nothing overlaps).  k_t_wgrad16d (256 + 256 registers: owns its SIMD as it is), k_t_wgrad16p, k_t_lin, k_t_wgrad: 0 differing samples
-// unguarded, 3 repetitions each - they stay as they are (k_t_wgrad16p would drop from two workgroups per CU to one).
+// unguarded, 3 repetitions each - they stay as they are (k_t_wgrad16p would drop from two workgroups per CU to one).  k_t_wgrad16q
+// (round 6's own 128-row product, bit 128): an aggressor again (130 - 270 differing normals per repetition), with its accumulators in
+// AGPRs (the compiler's choice, 66 + 128 registers) AND with them forced into architectural VGPRs (194 + 0): guarded.  What the
+// aggressors share is still not a property one could test for in source: refuted so far - the negative immediate offsets of the
+// weight ring's LDS-DMA, the v_fma_mix / v_bfe inline asm, AGPR accumulators (profiles/r06_coresidency_bisect.txt).
 // Experiment builds (-DDSN_EXPERIMENTS -DDSN_TRAIN_UNGUARDED=bits) leave the kernels of the given bits without the guard and guard all others.
-#define DSN_TRAIN_AGGRESSORS 3
+#define DSN_TRAIN_AGGRESSORS 131
 #if defined(DSN_EXPERIMENTS) && defined(DSN_TRAIN_UNGUARDED)
 #define DSN_OWN_SIMD_T(bit) do { if (!((DSN_TRAIN_UNGUARDED) & (bit))) DSN_OWN_SIMD(); } while (0)
 #else

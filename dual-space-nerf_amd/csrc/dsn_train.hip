@@ -1716,6 +1716,7 @@ template <int XW>
 __global__ void __launch_bounds__(256, 1) k_t_wgrad16q(const float* __restrict__ dY, const float* __restrict__ sy_ptr,
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, Rows rw, float* __restrict__ part) {
+    DSN_OWN_SIMD_T(128);
     constexpr int YW = 128, XB = XW / 32, XI = XW / 128;      // XI: DMA instructions of X per wave and step (1 KB = 256 / XW rows each)
     constexpr int PIECES = 2 + XI;                             // DMA instructions per wave and step
     constexpr int PART = YW * XW + 256;
@@ -1807,14 +1808,28 @@ __global__ void __launch_bounds__(256, 1) k_t_wgrad16q(const float* __restrict__
             else { opX[0][g][tid] = hi; opX[1][g][tid] = lo; }
         }
     };
+    // W16Q_ACC (experiment builds): where the accumulators live - 0: the compiler's choice (AGPRs here), 1: AGPRs by constraint,
+    // 2: architectural VGPRs by constraint.  (Round 6, co-residency hazard of DESIGN 4.5: is "f16 MFMA into AGPR accumulators" the aggressor?)
+#ifndef W16Q_ACC
+#define W16Q_ACC 0
+#endif
+    auto mfma = [&](const t_half8& a, const t_half8& b, t_f32x16& c) {
+#if defined(DSN_EXPERIMENTS) && W16Q_ACC == 1
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#elif defined(DSN_EXPERIMENTS) && W16Q_ACC == 2
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+    };
     auto multiply = [&]() {
         const t_half8 ah = opY[0][half][32 * wave + col], al = opY[1][half][32 * wave + col];
 #pragma unroll
         for (int b = 0; b < XB; ++b) {
             const t_half8 bh = opX[0][half][32 * b + col], bl = opX[1][half][32 * b + col];
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+            mfma(ah, bh, acc[b]);
+            mfma(ah, bl, acc[b]);
+            mfma(al, bh, acc[b]);
         }
     };
     const int pre = full < W16Q_STAGES - 1 ? full : W16Q_STAGES - 1;
