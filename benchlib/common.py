@@ -45,6 +45,16 @@ def _flush_c_stdio():
         pass
 
 
+def fail_line(args, rank, world, what, code=3):
+    """A run that cannot measure says so in ONE JSON line on stdout (the driver parses the last line of stdout: it finds `error`, no
+    value) and exits non-zero - instead of a traceback, or of N ranks waiting for each other until the driver's own clock runs out."""
+    _flush_c_stdio()
+    print(json.dumps({"metric": "rendered rays/sec", "value": None, "unit": "rays/s", "n_gpus": world, "steps": getattr(args, "steps", None),
+                      "warmup": getattr(args, "warmup", None), "error": what, "failed_rank": rank}), flush=True)
+    _flush_c_stdio()
+    os._exit(code)
+
+
 class Ranks:
     """The process group of a bench run: one rank per GPU over RCCL (backend "nccl" on ROCm), or gloo on the CPU for --dry-launch.
     Everything the three modes need from it: barrier, the max over ranks of the timed region, every rank's own time, and what the
@@ -72,19 +82,60 @@ class Ranks:
             # end to end on a one-GPU box.  A control-flow check: the ranks share the GPU, the times mean nothing.
             self.one_gpu = os.environ.get("DSN_BENCH_ONE_GPU") == "1"
             idx = 0 if self.one_gpu else self.local
-            assert idx < torch.cuda.device_count(), (f"rank {self.rank}: local rank {self.local} has no GPU "
-                                                     f"({torch.cuda.device_count()} visible)")
+            n_dev = torch.cuda.device_count()
+            if idx >= n_dev:
+                fail_line(args, self.rank, self.world, f"rank {self.rank}: LOCAL_RANK {self.local} has no GPU ({n_dev} visible on this node; "
+                                                       f"HIP_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES')!r})")
             self.dev = torch.device("cuda", idx)
             torch.cuda.set_device(self.dev)
+        # Preflight of a multi-rank run nobody has watched yet.  (1) every rank says which device it bound (stderr);
+        # (2) rendezvous, communicator set-up and the FIRST collective run under a watchdog - a rank that never arrives (crashed, wrong
+        # MASTER_PORT, a device another process holds) would leave the others inside RCCL for ever: after DSN_BENCH_INIT_TIMEOUT
+        # seconds (default 180) the waiting rank prints a JSON error line and exits; (3) that first collective counts the ranks - an
+        # all-reduce of ones must return N before anything is timed.  DSN_BENCH_TEST_FAIL (tests): provoke each failure.
+        test_fail = os.environ.get("DSN_BENCH_TEST_FAIL", "")
+        if test_fail == f"nodev_rank{self.rank}":
+            fail_line(args, self.rank, self.world, f"rank {self.rank}: LOCAL_RANK {self.local} has no GPU (provoked: DSN_BENCH_TEST_FAIL)")
+        if self.world > 1 or self.on:
+            name = "cpu (dry launch)" if self.dry else f"cuda:{self.dev.index} {torch.cuda.get_device_name(self.dev)}"
+            print(f"[bench rank {self.rank}/{self.world}] LOCAL_RANK {self.local} -> {name}; "
+                  f"visible devices {0 if self.dry else torch.cuda.device_count()}; MASTER {os.environ.get('MASTER_ADDR', '127.0.0.1')}:"
+                  f"{os.environ.get('MASTER_PORT', '29531')}", file=sys.stderr, flush=True)
+        self.seen = 1
         if self.on:
+            import datetime
+            import threading
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             self.backend = "gloo" if self.dry else os.environ.get("DSN_BENCH_BACKEND", "nccl")
-            if self.backend == "gloo":
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            else:
-                dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world)
-            assert dist.get_world_size() == self.world and (args.gpus is None or dist.get_world_size() == args.gpus)
+            limit = float(os.environ.get("DSN_BENCH_INIT_TIMEOUT", "180"))
+            stage = ["rendezvous (init_process_group)"]
+            watchdog = threading.Timer(limit, lambda: fail_line(
+                args, self.rank, self.world, f"rank {self.rank}: {stage[0]} did not finish within {limit:g} s - a rank is missing or the "
+                                              f"collective library cannot reach it (backend {self.backend}); nothing was timed", 4))
+            watchdog.daemon = True
+            watchdog.start()
+            if test_fail == f"hang_rank{self.rank}":
+                time.sleep(10 * limit + 3600)
+            try:
+                tmo = datetime.timedelta(seconds=max(limit, 30.0))
+                if self.backend == "gloo":
+                    dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=tmo)
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world, timeout=tmo)
+                stage[0] = "the first collective (all-reduce of ones: communicator set-up)"
+                one = torch.ones(1, dtype=torch.int32, device=self.dev)
+                if test_fail == "miscount" and self.rank == self.world - 1:
+                    one.zero_()
+                dist.all_reduce(one)
+                self.seen = int(one.item())
+            except Exception as e:      # (a rendezvous / communicator error is a failed preflight too, not a traceback)
+                watchdog.cancel()
+                fail_line(args, self.rank, self.world, f"rank {self.rank}: {stage[0]} failed: {type(e).__name__}: {str(e)[:300]}", 4)
+            watchdog.cancel()
+            if self.seen != self.world or dist.get_world_size() != self.world or (args.gpus is not None and dist.get_world_size() != args.gpus):
+                fail_line(args, self.rank, self.world, f"rank {self.rank}: the collective library counted {self.seen} rank(s) (all-reduce of ones), "
+                                                       f"world size {dist.get_world_size()}, expected {self.world}; nothing was timed", 5)
 
     def sync(self):
         if not self.dry:

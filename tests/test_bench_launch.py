@@ -88,3 +88,44 @@ def test_more_ranks_than_gpus_is_refused_before_anything_is_launched():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=_env(), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
     assert not _json_lines(p.stdout)
+
+
+# ---- preflight of a multi-rank run: every way the first contact can go wrong ends in ONE JSON error line, not a hang ----
+def _run_failing(env_extra, timeout=240):
+    env = _env()
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    return p, _json_lines(p.stdout)
+
+
+def test_every_rank_reports_its_device_binding():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "1", "--warmup", "0"], env=_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for r in (0, 1):
+        assert f"[bench rank {r}/2] LOCAL_RANK {r} ->" in p.stderr, p.stderr[-2000:]
+
+
+def test_a_rank_that_never_arrives_gives_an_error_line_not_a_hang():
+    """rank 1 sleeps in front of the rendezvous: rank 0's watchdog prints the error line after DSN_BENCH_INIT_TIMEOUT seconds"""
+    p, js = _run_failing({"DSN_BENCH_TEST_FAIL": "hang_rank1", "DSN_BENCH_INIT_TIMEOUT": "8"})
+    assert p.returncode != 0
+    errs = [j for j in js if j.get("error")]
+    assert errs and errs[0]["value"] is None and errs[0]["n_gpus"] == 2 and "did not finish within 8 s" in errs[0]["error"], (p.stdout, p.stderr[-1500:])
+    assert not [j for j in js if j.get("value") is not None]
+
+
+def test_a_rank_without_a_device_says_so_in_a_json_line():
+    p, js = _run_failing({"DSN_BENCH_TEST_FAIL": "nodev_rank1", "DSN_BENCH_INIT_TIMEOUT": "8"})
+    assert p.returncode != 0
+    errs = [j for j in js if j.get("error")]
+    assert errs and any("has no GPU" in j["error"] and j["failed_rank"] == 1 for j in errs), (p.stdout, p.stderr[-1500:])
+
+
+def test_ranks_are_counted_before_anything_is_timed():
+    """the first collective is an all-reduce of ones: a world the library miscounts stops the run"""
+    p, js = _run_failing({"DSN_BENCH_TEST_FAIL": "miscount", "DSN_BENCH_INIT_TIMEOUT": "60"})
+    assert p.returncode != 0
+    errs = [j for j in js if j.get("error")]
+    assert errs and all("counted 1 rank(s)" in j["error"] for j in errs), (p.stdout, p.stderr[-1500:])
