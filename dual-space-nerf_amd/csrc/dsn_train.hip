@@ -2020,7 +2020,10 @@ enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_SEED = 3 };
 template <int K, int M, bool TRANS, int EPI>
 __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
                                                   int64_t N, const float* __restrict__ bias_or_wv, const float* __restrict__ msrc,
-                                                  const float* __restrict__ sc, Rows rw) {
+                                                  const float* __restrict__ sc, Rows rw, const uint4* __restrict__ recs, int rec_layer) {
+    // recs / rec_layer (EPI_SEED, optional; round 6): the relu pattern of trunk layer `rec_layer` from the training forward's 224-byte
+    // records - [sample][half][layer] uint4, bit 15 - r of the 16-bit word of block t = accumulator register r (dsn_field16.hip) -
+    // instead of `msrc > 0`: 16 bytes per row and half in place of 512 (the pattern the tangent / adjoint kernels use anyway)
     DSN_OWN_SIMD_T(16);
     constexpr int NT = M / 32, NQ = NT / 4;
     // B in LDS as [k][quad of column tiles][column in tile][tile in quad]: the 4 column tiles a lane feeds with one k come
@@ -2048,12 +2051,17 @@ __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, c
         // what the epilogue needs from memory is requested NOW and used after the products: its latency hides behind them
         float4 mk[EPI == EPI_MASK || EPI == EPI_SEED ? NT : 1][4];
         float scn = 0.0f;
+        const bool by_rec = EPI == EPI_SEED && recs != nullptr;      // kernel-uniform
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
         if (EPI == EPI_MASK || EPI == EPI_SEED) {
-            const float* mr = msrc + crow * M + 4 * half;
+            if (by_rec) rec = recs[((size_t)crow * 2 + half) * 7 + rec_layer];
+            else {
+                const float* mr = msrc + crow * M + 4 * half;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mk[t][q] = *reinterpret_cast<const float4*>(mr + 32 * t + 8 * q);
+                    for (int q = 0; q < 4; ++q) mk[t][q] = *reinterpret_cast<const float4*>(mr + 32 * t + 8 * q);
+            }
             if (EPI == EPI_SEED) scn = sc[crow];
         }
         t_f32x16 acc[NT];
@@ -2097,8 +2105,14 @@ __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, c
                 for (int q = 0; q < 4; ++q) {
                     const int f0 = 32 * t + 8 * q + 4 * half;
                     float v[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-                    const float m4[4] = {mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].x, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].y,
-                                         mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].z, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].w};
+                    float m4[4] = {mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].x, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].y,
+                                   mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].z, mk[EPI == EPI_MASK || EPI == EPI_SEED ? t : 0][q].w};
+                    if (by_rec) {
+                        const uint32_t wd = (t >> 1) == 0 ? rec.x : ((t >> 1) == 1 ? rec.y : ((t >> 1) == 2 ? rec.z : rec.w));
+                        const uint32_t pat = (wd >> (16 * (t & 1))) & 0xffffu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m4[e] = ((pat >> (15 - (4 * q + e))) & 1u) ? 1.0f : 0.0f;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e] + sV[f0 + e], 0.0f);
@@ -2112,11 +2126,12 @@ __global__ void __launch_bounds__(256, 1) k_t_lin(const float* __restrict__ X, c
 }
 template <int K, int M, bool TRANS, int EPI>
 void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_or_wv, const float* msrc, const float* sc, hipStream_t st,
-         Rows rw = Rows{nullptr, nullptr}) {
+         Rows rw = Rows{nullptr, nullptr}, const void* recs = nullptr, int rec_layer = 0) {
     const int64_t ntile = (N + 31) / 32;
     int groups = (int)((ntile + 3) / 4);
     if (groups > 256) groups = 256;               // one workgroup per CU: B is staged once per workgroup
-    hipLaunchKernelGGL((k_t_lin<K, M, TRANS, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, W, Y, N, bias_or_wv, msrc, sc, rw);
+    hipLaunchKernelGGL((k_t_lin<K, M, TRANS, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, W, Y, N, bias_or_wv, msrc, sc, rw,
+                       (const uint4*)recs, rec_layer);
 }
 
 struct TrainWs {
@@ -2385,7 +2400,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     else T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
     wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st, R2);
     // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in
-    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2);
+    // (round 6: the relu pattern of layer 6 from the forward's records - 32 bytes per row instead of the 1 KB row of h_6;
+    //  DSN_TRAIN_SEED_MASK=h keeps the `h_6 > 0` form, A/B and cross-check)
+    static const bool seed_by_h = [] { const char* e = getenv("DSN_TRAIN_SEED_MASK"); return e && e[0] == 'h'; }();
+    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2, seed_by_h ? nullptr : w.masks, 6);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = pairs ? w.an : w.tn;
