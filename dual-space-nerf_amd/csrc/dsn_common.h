@@ -252,29 +252,32 @@ __host__ __device__ inline float dsn_stop_eps_scaled(int S, float colour_scale) 
     return e < cap ? e : cap;
 }
 // DSN_OWN_SIMD(): the wave's register allocation covers the WHOLE 512-entry register file of its SIMD, so that no wave of another kernel
-// can be resident beside it.  Why (round 5, docs/LAB_NOTEBOOK.md "frames in flight were not bit-identical"): with several frames in
-// flight, waves of the small kernels of one frame (k_normal, k_nns_search, ...: 24-64 registers) that landed on a SIMD beside a wave of
-// the split-fp16 field kernels of another frame (448 registers, so 64 stay free) consumed registers BEFORE their own global loads had
-// landed - 0.2-1 % of a frame's samples came out with a slightly different canonical point or normal, never the same ones twice.  The
-// field kernels themselves are unaffected and stay within their allocation (checked in the ISA); neither a register-heavy spinner, nor
-// LDS-DMA loops, nor MFMA-free builds of the kernel alone reproduce it; a field wave that owns its SIMD does not cause it (0 differing
-// samples in every configuration tested, scripts/dbg/race_*.py).  Two dummy register writes at kernel entry; costs the co-residency of other
-// frames' small kernels on the compute units the persistent field workgroups occupy (they keep the eighth DSN_SHARE_CUS leaves them).
-// (v255 AND a255: 256 architectural + 256 accumulation registers whatever the kernel itself needs - a255 alone sits behind the kernel's own
-//  VGPR count, rounded to 4)
+// can be resident beside it.
+// THE RULE (round 6): a kernel that issues v_mfma_f32_32x32x16_f16 - gfx950's K = 16 form of the f16 MFMA - must own its SIMDs.
+// Why.  Round 5 (docs/LAB_NOTEBOOK.md "frames in flight were not bit-identical"): with several frames in flight, waves of the small
+// kernels of one frame (k_normal, k_nns_search, ...: 24-64 registers) that landed on a SIMD beside a wave of the split-fp16 field kernels
+// of another frame consumed registers BEFORE their own global loads had landed - 0.2-1 % of a frame's samples came out with a slightly
+// different canonical point or normal, never the same ones twice.  The aggressors themselves are unaffected and stay within their
+// allocation (ISA checked).  Round 5 found the condition (co-residency) and this guard; round 6 found the trigger
+// (scripts/dbg/race_train.py + race_bisect.sh, profiles/r06_coresidency_bisect.txt): builds that leave ONE kernel unguarded beside 14
+// frames' shading / geometry phases.  Aggressors: k_field16 (all modes), k_light16, k_tangent16, k_adjoint16, k_t_wgrad16q, k_t_wgrad16p
+// (weak: 1 repetition in 12) - every kernel that issues the K = 16 f16 MFMA.  Clean: k_t_lin, k_t_wgrad (fp32 MFMA 32x32x2), whatever
+// their register and AGPR use.  Not the trigger: negative immediate offsets of the weight ring's LDS-DMA, the v_fma_mix / v_bfe inline
+// asm, accumulators in AGPRs vs VGPRs (each exchanged alone: still an aggressor).  THE trigger: k_t_wgrad16q with every
+// v_mfma_f32_32x32x16_f16 replaced by two v_mfma_f32_32x32x8_f16 (same registers, same LDS-DMA, same occupancy, twice the matrix-pipe
+// time): 0 differing samples in 12 repetitions, against 9 of 12 with the K = 16 instruction.
+// Consequences: every K = 16 kernel carries the guard (below; tests/test_guard_coverage.py enforces it in source); k_t_wgrad16p, which
+// is bound by its operand stream, runs on the K = 8 instruction instead and keeps two workgroups per CU; fp32-MFMA kernels need no guard
+// (k_field / k_light keep theirs: 480 registers / the fallback path).  Costs the co-residency of other frames' small kernels on the
+// compute units the persistent field workgroups occupy (they keep the eighth DSN_SHARE_CUS leaves them): ~0.15 ms per frame.
+// Two dummy register writes at kernel entry (v255 AND a255: 256 architectural + 256 accumulation registers whatever the kernel itself
+// needs - a255 alone sits behind the kernel's own VGPR count, rounded to 4).
 #define DSN_OWN_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
-// The training backward's matrix kernels (round 6, scripts/dbg/race_train.py + race_bisect.sh, profiles/r06_coresidency.txt): beside the
-// backward of an 8192 x 64 step, 14 frames' shading phases came out with 900 - 2700 differing normals, their geometry phases with 6 - 190
-// differing canonical points.  Bisected with builds that leave ONE kernel unguarded: k_tangent16 and k_adjoint16 are aggressors - the
-// two kernels built on the same dense16 weight-ring pipeline as k_field16 - and carry the guard (bits 1, 2; free inside a step, where
-// nothing overlaps).  k_t_wgrad16d (256 + 256 registers: owns its SIMD as it is), k_t_wgrad16p, k_t_lin, k_t_wgrad: 0 differing samples
-// unguarded, 3 repetitions each - they stay as they are (k_t_wgrad16p would drop from two workgroups per CU to one).  k_t_wgrad16q
-// (round 6's own 128-row product, bit 128): an aggressor again (130 - 270 differing normals per repetition), with its accumulators in
-// AGPRs (the compiler's choice, 66 + 128 registers) AND with them forced into architectural VGPRs (194 + 0): guarded.  What the
-// aggressors share is still not a property one could test for in source: refuted so far - the negative immediate offsets of the
-// weight ring's LDS-DMA, the v_fma_mix / v_bfe inline asm, AGPR accumulators (profiles/r06_coresidency_bisect.txt).
-// Experiment builds (-DDSN_EXPERIMENTS -DDSN_TRAIN_UNGUARDED=bits) leave the kernels of the given bits without the guard and guard all others.
-#define DSN_TRAIN_AGGRESSORS 131
+// The training backward's matrix kernels carry the guard through DSN_OWN_SIMD_T(bit): 1 k_tangent16, 2 k_adjoint16, 4 k_t_wgrad16d
+// (256 + 256 registers as it is), 64 k_t_wgrad16c, 128 k_t_wgrad16q - the K = 16 kernels; 16 k_t_lin, 32 k_t_wgrad (fp32 MFMA) do not.
+// Experiment builds (-DDSN_EXPERIMENTS -DDSN_TRAIN_UNGUARDED=bits) leave the kernels of the given bits without the guard and guard all
+// the others - the bisect's tool.
+#define DSN_TRAIN_AGGRESSORS 199
 #if defined(DSN_EXPERIMENTS) && defined(DSN_TRAIN_UNGUARDED)
 #define DSN_OWN_SIMD_T(bit) do { if (!((DSN_TRAIN_UNGUARDED) & (bit))) DSN_OWN_SIMD(); } while (0)
 #else

@@ -1502,7 +1502,7 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
                                                         const float* __restrict__ X, const float* __restrict__ sx_ptr, int64_t N,
                                                         int rows_per_wg, float* __restrict__ dW, int ldw, int in_valid,
                                                         float* __restrict__ dbias, Rows rw, float* __restrict__ part, WgradOps ops) {
-    DSN_OWN_SIMD_T(8);
+    // (no DSN_OWN_SIMD: K = 8 MFMAs only - see multiply())
     __shared__ __attribute__((aligned(16))) float ringY[W16P_STAGES][16][256];
     __shared__ __attribute__((aligned(16))) float ringX[W16P_STAGES][16][64];
     __shared__ __attribute__((aligned(16))) t_half8 opY[2][2][256];
@@ -1595,26 +1595,36 @@ __global__ void __launch_bounds__(256, 2) k_t_wgrad16p(const float* __restrict__
             opX[1][tid >> 6][tid & 63] = lo;
         }
     };
+    // Round 6: the products run on v_mfma_f32_32x32x8_f16 (K = 8, the CDNA3-era instruction), two per 16-row step and operand pair,
+    // not on gfx950's K = 16 form.  Waves that issue v_mfma_f32_32x32x16_f16 make co-resident waves of OTHER kernels consume their
+    // vector-memory loads early (dsn_common.h DSN_OWN_SIMD; found by exchanging exactly this instruction, profiles/r06_coresidency_bisect.txt);
+    // such kernels must own their SIMDs.  This one is bound by its operand stream (0.75 GB in 0.145 ms), its matrix work is a quarter of
+    // its time even at the K = 8 rate - so it keeps two workgroups per CU and needs no guard.  A K = 8 operand is half of the 8-sample
+    // vector the conversion stage publishes: lanes 0-31 take samples 0-3 of the group, lanes 32-63 samples 4-7.
+    typedef _Float16 t_half4 __attribute__((ext_vector_type(4)));
     auto multiply = [&]() {
-        t_half8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            ah[a] = opY[0][half][64 * wave + 32 * a + col];
-            al[a] = opY[1][half][64 * wave + 32 * a + col];
-        }
+        for (int g = 0; g < 2; ++g) {
+            t_half4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            bh[b] = opX[0][half][32 * b + col];
-            bl[b] = opX[1][half][32 * b + col];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = reinterpret_cast<const t_half4*>(&opY[0][g][64 * wave + 32 * a + col])[half];
+                al[a] = reinterpret_cast<const t_half4*>(&opY[1][g][64 * wave + 32 * a + col])[half];
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                bh[b] = reinterpret_cast<const t_half4*>(&opX[0][g][32 * b + col])[half];
+                bl[b] = reinterpret_cast<const t_half4*>(&opX[1][g][32 * b + col])[half];
             }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
     };
 #pragma nounroll
     for (int job = 0; job < ops.jobs; ++job) {
@@ -1818,6 +1828,12 @@ __global__ void __launch_bounds__(256, 1) k_t_wgrad16q(const float* __restrict__
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 #elif defined(DSN_EXPERIMENTS) && W16Q_ACC == 2
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#elif defined(DSN_EXPERIMENTS) && W16Q_ACC == 3
+        // (WRONG products, timing / hazard experiments only: the CDNA3-era K = 8 instruction twice instead of gfx950's K = 16 one)
+        typedef _Float16 t_half4 __attribute__((ext_vector_type(4)));
+        const t_half4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]}, b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+        c = __builtin_amdgcn_mfma_f32_32x32x8f16(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x8f16(a1, b1, c, 0, 0, 0);
 #else
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif

@@ -5,5 +5,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for v in "$@"; do
   echo "== variant $v" | tee -a gpurun_out/race_bisect.txt
-  DSNERF_LIB=$GRAFT_REPO_ROOT/dual-space-nerf_amd/variants/$v.so RACE_AGG=BACKWARD RACE_QUICK=1 timeout 300 python scripts/dbg/race_train.py 3 2>&1 | grep -A2 "^aggressor" | tee -a gpurun_out/race_bisect.txt
+  DSNERF_LIB=$GRAFT_REPO_ROOT/dual-space-nerf_amd/variants/$v.so RACE_AGG=BACKWARD RACE_QUICK=1 timeout 300 python scripts/dbg/race_train.py ${RACE_REPS:-3} 2>&1 | grep -A2 "^aggressor" | tee -a gpurun_out/race_bisect.txt
 done

@@ -1,40 +1,44 @@
-"""Source-level guard: every kernel built on the split-fp16 weight-ring pipeline of dsn_field16.hip (dense16 /
-dense16x / the screen's dense loop) - the family whose waves made co-resident waves of OTHER kernels consume registers before their
-loads had landed - must take its SIMD's whole register file (DSN_OWN_SIMD / DSN_OWN_SIMD_T with an aggressor bit).  Any
-other kernel that issues MFMAs must either carry the guard or be on the list of kernels the round-6 bisect cleared
-(scripts/dbg/race_bisect.sh, profiles/r06_coresidency_bisect.txt: 0 differing samples unguarded).  A new matrix kernel therefore
-fails this test until it is guarded or measured."""
+"""Source-level guard of THE RULE of csrc/dsn_common.h (round 6): a kernel that issues v_mfma_f32_32x32x16_f16 - gfx950's K = 16 form
+of the f16 MFMA - makes co-resident waves of OTHER kernels consume their vector-memory loads before they have landed (DESIGN 4.5;
+found by exchanging exactly this instruction for two K = 8 ones in an otherwise identical kernel, profiles/r06_coresidency_bisect.txt),
+so it must take its SIMD's whole register file (DSN_OWN_SIMD / DSN_OWN_SIMD_T with a bit of DSN_TRAIN_AGGRESSORS).  Kernels whose MFMAs
+are all of another kind (fp32 32x32x2, f16 32x32x8) are exempt by the rule and by measurement (12 repetitions beside 14 frames' shading
+and geometry phases: 0 differing samples).  A new kernel on the K = 16 instruction fails this test until it is guarded."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dual-space-nerf_amd", "csrc")
-# cleared by measurement (unguarded: 0 differing samples beside 14 frames' shading / geometry phases, 3 repetitions each)
-CLEARED = {"k_t_wgrad16d": "256 + 256 registers: nothing fits beside it; bisect tu4", "k_t_wgrad16p": "bisect tu8", "k_t_lin": "bisect tu16",
-           "k_t_wgrad": "bisect tu32", "k_t_wgrad16c": "round 3's kernel, DSN_WGRAD16=c only: 256 + 256 registers"}
-MFMA = re.compile(r"__builtin_amdgcn_mfma|MFMA16\(|DSN_MFMA\(|dense16x?<|dense16s<|v_mfma")
+X16 = re.compile(r"mfma_f32_32x32x16|MFMA16\(|dense16x?<|dense16s<")              # the K = 16 instruction and the pipelines built on it
+ANY_MFMA = re.compile(r"__builtin_amdgcn_mfma|MFMA16\(|DSN_MFMA\(|dense16x?<|dense16s<|v_mfma")
 GUARD = re.compile(r"DSN_OWN_SIMD\(\)|DSN_OWN_SIMD_T\((\d+)\)|v_mov_b32 v255")
+# matrix kernels WITHOUT the K = 16 instruction (what they issue instead): exempt - listed so that the scan's findings are explicit
+OTHER_MFMA = {"k_t_lin": "fp32 32x32x2", "k_t_wgrad": "fp32 32x32x2", "k_t_wgrad16p": "f16 32x32x8 (moved off the K = 16 form in round 6)",
+              "k_field": "fp32 32x32x2 (guarded anyway: 480 registers)", "k_light": "fp32 32x32x2 (guarded anyway: the fallback path)"}
+
+
+def _body(src, start):
+    i = src.index("{", start)
+    depth, j = 0, i
+    while True:
+        depth += src[j] == "{"
+        depth -= src[j] == "}"
+        j += 1
+        if depth == 0:
+            return src[i:j]
 
 
 def kernels(path):
     src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)                 # (comments name the instruction too)
     for m in re.finditer(r"__global__\s+void[^{;]*?\b(k_\w+)\s*\(", src):
-        name = m.group(1)
-        i = src.index("{", m.end())
-        depth, j = 0, i
-        while True:
-            c = src[j]
-            depth += c == "{"
-            depth -= c == "}"
-            j += 1
-            if depth == 0:
-                break
-        yield name, src[i:j], src
+        yield m.group(1), _body(src, m.end()), src
 
 
-def calls_matrix_pipeline(body, src, seen=None):
-    """does the kernel body (or a device function of this file it calls) issue MFMAs?"""
-    if MFMA.search(body):
+def reaches(body, src, pattern, seen=None):
+    """does the kernel body, or a device function of this file it calls, match `pattern`?"""
+    if pattern.search(body):
         return True
     seen = seen if seen is not None else set()
     for fn in set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*(?:<[^;{}()]*>)?\(", body)):
@@ -42,37 +46,28 @@ def calls_matrix_pipeline(body, src, seen=None):
             continue
         seen.add(fn)
         m = re.search(r"__device__[^;{]*?\b" + re.escape(fn) + r"\s*\([^;{]*?\)\s*\{", src)
-        if not m:
-            continue
-        i = m.end() - 1
-        depth, j = 0, i
-        while True:
-            depth += src[j] == "{"
-            depth -= src[j] == "}"
-            j += 1
-            if depth == 0:
-                break
-        if calls_matrix_pipeline(src[i:j], src, seen):
+        if m and reaches(_body(src, m.end() - 1), src, pattern, seen):
             return True
     return False
 
 
-def test_every_matrix_kernel_is_guarded_or_cleared():
+def test_every_kernel_on_the_k16_mfma_owns_its_simd():
     aggressor_bits = int(re.search(r"#define DSN_TRAIN_AGGRESSORS (\d+)", open(os.path.join(CSRC, "dsn_common.h")).read()).group(1))
-    found = {}
+    x16, other = {}, {}
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith(".hip"):
             continue
         for name, body, src in kernels(os.path.join(CSRC, f)):
-            if not calls_matrix_pipeline(body, src):
+            if not reaches(body, src, ANY_MFMA):
                 continue
             g = GUARD.search(body)
             guarded = bool(g) and (g.group(1) is None or (int(g.group(1)) & aggressor_bits) != 0)
-            found[name] = guarded
-            assert guarded or name in CLEARED, (f"{f}: matrix kernel {name} neither takes its SIMD's register file (DSN_OWN_SIMD) nor is it on "
-                                                f"the list of kernels cleared by scripts/dbg/race_bisect.sh")
-    # the known family is all there (the scan did not silently find nothing)
-    for k in ("k_field16", "k_field", "k_light16", "k_tangent16", "k_adjoint16", "k_screen16"):
-        assert found.get(k) is True, (k, found)
-    for k in ("k_t_wgrad16d", "k_t_wgrad16p", "k_t_lin", "k_t_wgrad"):
-        assert k in found, (k, found)
+            if reaches(body, src, X16):
+                x16[name] = guarded
+                assert guarded, f"{f}: {name} issues the K = 16 f16 MFMA and does not own its SIMD (DSN_OWN_SIMD): see csrc/dsn_common.h"
+            else:
+                other[name] = guarded
+                assert name in OTHER_MFMA, f"{f}: matrix kernel {name} is not on the K = 16 instruction and not listed: say what it issues"
+    # the scan found the family it is about (it did not silently match nothing)
+    assert set(x16) >= {"k_field16", "k_light16", "k_tangent16", "k_adjoint16", "k_screen16", "k_t_wgrad16d", "k_t_wgrad16q"}, x16
+    assert set(other) == set(OTHER_MFMA), (other, OTHER_MFMA)
