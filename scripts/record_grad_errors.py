@@ -23,11 +23,13 @@ for name in TT.GRAD_CASES:
     rec["reference"][name] = {k: max(err[k], nerr[k]) for k in err}
     rec["reference_norm"][name] = nerr
     print(name, "loss", loss, ref, "worst", max(err.values()), flush=True)
-if os.path.exists(os.path.join(ROOT, "tests", "golden", "full_train_grads_8192.npz")):
-    loss, ref, fwd, z, err, nerr = TT.config2_errors()
-    rec["reference"]["full_train_grads_8192"] = {k: max(err[k], nerr[k]) for k in err}
-    rec["config2_forward"] = {"loss": loss, "reference_loss": ref, "max_abs": fwd}
-    print("full_train_grads_8192 loss", loss, ref, fwd, "worst", max(err.values()), flush=True)
+rec["config2_forward"] = {}
+for name in ("full_train_grads_8192", "full_train_grads_8192_w4"):
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", name + ".npz")):
+        loss, ref, fwd, z, err, nerr = TT.config2_errors(name)
+        rec["reference"][name] = {k: max(err[k], nerr[k]) for k in err}
+        rec["config2_forward"][name] = {"loss": loss, "reference_loss": ref, "max_abs": fwd}
+        print(name, "loss", loss, ref, fwd, "worst", max(err.values()), flush=True)
 for name, nrays, nsamp in TT.ORACLE_CASES:
     err = TT.oracle_case_errors(name, nrays, nsamp)
     rec["oracle"][TT.oracle_case_key(name, nrays, nsamp)] = err
