@@ -702,7 +702,7 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     flags |= int(phases) & (PHASE_GEOMETRY | PHASE_FIELD | PHASE_SHADE)
     if share_cus:
         flags |= SHARE_CUS
-    if scene.lazy and train_cache is None:
+    if scene.lazy:               # (the training forward takes the flag too since round 6: dsn_render_rays_train's fused geometry)
         flags |= LAZY_LISTS
     if not phases or (int(phases) & PHASE_GEOMETRY):
         ws.begin_frame()          # (a larger record capacity asked for since the last frame: the buffer may be replaced HERE, only here)

@@ -126,14 +126,16 @@ class _RenderRays(torch.autograd.Function):
         params = [p.detach() for p in saved]
         sd = dict(zip(_lib.PARAM_ORDER, params))
         packed = r.net.packed(r.device)
-        if r.scene.frame_key != ctx.frame_key:              # another frame was set since this call's forward
+        cached = ctx.gen == getattr(r, "_cache_gen", -1)
+        # another frame was set since this call's forward - or the activations have to be recomputed and the frame was set lazily
+        # (its lists belong to the forward's render call: the recomputation's warp needs every cell's)
+        if r.scene.frame_key != ctx.frame_key or (not cached and r.scene.lazy):
             r.scene.set_frame(packed, xyz, poses, frame, zero_code, ls, rot, rc)
             r._frame_src = None
         if g_color is None:
             g_color = torch.zeros(o.shape[0], 3, device=r.device)
         if not hasattr(r, "_grad_ws"):
             r._grad_ws = _lib.GradWorkspace(r.device)
-        cached = ctx.gen == getattr(r, "_cache_gen", -1)
         if not cached:
             r._cache_gen = getattr(r, "_cache_gen", 0) + 1  # the recomputation below overwrites the shared workspace
         grads = _lib.render_rays_grad(r.scene, sd, poses, frame, zero_code, o, d, ctx.z_vals, noise, g_color, g_disp, g_acc,
@@ -186,6 +188,7 @@ class Renderer:
         # (DSN_FRAME_LAZY_LISTS: same lists entry for entry, for 48 % of the cells on a whole 512 x 512 frame, a tenth on a rank's
         # block of a partitioned frame).  False: every cell's lists in dsn_set_frame, as rounds 1-4 did.
         self.lazy_lists = True
+        self.train_lazy_lists = True
         # eval mode: plain-fp16 density screen in front of the accurate pass.  OPT-IN since round 4: its margin is
         # calibrated for the loaded parameters and audited while it runs - frames are bit-identical with it on or off on everything
         # tested - but that is statistical safety, not a proof, and the one converged checkpoint (w4) calibrates it off anyway.
@@ -505,7 +508,9 @@ class Renderer:
         self._poll_training_range()
         sd = dict(self.net.named_parameters())
         differentiable = self.net.training and torch.is_grad_enabled() and any(p.requires_grad for p in sd.values())
-        frame_args = self._set_frame(batch, lazy=not differentiable)      # (the training forward walks every cell's lists)
+        # (lazily set for training too since round 6: the training forward builds the lists of the cells its batch visits, or - small
+        #  batches - completes every cell's lists itself; `train_lazy_lists = False` keeps the per-step build of every cell in set_frame)
+        frame_args = self._set_frame(batch, lazy=(not differentiable) or self.train_lazy_lists)
         jitter, noise = self._draws(R, S)
         if self.sample_points_mode not in ("GG", "uniform"):
             raise Exception("error")   # the reference fails on unknown modes too (get_sampling_points returns nothing)

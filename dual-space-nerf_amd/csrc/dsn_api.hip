@@ -412,6 +412,7 @@ int dsn_camera_rays(const double* K3x3, const double* R3x3, const double* T3, co
 #define DSN_CELLMAJOR_MIN (1 << 20)   // below ~1 M samples the five extra launches cost more than they save (measured:
                                       // -0.12 ms at 128x128x32, +0.42 ms at 256x256x64)
 #define DSN_TRAIN_FAR_SEARCH_MIN (1 << 15)   // train mode: batches from here on search their far canonical points cell-major
+#define DSN_TRAIN_CELLMAJOR_MIN (1 << 18)    // train mode: batches from here on take the fused sampler + cell-major search + warp (round 6)
 struct DsnWorkspace {
     int32_t* count;       // [128] (first word = number of active samples)
     int32_t* active;      // [N]
@@ -811,9 +812,32 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     const int64_t N = (int64_t)R * S;
     const DsnTrainCache c = dsn_train_cache(grad_workspace, N);
     float* z = out_z ? out_z : w.z;
-    dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
     const bool exh = (flags & DSN_NN_EXHAUSTIVE) != 0;
-    dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
+    // Geometry.  Round 6: batches of DSN_TRAIN_CELLMAJOR_MIN samples or more take the eval frames' fused path - the sampler classifies
+    // the samples by fine cell, the cell-major search + warp run behind it (same index, same x_c, bit for bit: dsn_nn.hip) - and with
+    // DSN_LAZY_LISTS on a lazily set frame (DSN_FRAME_LAZY_LISTS) the posed mesh's lists are built for the cells the batch visits
+    // only: the per-step list build of every cell (0.48 ms of an 11.6 ms step at 8192 x 64) and the per-lane list walk of k_warp
+    // (0.18 ms) were the two largest non-matrix items of the step.  Smaller batches: k_warp on every cell's lists (a lazily set
+    // frame is completed first).  Every sample is warped (transparent samples with positive noise are evaluated: no lazy_canon).
+    static const long long train_cm_min = [] { const char* e = getenv("DSN_TRAIN_CELLMAJOR_MIN"); return e ? atoll(e) : (long long)DSN_TRAIN_CELLMAJOR_MIN; }();
+    const bool lazy = (flags & DSN_LAZY_LISTS) != 0;
+    const bool fused = !exh && N >= (int64_t)train_cm_min && !getenv("DSN_NN_UNFUSED");
+    if (lazy && !fused) dsn_launch_build_nn_complete(s.cent_world, F, s.nn_world, st);
+    if (fused) {
+        int32_t *counts = nullptr, *outside0 = nullptr, *outside = nullptr;
+        int32_t* g3 = (int32_t*)w.grad;      // scratch: cells (4 N) | ranks (4 N) | sorted records (16 N) across G and E, as in dsn_render_rays_ex
+        dsn_nn_cellmajor_begin(w.nn_small, &counts, &outside0, st);
+        dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st,
+                             s.nn_world.fine.g, g3, counts, outside0, g3 + N);
+        if (lazy) dsn_launch_build_nn_visited(s.cent_world, F, s.nn_world, counts, st);
+        dsn_launch_nn_cellmajor_warp(s.nn_world, ray_o, ray_d, z, N, S, g3, w.sort_scratch, w.nn_small, s.face_world, s.face_canon,
+                                     c.transparent, c.x_c, nullptr, nullptr, false, &outside, st, true, lazy);
+        dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st,
+                        nullptr, false, g3, outside);
+    } else {
+        dsn_launch_sample_gg(s.xyz, (flags & DSN_SAMPLE_UNIFORM) ? 0 : V, ray_o, ray_d, near, far, R, S, t_vals, jitter, z, nullptr, st);
+        dsn_launch_warp(s, nullptr, ray_o, ray_d, z, N, S, nullptr, nullptr, nullptr, c.transparent, c.x_c, nullptr, nullptr, nullptr, exh, st);
+    }
     // Rows the step evaluates: a transparent sample has its density forced to 0 (can_render.py:115-120), so with noise <= 0 its
     // alpha is exactly 0 (utils/nerf_net_utils.py:30-36: relu(0 + noise) = 0): neither its colour nor its density reaches an
     // output or receives a gradient.  Everything else - transparent samples with positive noise included, their colour is

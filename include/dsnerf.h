@@ -72,8 +72,9 @@ DSN_EXPORT int dsn_set_frame(void* scene, int V, int F, const void* packed, cons
  * lie in (the sampler classifies the samples by cell while it writes them; the build sits between it and the search).  Same kernels,
  * same sweeps, same lists entry for entry as the full build, for fewer cells: the samples of a 512 x 512 frame visit 48 % of the
  * posed mesh's fine cells, a rank's contiguous eighth of a partitioned frame a tenth (0.44 ms of list build per frame -> 0.1).
- * Such a level answers NO other query (its header keeps ok = 0): dsn_warp / dsn_lbs_warp / dsn_render_rays_train on a lazily set
- * frame take the exhaustive sweep - the same index, slowly; set the frame without the flag for those. */
+ * Such a level answers NO other query (its header keeps ok = 0): dsn_warp / dsn_lbs_warp / dsn_render_rays_grad without
+ * DSN_GRAD_CACHED on a lazily set frame take the exhaustive sweep - the same index, slowly; set the frame without the flag for
+ * those.  dsn_render_rays_train takes DSN_LAZY_LISTS like dsn_render_rays[_ex] (round 6). */
 #define DSN_FRAME_LAZY_LISTS 2
 DSN_EXPORT int dsn_set_frame_ex(void* scene, int V, int F, const void* packed, const float* xyz, const float* poses24x3, int frame_idx,
                      int zero_code, const float* light_shift3, const float* rot2x2, const float* rot_center2, int flags,

@@ -71,7 +71,8 @@ def test_lazy_lists_give_the_same_frame(nonuniform, wname, hw):
 
 def test_lazy_lists_through_the_renderer():
     """Renderer sets eval frames lazily (lazy_lists = True, the default): render_view / render / render_views == the same with every
-    cell's lists; a stage call after a lazily rendered frame re-sets the frame and answers from full lists; training is never lazy"""
+    cell's lists; a stage call after a lazily rendered frame re-sets the frame and answers from full lists; the training forward takes
+    lazily set frames too since round 6 (a batch below DSN_TRAIN_CELLMAJOR_MIN completes every cell's lists itself)"""
     canon, faces, batch = full_frame(hw=256)
     sd = state("x_w4")
     r1 = renderer_with(sd, canon, faces, density_screen=False)
@@ -104,7 +105,13 @@ def test_lazy_lists_through_the_renderer():
     sub = {k: (v[:, :2048].contiguous() if k in ("ray_o", "ray_d", "near", "far") else v) for k, v in fresh().items()}
     torch.manual_seed(1)
     out = r1.render(sub)["coarse"]
-    assert not r1.scene.lazy and out["color"].requires_grad
+    assert r1.scene.lazy and out["color"].requires_grad
+    r2.train()
+    torch.manual_seed(1)
+    out2 = r2.render(sub)["coarse"]
+    assert not r2.scene.lazy                                  # (lazy_lists = False switches it off for training as well)
+    for k in ("color", "acc_map", "depth_map", "weights", "z_vals"):
+        assert _same(out[k].detach(), out2[k].detach()), k
 
 
 def test_lazy_lists_that_do_not_fit_stay_exact_and_warn(monkeypatch):

@@ -218,3 +218,59 @@ def test_training_backward_beside_frames_leaves_them_bit_identical():
             assert torch.equal(a["transparent"], ref["transparent"])
             assert torch.equal(a["x_c"][live], ref["x_c"][live])
     assert overlapped >= 2, "the aggressor and the victims did not run at the same time: the test proves nothing"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# training forward: the eval frames' fused geometry (sampler classification + lazily built lists + cell-major search + warp)
+# ------------------------------------------------------------------------------------------------------------------------
+def test_training_geometry_fused_and_lazy_equals_the_per_lane_walk(monkeypatch):
+    """An 8192 x 64 training batch (>= DSN_TRAIN_CELLMAJOR_MIN samples) takes the fused path on a lazily set frame since round 6.  The
+    same batch with DSN_NN_UNFUSED (k_warp's per-lane list walk on every cell's lists, as rounds 1-5): forward outputs bit for bit,
+    and the gradient tensors that are reproducible from run to run bit for bit as well."""
+    import dsnerf_amd
+    from dsnerf_amd import synth
+    from cases import make_cfg
+    R, S, HW = 8192, 64, 512
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(HW, HW, xyz, fit_box=True)
+    sel = np.linspace(0, HW * HW - 1, R).astype(np.int64)
+    sd = state("x_w4")
+    cfg = make_cfg(S)
+    dev = torch.device("cuda:0")
+
+    def run(lazy):
+        net = dsnerf_amd.DualSpaceNeRF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.to(dev)
+        r = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+        r.train_lazy_lists = lazy
+        r.train()
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        b = {"ray_o": T(rays["ray_o"][sel])[None], "ray_d": T(rays["ray_d"][sel])[None], "near": T(rays["near"][sel])[None],
+             "far": T(rays["far"][sel])[None], "xyz": T(xyz)[None], "poses": T(synth.make_poses())[None], "Th": torch.zeros(1, 1, 3),
+             "frame": torch.tensor([5])}
+        torch.manual_seed(11)
+        out = r.render(b)["coarse"]
+        assert r.scene.lazy == lazy
+        target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32)).to(dev)
+        torch.nn.functional.mse_loss(out["color"], target).backward()
+        torch.cuda.synchronize()
+        assert r.range_overflow_count() == 0
+        return {k: out[k].detach().clone() for k in ("color", "acc_map", "depth_map", "weights", "z_vals")}, \\
+               {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    fa, ga = run(True)
+    fa2, ga2 = run(True)
+    monkeypatch.setenv("DSN_NN_UNFUSED", "1")
+    fb, gb = run(False)
+    monkeypatch.delenv("DSN_NN_UNFUSED")
+    for k in fa:
+        assert _same(fa[k], fb[k]), k
+    stable = [k for k in ga if torch.equal(ga[k], ga2[k])]
+    assert len(stable) >= 14                                   # (the trunk's matrices: fixed-order reductions)
+    for k in stable:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in ga:
+        d = float((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-30))
+        assert d < 1e-4, (k, d)
