@@ -855,7 +855,10 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     const int32_t* nn_far = nullptr;
     const char* far_env = getenv("DSN_TRAIN_FAR_SEARCH_MIN");      // test / tuning override (a huge value switches it off)
     if (!exh && N >= (far_env ? atoll(far_env) : (long long)DSN_TRAIN_FAR_SEARCH_MIN)) {
-        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, w.sort_scratch, w.pos, w.nn_small, st);
+        // (scratch of the segmented search, round 6: buffers the training forward does not use - the per-slice lists + the live list,
+        //  8 N contiguous bytes, for the (distance, index) keys; the active list for the wave -> cell map and the scatter cursors)
+        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, w.sort_scratch, w.pos, w.nn_small, st,
+                                       (void*)w.slices, F, w.active, N);
         nn_far = w.pos;
     }
     dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st, nn_far);

@@ -41,7 +41,8 @@ void dsn_launch_warp(const DsnSceneView& s, const float* pts, const float* ray_o
 size_t dsn_nn_sort_scratch_size(int64_t N);
 // nn [N] <- exact nearest centroid for the (live) points outside the fine grid and inside the coarse one, -1 for all others
 void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, const float* pts, const uint8_t* live, int64_t N,
-                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
+                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st, void* keys8N = nullptr, int F = 0,
+                                    int32_t* wave_scratch = nullptr, int64_t wave_scratch_ints = 0);
 void dsn_launch_nn_cellmajor(const DsnNNView& v, const float* pts, const float* ray_o, const float* ray_d, const float* z_vals,
                              int64_t N, int S, int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st);
 // the same search with the rest of the warp stage fused behind it (transparent, x_c, active list written by the search kernel);

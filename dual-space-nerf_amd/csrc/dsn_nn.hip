@@ -415,10 +415,18 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify(const DsnGrid* __r
 __device__ __forceinline__ bool nns_lists_usable(const DsnGrid* __restrict__ gf, int lazy_call) { return gf->ok || (lazy_call && gf->lazy == 2); }
 __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ gf, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ offs, int32_t* __restrict__ wave_offs,
-                                                    int32_t* __restrict__ totals, int keep_counts, int lazy_call) {
+                                                    int32_t* __restrict__ totals, int keep_counts, int lazy_call,
+                                                    const int32_t* __restrict__ list_off = nullptr, int seg = 0) {
+    // list_off / seg (optional, the far search of the training forward): a cell's waves are multiplied by ceil(list length / seg) -
+    // every wave then walks one SEGMENT of the cell's candidate list (k_nns_search_far)
     __shared__ int s_n[1024 * SCAN_PER];
     __shared__ int s_w[16];
     const int ncell = nns_lists_usable(gf, lazy_call) ? gf->ncell : 0;      // (lazy = 2: lists of the visited cells, built for this very search)
+    auto waves_of = [&](int cell, int cnt) {
+        int wv = (cnt + NNS_PER - 1) / NNS_PER;
+        if (list_off && wv > 0 && cell < ncell) { const int len = list_off[cell + 1] - list_off[cell]; wv *= len > seg ? (len + seg - 1) / seg : 1; }
+        return wv;
+    };
     const int t = threadIdx.x;
     int carry_a = 0, carry_b = 0;
     for (int base = 0; base < ncell; base += 1024 * SCAN_PER) {
@@ -426,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
         __syncthreads();
         int v[SCAN_PER], a = 0, b = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; a += v[k]; b += (v[k] + NNS_PER - 1) / NNS_PER; }
+        for (int k = 0; k < SCAN_PER; ++k) { v[k] = s_n[t * SCAN_PER + k]; a += v[k]; b += waves_of(base + t * SCAN_PER + k, v[k]); }
         int tot_a, tot_b;
         int ra = carry_a + dsn_block_exscan(a, s_w, tot_a);
         int rb = carry_b + dsn_block_exscan(b, s_w, tot_b);
@@ -436,7 +444,7 @@ __global__ void __launch_bounds__(1024) k_nns_scan(const DsnGrid* __restrict__ g
         for (int i = t; i < 1024 * SCAN_PER; i += 1024) if (base + i < ncell) offs[base + i] = s_n[i];
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += (v[k] + NNS_PER - 1) / NNS_PER; }
+        for (int k = 0; k < SCAN_PER; ++k) { s_n[t * SCAN_PER + k] = rb; rb += waves_of(base + t * SCAN_PER + k, v[k]); }
         __syncthreads();
         for (int i = t; i < 1024 * SCAN_PER; i += 1024)
             if (base + i < ncell) { wave_offs[base + i] = s_n[i]; if (!keep_counts) counts[base + i] = 0; }
@@ -795,8 +803,93 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_classify_coarse(const DsnGr
     const NnsRun r = nns_run(c, lane);
     if (r.head && c >= 0) atomicAdd(counts + c, r.len);
 }
+// The far search with the candidate lists cut into SEGMENTS (round 6).  Far from the body a coarse cell's list approaches all F
+// centroids; one wave walking it alone (two dependent scalar loads per candidate) took ~0.2 ms, and the kernel lasted as long as
+// its longest such wave whatever the chip had free (0.39 - 0.42 ms per 8192 x 64 training step, the largest non-matrix kernel).
+// Here wave (chunk of <= 128 samples, segment of <= NNS_FAR_SEG candidates) finds the segment's nearest candidate per sample and the
+// segments meet in a 64-bit atomicMin on (distance bits, face index): distances are non-negative floats, so the integer order IS
+// the (distance, index) lexicographic order - the smallest distance and, among equal ones, the smallest index: what the serial
+// ascending sweep with its strict '<' returns, from the same dsn_d2 values.
+#define NNS_FAR_SEG 768
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_search_far(const int32_t* __restrict__ off_c, const int32_t* __restrict__ list_c,
+                                                                const int32_t* __restrict__ wave_cell, const int32_t* __restrict__ wave_offs,
+                                                                const int32_t* __restrict__ totals, const int32_t* __restrict__ offs,
+                                                                const int32_t* __restrict__ counts, const float4* __restrict__ sorted,
+                                                                const float4* __restrict__ cent, unsigned long long* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (NNS_THREADS / 64) + (threadIdx.x >> 6));
+    if (w >= totals[0]) return;
+    const int c = __builtin_amdgcn_readfirstlane(wave_cell[w]);
+    const int cnt_c = __builtin_amdgcn_readfirstlane(counts[c]);
+    const int chunks = (cnt_c + NNS_PER - 1) / NNS_PER;
+    const int lw = w - __builtin_amdgcn_readfirstlane(wave_offs[c]);
+    const int sg = lw / chunks, ch = lw - sg * chunks;            // (segment-major: the chunks of one segment share its candidates in cache)
+    const int slot = ch * NNS_PER + lane;
+    const bool valid[2] = {slot < cnt_c, slot + 64 < cnt_c};
+    float4 q[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const int so = __builtin_amdgcn_readfirstlane(offs[c]);
+    if (valid[0]) q[0] = sorted[so + slot];
+    if (valid[1]) q[1] = sorted[so + slot + 64];
+    const int o = __builtin_amdgcn_readfirstlane(off_c[c]);
+    const int len = __builtin_amdgcn_readfirstlane(off_c[c + 1]) - o;
+    const int k0 = sg * NNS_FAR_SEG;
+    const int n = (len > NNS_FAR_SEG ? (k0 + NNS_FAR_SEG < len ? NNS_FAR_SEG : len - k0) : len);
+    const int32_t* __restrict__ ids = list_c + o + (len > NNS_FAR_SEG ? k0 : 0);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 px = {q[0].x, q[1].x}, py = {q[0].y, q[1].y}, pz = {q[0].z, q[1].z};
+    float best[2] = {INFINITY, INFINITY};
+    int bi[2] = {0x7fffffff, 0x7fffffff};
+    auto step = [&](const float4 a) {      // exactly dsn_d2 per component of the pair
+        const f32x2 cx = {a.x, a.x}, cy = {a.y, a.y}, cz = {a.z, a.z};
+        const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
+        f32x2 d = dx * dx;
+        d = __builtin_elementwise_fma(dy, dy, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+        const int id = __float_as_int(a.w);
+        if (d.x < best[0]) { best[0] = d.x; bi[0] = id; }
+        if (d.y < best[1]) { best[1] = d.y; bi[1] = id; }
+    };
+    auto at = [&](int f) { float4 a = cent[f]; a.w = __int_as_float(f); return a; };
+    constexpr int NB = 4;      // one batch ahead on the indices, one on the centroids (see k_nns_search)
+    const int nb = n / NB;
+    int f1[NB], f2[NB];
+    float4 a0[NB], a1[NB];
+    if (nb > 0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) f1[j] = ids[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a0[j] = at(f1[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) f1[j] = ids[NB * (1 < nb ? 1 : 0) + j];
+        for (int b = 0; b < nb; ++b) {
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) a1[j] = at(f1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) f2[j] = ids[NB * (b + 2 < nb ? b + 2 : 0) + j];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) step(a0[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { a0[j] = a1[j]; f1[j] = f2[j]; }
+        }
+    }
+    for (int k = NB * nb; k < n; ++k) step(at(ids[k]));
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+        if (valid[h2] && best[h2] < INFINITY)
+            atomicMin(keys + __float_as_int(q[h2].w), ((unsigned long long)__float_as_uint(best[h2]) << 32) | (unsigned)bi[h2]);
+}
+__global__ void __launch_bounds__(NNS_THREADS) k_nns_far_finish(const int32_t* __restrict__ cell_of, const unsigned long long* __restrict__ keys,
+                                                                int64_t N, int32_t* __restrict__ nn) {
+    const int64_t i = (int64_t)blockIdx.x * NNS_THREADS + threadIdx.x;
+    if (i < N && cell_of[i] >= 0) nn[i] = (int32_t)(keys[i] & 0xffffffffull);
+}
 void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, const float* pts, const uint8_t* live, int64_t N,
-                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st) {
+                                    int32_t* cell_of, void* sorted, int32_t* nn, void* small, hipStream_t st, void* keys8N, int F,
+                                    int32_t* wave_scratch, int64_t wave_scratch_ints) {
+    // keys8N (optional, 8 N bytes of scratch) + wave_scratch (ints: the wave -> cell map of the segmented launch + scatter cursors): the
+    // segmented search (k_nns_search_far).  NULL, too little scratch or DSN_FAR_SEGMENTS=0: one wave per list, as rounds 3-5
     char* q = (char*)small;
     int32_t* counts = (int32_t*)q;     q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
     int32_t* offs = (int32_t*)q;       q += dsn_align256(4 * (size_t)(DSN_NN_FINE_MAXCELL + 1));
@@ -807,6 +900,26 @@ void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, cons
     (void)hipMemsetAsync(counts, 0, 4 * (size_t)(DSN_NN_COARSE_MAXCELL + 1), st);
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify_coarse, gN, b, 0, st, v.fine.g, v.coarse.g, pts, live, N, cell_of, nn, counts);
+    static const bool seg_off = [] { const char* e = getenv("DSN_FAR_SEGMENTS"); return e && e[0] == '0'; }();
+    const int64_t nseg_max = ((int64_t)F + NNS_FAR_SEG - 1) / NNS_FAR_SEG;
+    const int64_t mw = (N / NNS_PER + DSN_NN_COARSE_MAXCELL + 1) * (nseg_max > 0 ? nseg_max : 1);      // most waves the scan can ask for
+    if (keys8N && wave_scratch && !seg_off && mw + DSN_NN_COARSE_MAXCELL + 1 <= wave_scratch_ints) {
+        wave_cell = wave_scratch;
+        (void)hipMemsetAsync(keys8N, 0xff, 8 * (size_t)N, st);
+        hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 1, 0, (const int32_t*)v.coarse.offsets,
+                           NNS_FAR_SEG);
+        hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell, 0);
+        // (counts kept by the scan: the atomic scatter needs cursors of its own - the wave offsets' neighbour array is free: ranks via a
+        //  cleared copy would cost a launch; k_nns_scatter runs on a zeroed cursor array placed behind wave_cell)
+        int32_t* cursor = wave_cell + mw;
+        (void)hipMemsetAsync(cursor, 0, 4 * (size_t)(DSN_NN_COARSE_MAXCELL + 1), st);
+        hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,
+                           offs, cursor, (float4*)sorted);
+        hipLaunchKernelGGL(k_nns_search_far, dim3((unsigned)((mw + 3) / 4)), b, 0, st, v.coarse.offsets, (const int32_t*)v.coarse.list, wave_cell,
+                           wave_offs, totals, offs, counts, (const float4*)sorted, cent, (unsigned long long*)keys8N);
+        hipLaunchKernelGGL(k_nns_far_finish, gN, b, 0, st, cell_of, (const unsigned long long*)keys8N, N, nn);
+        return;
+    }
     hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 0, 0);
     hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell, 0);
     hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,

@@ -257,8 +257,8 @@ def test_training_geometry_fused_and_lazy_equals_the_per_lane_walk(monkeypatch):
         torch.nn.functional.mse_loss(out["color"], target).backward()
         torch.cuda.synchronize()
         assert r.range_overflow_count() == 0
-        return {k: out[k].detach().clone() for k in ("color", "acc_map", "depth_map", "weights", "z_vals")}, \\
-               {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        fwd = {k: out[k].detach().clone() for k in ("color", "acc_map", "depth_map", "weights", "z_vals")}
+        return fwd, {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
     fa, ga = run(True)
     fa2, ga2 = run(True)
