@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search_far(const int32_t* _
                                                                 const int32_t* __restrict__ wave_cell, const int32_t* __restrict__ wave_offs,
                                                                 const int32_t* __restrict__ totals, const int32_t* __restrict__ offs,
                                                                 const int32_t* __restrict__ counts, const float4* __restrict__ sorted,
-                                                                const float4* __restrict__ cent, unsigned long long* __restrict__ keys) {
+                                                                const float4* __restrict__ cent, unsigned long long* __restrict__ keys, int seg) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (NNS_THREADS / 64) + (threadIdx.x >> 6));
     if (w >= totals[0]) return;
@@ -832,9 +832,9 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search_far(const int32_t* _
     if (valid[1]) q[1] = sorted[so + slot + 64];
     const int o = __builtin_amdgcn_readfirstlane(off_c[c]);
     const int len = __builtin_amdgcn_readfirstlane(off_c[c + 1]) - o;
-    const int k0 = sg * NNS_FAR_SEG;
-    const int n = (len > NNS_FAR_SEG ? (k0 + NNS_FAR_SEG < len ? NNS_FAR_SEG : len - k0) : len);
-    const int32_t* __restrict__ ids = list_c + o + (len > NNS_FAR_SEG ? k0 : 0);
+    const int k0 = sg * seg;
+    const int n = (len > seg ? (k0 + seg < len ? seg : len - k0) : len);
+    const int32_t* __restrict__ ids = list_c + o + (len > seg ? k0 : 0);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 px = {q[0].x, q[1].x}, py = {q[0].y, q[1].y}, pz = {q[0].z, q[1].z};
     float best[2] = {INFINITY, INFINITY};
@@ -901,13 +901,14 @@ void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, cons
     const dim3 gN((unsigned)((N + NNS_THREADS - 1) / NNS_THREADS)), b(NNS_THREADS);
     hipLaunchKernelGGL(k_nns_classify_coarse, gN, b, 0, st, v.fine.g, v.coarse.g, pts, live, N, cell_of, nn, counts);
     static const bool seg_off = [] { const char* e = getenv("DSN_FAR_SEGMENTS"); return e && e[0] == '0'; }();
-    const int64_t nseg_max = ((int64_t)F + NNS_FAR_SEG - 1) / NNS_FAR_SEG;
+    static const int seg = [] { const char* e = getenv("DSN_FAR_SEG"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 16384 ? v & ~3 : NNS_FAR_SEG; }();
+    const int64_t nseg_max = ((int64_t)F + seg - 1) / seg;
     const int64_t mw = (N / NNS_PER + DSN_NN_COARSE_MAXCELL + 1) * (nseg_max > 0 ? nseg_max : 1);      // most waves the scan can ask for
     if (keys8N && wave_scratch && !seg_off && mw + DSN_NN_COARSE_MAXCELL + 1 <= wave_scratch_ints) {
         wave_cell = wave_scratch;
         (void)hipMemsetAsync(keys8N, 0xff, 8 * (size_t)N, st);
         hipLaunchKernelGGL(k_nns_scan, dim3(1), dim3(1024), 0, st, v.coarse.g, counts, offs, wave_offs, totals, 1, 0, (const int32_t*)v.coarse.offsets,
-                           NNS_FAR_SEG);
+                           seg);
         hipLaunchKernelGGL(k_nns_expand, dim3(DSN_NN_COARSE_MAXCELL / NNS_THREADS), b, 0, st, v.coarse.g, wave_offs, totals, wave_cell, 0);
         // (counts kept by the scan: the atomic scatter needs cursors of its own - the wave offsets' neighbour array is free: ranks via a
         //  cleared copy would cost a launch; k_nns_scatter runs on a zeroed cursor array placed behind wave_cell)
@@ -916,7 +917,7 @@ void dsn_launch_nn_cellmajor_coarse(const DsnNNView& v, const float4* cent, cons
         hipLaunchKernelGGL(k_nns_scatter, gN, b, 0, st, cell_of, pts, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 1,
                            offs, cursor, (float4*)sorted);
         hipLaunchKernelGGL(k_nns_search_far, dim3((unsigned)((mw + 3) / 4)), b, 0, st, v.coarse.offsets, (const int32_t*)v.coarse.list, wave_cell,
-                           wave_offs, totals, offs, counts, (const float4*)sorted, cent, (unsigned long long*)keys8N);
+                           wave_offs, totals, offs, counts, (const float4*)sorted, cent, (unsigned long long*)keys8N, seg);
         hipLaunchKernelGGL(k_nns_far_finish, gN, b, 0, st, cell_of, (const unsigned long long*)keys8N, N, nn);
         return;
     }
