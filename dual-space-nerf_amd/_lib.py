@@ -41,6 +41,7 @@ EXPORTS = [
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
     "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_render_workspace_bytes_for",
     "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_early_stop_colour_headroom", "dsn_render_rays_ex",
+    "dsn_render_rays_grad_ex", "dsn_aux_create", "dsn_aux_destroy",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -90,8 +91,8 @@ def lib():
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 6:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 6 - rebuild it "
+        if L.dsn_abi_version() != 7:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 7 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -869,6 +870,26 @@ class GradWorkspace:
     def __init__(self, device):
         self.device = torch.device(device)
         self.buf = None
+        self._aux = None           # (aux stream, fork event, join event) of dsn_render_rays_grad_ex, made on first use
+
+    def aux(self):
+        """the second stream + two events the backward's independent chains use (DSN_TRAIN_AUX=0: none - one stream, as rounds 1-5)"""
+        if os.environ.get("DSN_TRAIN_AUX", "1") == "0":
+            return (None, None, None)
+        if self._aux is None:
+            h = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+            with torch.cuda.device(self.device):
+                _check(lib().dsn_aux_create(C.byref(h[0]), C.byref(h[1]), C.byref(h[2])), "dsn_aux_create")
+            self._aux = tuple(C.c_void_p(x.value) for x in h)
+        return self._aux
+
+    def __del__(self):
+        a, self._aux = getattr(self, "_aux", None), None
+        if a is not None:
+            try:
+                lib().dsn_aux_destroy(*a)
+            except Exception:
+                pass
 
     def get(self, R, S):
         need = lib().dsn_grad_workspace_bytes(int(R), int(S))
@@ -926,10 +947,11 @@ def render_rays_grad(scene: Scene, params, poses, frame_idx, zero_code, ray_o, r
     poses = _f32(poses.reshape(24, 3), dev)
     f = lambda a: None if a is None else _f32(a, dev)
     args = [f(ray_o), f(ray_d), f(z_vals), f(noise), f(d_rgb), f(d_disp), f(d_acc), f(d_depth), f(d_weights)]
-    _check(lib().dsn_render_rays_grad(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
-                                      _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), int(R), int(S),
-                                      _ptr(args[4]), _ptr(args[5]), _ptr(args[6]), _ptr(args[7]), _ptr(args[8]), gp,
-                                      _ptr(buf), 1 if cached else 0, _stream()), "dsn_render_rays_grad")
+    ax = ws.aux()
+    _check(lib().dsn_render_rays_grad_ex(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), pp, _ptr(poses), int(frame_idx), int(bool(zero_code)),
+                                         _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]), int(R), int(S),
+                                         _ptr(args[4]), _ptr(args[5]), _ptr(args[6]), _ptr(args[7]), _ptr(args[8]), gp,
+                                         _ptr(buf), 1 if cached else 0, _stream(), ax[0], ax[1], ax[2]), "dsn_render_rays_grad")
     scene._keep_grad = (prm, args, poses, packed)
     return grads
 

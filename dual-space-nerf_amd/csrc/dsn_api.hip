@@ -337,18 +337,55 @@ int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, co
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
                          int flags, void* stream) {
+    return dsn_render_rays_grad_ex(scene, V, F, packed, params33_host, poses24x3, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, R, S, d_rgb,
+                                   d_disp, d_acc, d_depth, d_weights, grads33_host, workspace, flags, stream, nullptr, nullptr, nullptr);
+}
+
+int dsn_render_rays_grad_ex(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
+                            int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
+                            const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
+                            const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
+                            int flags, void* stream, void* aux_stream, void* ev_fork, void* ev_join) {
     DSN_REQUIRE(scene && packed && params33_host && poses24x3 && ray_o && ray_d && z_vals && d_rgb && grads33_host && workspace,
                 "dsn_render_rays_grad: null argument");
     DSN_REQUIRE(R > 0 && S > 0 && V > 0 && F > 0, "dsn_render_rays_grad: bad sizes");
     DSN_REQUIRE(frame_idx >= 0 && frame_idx < 500, "dsn_render_rays_grad: frame index outside the embedding table");
+    DSN_REQUIRE((aux_stream != nullptr) == (ev_fork != nullptr) && (aux_stream != nullptr) == (ev_join != nullptr),
+                "dsn_render_rays_grad_ex: the auxiliary stream and its two events go together");
+    DSN_REQUIRE(!aux_stream || aux_stream != stream, "dsn_render_rays_grad_ex: the auxiliary stream must not be the call's own stream");
     for (int i = 0; i < DSN_NUM_PARAMS; ++i)
         DSN_REQUIRE(params33_host[i] && grads33_host[i], "dsn_render_rays_grad: null parameter / gradient pointer");
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
+    const DsnTrainAux aux = {(hipStream_t)aux_stream, (hipEvent_t)ev_fork, (hipEvent_t)ev_join};
     const char* err = dsn_train_run(s, (const float*)packed, params33_host, poses24x3, frame_idx, zero_code, ray_o, ray_d, z_vals, noise, R, S, d_rgb,
                                     d_disp, d_acc, d_depth, d_weights, grads33_host, workspace, (hipStream_t)stream,
-                                    (flags & DSN_GRAD_CACHED) != 0);
+                                    (flags & DSN_GRAD_CACHED) != 0, nullptr, nullptr, nullptr, aux_stream ? &aux : nullptr);
     if (err) return dsn_fail("dsn_render_rays_grad: %s failed", err);
     return dsn_check_launch("dsn_render_rays_grad");
+}
+
+// the caller's auxiliary stream + fork / join events of dsn_render_rays_grad_ex, for callers without a HIP binding of their own
+// (created and destroyed by the caller through these two; the library keeps no record of them)
+int dsn_aux_create(void** aux_stream, void** ev_fork, void** ev_join) {
+    DSN_REQUIRE(aux_stream && ev_fork && ev_join, "dsn_aux_create: null argument");
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        if (st) (void)hipStreamDestroy(st);
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        return dsn_fail("%s", "dsn_aux_create: hipStreamCreate / hipEventCreate failed");
+    }
+    *aux_stream = (void*)st; *ev_fork = (void*)a; *ev_join = (void*)b;
+    return 0;
+}
+int dsn_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join) {
+    int bad = 0;
+    if (aux_stream) bad |= hipStreamDestroy((hipStream_t)aux_stream) != hipSuccess;
+    if (ev_fork) bad |= hipEventDestroy((hipEvent_t)ev_fork) != hipSuccess;
+    if (ev_join) bad |= hipEventDestroy((hipEvent_t)ev_join) != hipSuccess;
+    return bad ? dsn_fail("%s", "dsn_aux_destroy: destroy failed") : 0;
 }
 
 // backward of DualSpaceNeRF.forward on explicit points (model/spacenet.py:210-266): see dsnerf.h

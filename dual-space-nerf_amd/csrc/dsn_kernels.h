@@ -136,12 +136,15 @@ void dsn_launch_adjoint16(const float* packed, int64_t N, const void* masks, con
 void dsn_launch_tangent16(const float* packed, const float* x_c, const float* u, int64_t N, const void* masks, float* tr_t,
                           float* gmax, hipStream_t st, int32_t* range_count = nullptr, const int32_t* row_list = nullptr,
                           const int32_t* row_count = nullptr, float* colsum6 = nullptr);
+// a second stream of the caller's for the training backward's two independent chains (dsn_render_rays_grad_ex): fork / join events
+struct DsnTrainAux { hipStream_t stream; hipEvent_t fork, join; };
 const char* dsn_train_run(const DsnSceneView& s, const float* packed, const float* const* params33, const float* poses, int frame_idx,
                           int zero_code,
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
                           const float* d_weights, float* const* grads33, void* workspace, hipStream_t st, bool cached = false,
-                          const float* ext_x_c = nullptr, const float* ext_d_col = nullptr, const float* ext_d_sig = nullptr);
+                          const float* ext_x_c = nullptr, const float* ext_d_col = nullptr, const float* ext_d_sig = nullptr,
+                          const DsnTrainAux* aux = nullptr);
 
 // dsn_image.hip: image epilogue on the device (post_process scatter, clamp, mse / psnr)
 size_t dsn_image_workspace_size(int H, int W);

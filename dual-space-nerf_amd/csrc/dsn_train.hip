@@ -2228,7 +2228,8 @@ void colsum(const float* a, int C, int64_t N, float* out, hipStream_t st, Rows r
 template <int OUT>
 void wcolsum(const float* X, int C, const float* dY, int64_t N, float* dW, float* db, hipStream_t st, Rows rw = Rows{nullptr, nullptr},
              const float* W = nullptr, float* dX = nullptr, float* gmax = nullptr) {
-    const int rows = 256;
+    static const int rows_env = [] { const char* e = getenv("DSN_WCOLSUM_ROWS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 4096 ? v : 0; }();
+    const int rows = rows_env ? rows_env : 512;      // (round 6: 256 -> 512 rows per block, -0.07 ms per step - the blocks' atomics, not the rows, were the cost; 1024: slower)
     hipLaunchKernelGGL((k_t_wcolsum<OUT>), dim3((unsigned)((N + rows - 1) / rows)), dim3(T_THREADS), 0, st, X, C, dY, N, rows, dW, db, rw, W, dX,
                        (unsigned*)gmax);
 }
@@ -2277,7 +2278,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
                           const float* ray_o, const float* ray_d, const float* z_vals, const float* noise, int R, int S,
                           const float* d_rgb, const float* d_disp, const float* d_acc, const float* d_depth,
                           const float* d_weights, float* const* grd, void* workspace, hipStream_t st, bool cached,
-                          const float* ext_x_c, const float* ext_d_col, const float* ext_d_sig) {
+                          const float* ext_x_c, const float* ext_d_col, const float* ext_d_sig, const DsnTrainAux* aux) {
     // ext_* (all three or none): "module" mode, the backward of DualSpaceNeRF.forward (model/spacenet.py:210-266) on explicit
     // points - canonical points ext_x_c [N,3] instead of the warp of the rays' samples, and the per-sample cotangents of
     // (colour, density) ext_d_col [N,3] / ext_d_sig [N] instead of the adjoint of compositing.  The caller passes S = 1,
@@ -2355,6 +2356,20 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     if (two_pass_heads) hipLaunchKernelGGL(k_t_pe, grid_for(N64 * PE_LD), dim3(T_THREADS), 0, st, w.x_c, N64, w.pe, R2);
     hipLaunchKernelGGL(k_t_colour_adjoint, grid_for(N64), dim3(T_THREADS), 0, st, d_col, w.ess, w.wl, w.pre, N64, w.d_ess,
                        w.d_pre, R2);
+    // Two chains that do not depend on each other hang off this point (round 6): T - the lighting MLP's backward, u = dL/dg, the PE
+    // tangent and k_tangent16 - and A - the colour head's backward, the adjoint seed and k_adjoint16.  Most of their kernels are small
+    // (0.1 - 0.25 ms, a few hundred MB each, 2 - 3 TB/s alone): with a second stream of the CALLER's (dsn_render_rays_grad_ex: aux
+    // stream + two events, fork here, join in front of the weight-gradient products) chain A runs beside chain T.  Same kernels, same
+    // arguments, same values; the only shared scratch - the partial tiles of the two 128-row products - is given a place of its own
+    // (three adjoint layers' arrays, which k_adjoint16 fills later on the same stream).  Without aux: one stream, as before.
+    static const bool pairs_ = [] { const char* e = getenv("DSN_WGRAD_PAIRS"); return !(e && e[0] == '0'); }();
+    const bool two = aux && aux->stream && aux->fork && aux->join && pairs_ && heads16 && N64 >= 4096;
+    hipStream_t sa = st;
+    if (two) {
+        sa = aux->stream;
+        if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(sa, aux->fork, 0) != hipSuccess) return "fork of the auxiliary stream";
+    }
+    float* const part_a = two ? w.an[3] : w.wg_part;      // (3 KB per row: an[3 .. 5], contiguous; a 128 x 256 tile per workgroup needs 2.1 KB per row at most)
 
     // ---- lighting MLP backward -----------------------------------------------------------------------------------
     // (the heads' weight gradients and the data gradients behind their relus in ONE sweep over hl2 / rr; DSN_TRAIN_UNFUSED_HEADS=1: two)
@@ -2411,10 +2426,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         hipLaunchKernelGGL(k_t_rgb_hidden_adjoint, grid_for((N64 * 128) / 4), dim3(T_THREADS), 0, st, w.d_ess, prm[P_RGB3_W], w.rr, N64 * 128,
                            w.d_rr, R2);
     } else
-        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], st, R2, prm[P_RGB3_W], w.d_rr, g_drr);
-    if (heads16) wgrad_mfma16q<256>(N64, w.h[6], nullptr, w.d_rr, g_drr, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2, w.wg_part);
+        wcolsum<3>(w.rr, 128, w.d_ess, N64, grd[P_RGB3_W], grd[P_RGB3_B], sa, R2, prm[P_RGB3_W], w.d_rr, g_drr);
+    if (heads16) wgrad_mfma16q<256>(N64, w.h[6], nullptr, w.d_rr, g_drr, grd[P_RGB1_W], 256, sa, grd[P_RGB1_B], R2, part_a);
     else T_CHECK(wgrad_mfma(N64, 256, 256, 128, w.h[6], 256, w.d_rr, 128, grd[P_RGB1_W], 256, st, grd[P_RGB1_B], R2));
-    wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], st, R2);
+    wcolsum<1>(w.h[6], 256, d_sig, N64, grd[P_DEN_W], grd[P_DEN_B], sa, R2);
     // cur = ahat_6 = (h6 > 0) (d_rr W_rgb1 + d_sig w_den): the colour head's data gradient with the density head's seed fused in
     // (round 6: the relu pattern of layer 6 from the forward's records - 32 bytes per row instead of the 1 KB row of h_6;
     //  DSN_TRAIN_SEED_MASK=h keeps the `h_6 > 0` form, A/B and cross-check)
@@ -2423,7 +2438,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = pairs ? w.an : w.tn;
-    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, st, range_cnt, R2.list, R2.cnt);
+    dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, sa, range_cnt, R2.list, R2.cnt);
+    if (two && (hipEventRecord(aux->join, sa) != hipSuccess || hipStreamWaitEvent(st, aux->join, 0) != hipSuccess)) return "join of the auxiliary stream";
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
         if (pairs) {

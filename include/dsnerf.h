@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 6
+#define DSN_ABI_VERSION 7
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -257,6 +257,21 @@ DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void*
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
                          const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
                          int flags, void* stream);
+/* The same with a SECOND stream of the caller's (round 6).  Behind the adjoint of compositing the backward splits into two chains
+ * that do not depend on each other - the lighting MLP's backward + the tangent pass, and the colour head's backward + the adjoint
+ * pass (trainer.py:70-81 loss.backward() through model/spacenet.py:251-265 on one side, :136-147 on the other) - most of whose
+ * kernels are too small to fill the chip.  With aux_stream / ev_fork / ev_join (a hipStream_t and two hipEvent_t, all three or none)
+ * the second chain is enqueued on aux_stream between a fork and a join: everything the call enqueues is still ordered after what
+ * `stream` held before the call and before what it gets afterwards, and nothing is synchronised on the host.  Same kernels, same
+ * values.  dsn_aux_create / dsn_aux_destroy make and free such a triple for callers without a HIP binding of their own; they are
+ * the caller's, the library keeps no record of them. */
+DSN_EXPORT int dsn_render_rays_grad_ex(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
+                         int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
+                         const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,
+                         const float* d_depth, const float* d_weights, float* const* grads33_host, void* workspace,
+                         int flags, void* stream, void* aux_stream, void* ev_fork, void* ev_join);
+DSN_EXPORT int dsn_aux_create(void** aux_stream, void** ev_fork, void** ev_join);
+DSN_EXPORT int dsn_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join);
 
 /* Backward of DualSpaceNeRF.forward(pos[N,6], rays[N,6], frame_idx, batch_info) (model/spacenet.py:210-266) on explicit
  * points, what autograd computes when a caller differentiates (colour, density) w.r.t. the parameters (can_render.py:97-134
