@@ -2434,7 +2434,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // (round 6: the relu pattern of layer 6 from the forward's records - 32 bytes per row instead of the 1 KB row of h_6;
     //  DSN_TRAIN_SEED_MASK=h keeps the `h_6 > 0` form, A/B and cross-check)
     static const bool seed_by_h = [] { const char* e = getenv("DSN_TRAIN_SEED_MASK"); return e && e[0] == 'h'; }();
-    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, st, R2, seed_by_h ? nullptr : w.masks, 6);
+    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, sa, R2, seed_by_h ? nullptr : w.masks, 6);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = pairs ? w.an : w.tn;
