@@ -274,3 +274,57 @@ def test_training_geometry_fused_and_lazy_equals_the_per_lane_walk(monkeypatch):
     for k in ga:
         d = float((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-30))
         assert d < 1e-4, (k, d)
+
+
+@pytest.mark.gpu
+def test_two_stream_backward_equals_the_one_stream_backward(monkeypatch):
+    """dsn_render_rays_grad_ex with an auxiliary stream (default since round 6: the colour head / adjoint chain beside the lighting /
+    tangent chain) against the same call on ONE stream (DSN_TRAIN_AUX=0).  Every run starts from a fresh workspace filled with 0xFF
+    (DSN_POISON_SCRATCH) so that a kernel launched on the wrong stream cannot pass by reading what an earlier, identical run left
+    behind - which is how the adjoint seed on the main stream once went unnoticed.  The tensors with fixed-order reductions: bit for
+    bit; the atomically accumulated ones: within their own run-to-run spread."""
+    import dsnerf_amd
+    from dsnerf_amd import synth
+    from cases import make_cfg
+    monkeypatch.setenv("DSN_POISON_SCRATCH", "1")
+    R, S, HW = 2048, 64, 256
+    canon, faces = synth.make_body()
+    xyz = synth.pose_body(canon)
+    rays = synth.make_rays(HW, HW, xyz, fit_box=True)
+    sel = np.linspace(0, HW * HW - 1, R).astype(np.int64)
+    sd = state("x_w4")
+    cfg = make_cfg(S)
+    dev = torch.device("cuda:0")
+
+    def run(aux):
+        monkeypatch.setenv("DSN_TRAIN_AUX", aux)
+        net = dsnerf_amd.DualSpaceNeRF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.to(dev)
+        r = dsnerf_amd.Renderer(net, None, cfg, torch.from_numpy(canon), body_data={"f": faces}, device=dev)
+        r.train()
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        b = {"ray_o": T(rays["ray_o"][sel])[None], "ray_d": T(rays["ray_d"][sel])[None], "near": T(rays["near"][sel])[None],
+             "far": T(rays["far"][sel])[None], "xyz": T(xyz)[None], "poses": T(synth.make_poses())[None], "Th": torch.zeros(1, 1, 3),
+             "frame": torch.tensor([5])}
+        torch.manual_seed(11)
+        out = r.render(b)["coarse"]
+        target = T(synth.hash_uniform(R * 3, 77).reshape(R, 3).astype(np.float32)).to(dev)
+        (torch.nn.functional.mse_loss(out["color"], target) + 0.1 * out["acc_map"].mean()).backward()   # (no synchronize in between)
+        g = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        assert r.range_overflow_count() == 0
+        assert (r._grad_ws._aux is not None) == (aux == "1")
+        return g
+
+    one, one2, two, two2 = run("0"), run("0"), run("1"), run("1")
+    stable = [k for k in one if torch.equal(one[k], one2[k])]
+    assert len(stable) >= 14
+    for k in one:
+        assert torch.isfinite(two[k]).all(), k
+        n = one[k].norm().clamp_min(1e-30)
+        spread = max(float((one[k] - one2[k]).norm() / n), float((two[k] - two2[k]).norm() / n))
+        d = float((one[k] - two[k]).norm() / n)
+        if k in stable:
+            assert torch.equal(one[k], two[k]) and torch.equal(two[k], two2[k]), k
+        else:
+            assert d <= 4.0 * spread + 1e-7, (k, d, spread)
