@@ -2150,6 +2150,142 @@ void lin(const float* X, const float* W, float* Y, int64_t N, const float* bias_
                        (const uint4*)recs, rec_layer);
 }
 
+// k_t_lin16 (round 6): the split-fp16 sibling of k_t_lin<K, M, false, EPI_MASK | EPI_SEED> - the two data-gradient products of the
+// heads' backward, d_hl1 = (hl1 > 0) (d_hl2 W_l2) and ahat_6 = m_6 (d_rr W_rgb1 + d_sig w_den).  On the fp32 MFMA they were bound by the
+// matrix pipe (0.17 + 0.25 ms per 8192 x 64 step at 60 - 80 TFLOP/s); with hi + lo halves (X / sx and W, three K = 16 products per tile
+// and step, as everywhere else in the backward) the pipe's share drops to a sixth and the sweeps run at what their 1.5 KB per row cost.
+// sx: the batch-wide magnitude of X the producing sweep left (k_t_wcolsum's gmax).  W is split as it is staged: [k / 8][column] half8
+// pairs, K M 4 bytes of LDS (128 KB for 128 x 256), one workgroup per CU.  A lane owns one row of the wave's 32-row tile and the k-groups
+// of its half-wave: its 16 float4 of the NEXT tile are requested before the products of this one.  Same accumulator layout, same
+// epilogues and stores as k_t_lin.
+template <int K, int M, int EPI>
+__global__ void __launch_bounds__(256, 1) k_t_lin16(const float* __restrict__ X, const float* __restrict__ sx_ptr, const float* __restrict__ W,
+                                                    float* __restrict__ Y, int64_t N, const float* __restrict__ wv,
+                                                    const float* __restrict__ msrc, const float* __restrict__ sc, Rows rw,
+                                                    const uint4* __restrict__ recs, int rec_layer) {
+    DSN_OWN_SIMD();
+    static_assert(EPI == EPI_MASK || EPI == EPI_SEED, "the backward's two data-gradient products");
+    constexpr int NT = M / 32, KG = K / 8, ST = K / 16;
+    __shared__ __attribute__((aligned(16))) t_half8 sWh[KG][M];
+    __shared__ __attribute__((aligned(16))) t_half8 sWl[KG][M];
+    __shared__ float sV[M];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KG * M; i += 256) {
+        const int kg = i / M, m = i % M;
+        t_half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = W[(8 * kg + j) * M + m];
+            const _Float16 h = (_Float16)w;
+            hi[j] = h;
+            lo[j] = (_Float16)(w - (float)h);
+        }
+        sWh[kg][m] = hi;
+        sWl[kg][m] = lo;
+    }
+    if (EPI == EPI_SEED)
+        for (int i = tid; i < M; i += 256) sV[i] = wv[i];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const float sx = sx_ptr ? t_pow2_at_least(*sx_ptr) : 1.0f, inv = 1.0f / sx;
+    const int64_t NL = rows_n(rw, N);
+    const int64_t ntile = (NL + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float4 xn[2 * ST];
+    auto request = [&](int64_t tile) {
+        const int64_t lrow = tile * 32 + col;
+        const float* xr = X + rows_at(rw, lrow < NL ? lrow : NL - 1) * K + 8 * half;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            xn[2 * s] = *reinterpret_cast<const float4*>(xr + 16 * s);
+            xn[2 * s + 1] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
+        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) request(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t lrow = tile * 32 + col;
+        const bool valid = lrow < NL;
+        const int64_t crow = rows_at(rw, valid ? lrow : NL - 1);
+        float4 xc[2 * ST];
+#pragma unroll
+        for (int i = 0; i < 2 * ST; ++i) xc[i] = xn[i];
+        if (tile + stride < ntile) request(tile + stride);
+        // what the epilogue needs from memory is requested now and used behind the products
+        float4 mk[EPI == EPI_MASK ? NT : 1][4];
+        float scn = 0.0f;
+        const bool by_rec = EPI == EPI_SEED && recs != nullptr;      // kernel-uniform
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (by_rec) rec = recs[((size_t)crow * 2 + half) * 7 + rec_layer];
+        else if (EPI == EPI_MASK) {
+            const float* mr = msrc + crow * M + 4 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mk[EPI == EPI_MASK ? t : 0][q] = *reinterpret_cast<const float4*>(mr + 32 * t + 8 * q);
+        }
+        if (EPI == EPI_SEED) scn = sc[crow];
+        t_f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            const float xv[8] = {xc[2 * s].x, xc[2 * s].y, xc[2 * s].z, xc[2 * s].w, xc[2 * s + 1].x, xc[2 * s + 1].y, xc[2 * s + 1].z, xc[2 * s + 1].w};
+            t_half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = xv[j] * inv;
+                const _Float16 h = (_Float16)x;
+                bh[j] = h;
+                bl[j] = (_Float16)(x - (float)h);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const t_half8 ah = sWh[2 * s + half][32 * t + col], al = sWl[2 * s + half][32 * t + col];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            }
+        }
+        // store: registers 4 q .. 4 q + 3 of tile t = features 32 t + 8 q + 4 half + (0..3) of this lane's row: float4 (as k_t_lin)
+        if (valid) {
+            float* yr = Y + crow * M + 4 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * t + 8 * q + 4 * half;
+                    float v[4] = {acc[t][4 * q] * sx, acc[t][4 * q + 1] * sx, acc[t][4 * q + 2] * sx, acc[t][4 * q + 3] * sx};
+                    const float4 m = mk[EPI == EPI_MASK ? t : 0][q];
+                    float m4[4] = {m.x, m.y, m.z, m.w};
+                    if (by_rec) {
+                        const uint32_t wd = (t >> 1) == 0 ? rec.x : ((t >> 1) == 1 ? rec.y : ((t >> 1) == 2 ? rec.z : rec.w));
+                        const uint32_t pat = (wd >> (16 * (t & 1))) & 0xffffu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m4[e] = ((pat >> (15 - (4 * q + e))) & 1u) ? 1.0f : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (EPI == EPI_MASK) v[e] = m4[e] > 0.0f ? v[e] : 0.0f;
+                        if (EPI == EPI_SEED) v[e] = m4[e] > 0.0f ? v[e] + scn * sV[f0 + e] : 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(yr + 32 * t + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+    }
+}
+template <int K, int M, int EPI>
+void lin16(const float* X, const float* sx, const float* W, float* Y, int64_t N, const float* wv, const float* msrc, const float* sc,
+           hipStream_t st, Rows rw, const void* recs = nullptr, int rec_layer = 0) {
+    const int64_t ntile = (N + 31) / 32;
+    int groups = (int)((ntile + 3) / 4);
+    if (groups > 256) groups = 256;               // one workgroup per CU: W is split and staged once per workgroup
+    hipLaunchKernelGGL((k_t_lin16<K, M, EPI>), dim3((unsigned)groups), dim3(256), 0, st, X, sx, W, Y, N, wv, msrc, sc, rw, (const uint4*)recs,
+                       rec_layer);
+}
+
 struct TrainWs {
     uint8_t* transparent;
     int32_t* idx_c;
@@ -2383,7 +2519,11 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     //  magnitudes the sweeps above leave; DSN_TRAIN_HEADS=fp32 keeps the exact-fp32 MFMA kernel, A/B and cross-check)
     if (heads16) wgrad_mfma16q<128>(N64, w.hl1, nullptr, w.d_hl2, g_dhl2, grd[P_L2_W], 128, st, grd[P_L2_B], R2, w.wg_part);
     else T_CHECK(wgrad_mfma(N64, 128, 128, 128, w.hl1, 128, w.d_hl2, 128, grd[P_L2_W], 128, st, grd[P_L2_B], R2));
-    lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);          // d_hl1 = (hl1 > 0) (d_hl2 W2)
+    // (round 6: the two data-gradient products of the heads on the split-fp16 kernel k_t_lin16; DSN_TRAIN_LIN=fp32 keeps k_t_lin, A/B and cross-check)
+    static const bool lin_fp32 = [] { const char* e = getenv("DSN_TRAIN_LIN"); return e && e[0] == 'f'; }();
+    const bool lin16_ = heads16 && !lin_fp32;      // (the operand scales come from the fused sweeps)
+    if (lin16_) lin16<128, 128, EPI_MASK>(w.d_hl2, g_dhl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);   // d_hl1 = (hl1 > 0) (d_hl2 W2)
+    else lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);
     // (the first lighting layer keeps its two passes over d_hl1: a VALU kernel that also accumulates dW0 takes 0.39 ms against
     //  0.107 for the exact-fp32 MFMA product + 0.129 for the data gradient - tried in round 5)
     T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2));
@@ -2434,7 +2574,8 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     // (round 6: the relu pattern of layer 6 from the forward's records - 32 bytes per row instead of the 1 KB row of h_6;
     //  DSN_TRAIN_SEED_MASK=h keeps the `h_6 > 0` form, A/B and cross-check)
     static const bool seed_by_h = [] { const char* e = getenv("DSN_TRAIN_SEED_MASK"); return e && e[0] == 'h'; }();
-    lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, sa, R2, seed_by_h ? nullptr : w.masks, 6);
+    if (lin16_ && !seed_by_h) lin16<128, 256, EPI_SEED>(w.d_rr, g_drr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], nullptr, d_sig, sa, R2, w.masks, 6);   // (pattern from the records only)
+    else lin<128, 256, false, EPI_SEED>(w.d_rr, prm[P_RGB1_W], cur, N64, prm[P_DEN_W], w.h[6], d_sig, sa, R2, seed_by_h ? nullptr : w.masks, 6);
     // cur = ahat_6.  The layers below it in one fused split-fp16 launch (k_adjoint16 -> ahat_5 ... ahat_0 in the buffers the
     // tangent products are done with), then  dW_l += ahat_l^T h_{l-1}  and the bias gradients (column sums)
     float* const* an = pairs ? w.an : w.tn;

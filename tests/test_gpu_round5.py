@@ -516,7 +516,8 @@ def test_paired_weight_gradient_launches_match_the_single_ones(tmp_path):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}
-    for tag, env_extra in (("pairs", {}), ("pairs_again", {}), ("single", {"DSN_WGRAD_PAIRS": "0"}), ("two_pass_heads", {"DSN_TRAIN_UNFUSED_HEADS": "1"})):
+    for tag, env_extra in (("pairs", {}), ("pairs_again", {}), ("single", {"DSN_WGRAD_PAIRS": "0"}), ("lin_fp32", {"DSN_TRAIN_LIN": "fp32"}),
+                           ("two_pass_heads", {"DSN_TRAIN_UNFUSED_HEADS": "1"})):
         env = dict(os.environ, **env_extra)
         path = str(tmp_path / (tag + ".npz"))
         p = subprocess.run([sys.executable, os.path.join(here, "_grads_dump.py"), "full_train_grads_w4", path], env=env, capture_output=True,
@@ -532,9 +533,13 @@ def test_paired_weight_gradient_launches_match_the_single_ones(tmp_path):
         err = np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
         assert err < 2e-6, (k, err)
         # the heads' data gradients and the backward's encoding written inside the sweeps that read their inputs (default) or by
-        # kernels of their own (DSN_TRAIN_UNFUSED_HEADS=1): the same values, so the trunk's gradients agree bit for bit
-        c = outs["two_pass_heads"][k]
+        # kernels of their own (DSN_TRAIN_UNFUSED_HEADS=1): the same values, so the trunk's gradients agree bit for bit - with the
+        # heads' two data-gradient products on the exact-fp32 kernel in both (DSN_TRAIN_LIN=fp32: round 6 moved them to the split-fp16
+        # k_t_lin16, which needs the sweeps' operand scales and is not used by the unfused form)
+        c, d = outs["two_pass_heads"][k], outs["lin_fp32"][k]
         if "stage" in k:
-            assert np.array_equal(a, c), k
+            assert np.array_equal(d, c), k
         else:
-            assert np.linalg.norm(a.astype(np.float64) - c) / max(np.linalg.norm(c.astype(np.float64)), 1e-30) < 2e-6, k
+            assert np.linalg.norm(d.astype(np.float64) - c) / max(np.linalg.norm(c.astype(np.float64)), 1e-30) < 2e-6, k
+        # k_t_lin16 against k_t_lin: two roundings of 2^-22 of the operand's batch-wide magnitude per product
+        assert np.linalg.norm(a.astype(np.float64) - d) / max(np.linalg.norm(d.astype(np.float64)), 1e-30) < 2e-6, k

@@ -267,8 +267,10 @@ def test_training_geometry_fused_and_lazy_equals_the_per_lane_walk(monkeypatch):
     monkeypatch.delenv("DSN_NN_UNFUSED")
     for k in fa:
         assert _same(fa[k], fb[k]), k
-    stable = [k for k in ga if torch.equal(ga[k], ga2[k])]
-    assert len(stable) >= 14                                   # (the trunk's matrices: fixed-order reductions)
+    # (the trunk's tensors: fixed-order two-stage reductions - reproducible by construction; an atomically accumulated tensor that
+    #  happens to repeat in two runs says nothing about a third)
+    stable = [k for k in ga if "stage" in k and torch.equal(ga[k], ga2[k])]
+    assert len(stable) >= 12
     for k in stable:
         assert torch.equal(ga[k], gb[k]), k
     for k in ga:
@@ -317,8 +319,8 @@ def test_two_stream_backward_equals_the_one_stream_backward(monkeypatch):
         return g
 
     one, one2, two, two2 = run("0"), run("0"), run("1"), run("1")
-    stable = [k for k in one if torch.equal(one[k], one2[k])]
-    assert len(stable) >= 14
+    stable = [k for k in one if "stage" in k and torch.equal(one[k], one2[k])]      # (fixed-order reductions: the trunk)
+    assert len(stable) >= 12
     for k in one:
         assert torch.isfinite(two[k]).all(), k
         n = one[k].norm().clamp_min(1e-30)
