@@ -371,6 +371,9 @@ void dsn_launch_build_nn(const float4* cent, int F, const DsnNNView& nn, float p
 // are searched by k_warp as before.
 // ---------------------------------------------------------------------------------------------
 #define NNS_THREADS 256
+#ifndef NNS_SURVIVORS
+#define NNS_SURVIVORS 320     // candidates a wave of k_nns_search keeps in LDS after pruning (5 KB per wave, 20 KB per workgroup)
+#endif
 #define NNS_PER 128           // samples of one cell a wave of k_nns_search takes (two per lane)
 
 __device__ __forceinline__ void nns_point(const float* __restrict__ pts, const float* __restrict__ ray_o,
@@ -653,6 +656,85 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
         }
         for (k = NB * nb; k < n; ++k) step(at(ids[k]));
     } else {
+    // Per-wave pruning of the cell's candidate list (round 6).  The list holds every face that can be nearest to SOME point of the cell;
+    // the wave's 128 samples fill a part of it.  With B = the bounding box of
+    // the wave's samples and T = min over the candidates of the squared distance from the candidate to the FARTHEST corner of B (every
+    // sample has a candidate within T), a candidate whose squared distance to the NEAREST point of B exceeds T (1 + 1e-4) is farther
+    // than the winner from every sample of the wave, whatever the float32 rounding of the two distances (relative 4e-7 each): it can
+    // neither win nor tie.  Both bounds are evaluated one candidate per LANE (a sixty-fourth of the per-sample loop's cost per
+    // candidate); the survivors go to LDS in list order, so the per-sample loop below sees the same candidates in the same order minus
+    // those that cannot matter: the same nearest face, bit for bit.  DSN_NN_NO_PRUNE (experiment builds): off.
+    // Measured on the bench frame (profiles/r06_nns_prune.txt): lists of 292 candidates on average, 78 % of them survive (a cell's
+    // consecutive samples are spread over most of the cell - the sampler counts them row segment by row segment, depth by depth):
+    // 0.885 -> 0.83 ms per frame.  With the samples sub-sorted inside their cell (6-bit Morton key through LDS, one workgroup per cell)
+    // 54 % survive and the search takes 0.716 ms - and the sort 0.146: not kept.  More survivors than the wave's LDS holds: drained in rounds.
+    bool pruned = false;
+    int ns = 0;
+#if !defined(DSN_NN_NO_PRUNE)
+    __shared__ __attribute__((aligned(16))) float4 s_surv[NNS_THREADS / 64][NNS_SURVIVORS];
+    float4* const surv = s_surv[threadIdx.x >> 6];
+    if (n >= 96) {                                   // wave-uniform
+        const float INF = INFINITY;
+        float lo[3] = {fminf(valid[0] ? q[0].x : INF, valid[1] ? q[1].x : INF), fminf(valid[0] ? q[0].y : INF, valid[1] ? q[1].y : INF),
+                       fminf(valid[0] ? q[0].z : INF, valid[1] ? q[1].z : INF)};
+        float hi[3] = {fmaxf(valid[0] ? q[0].x : -INF, valid[1] ? q[1].x : -INF), fmaxf(valid[0] ? q[0].y : -INF, valid[1] ? q[1].y : -INF),
+                       fmaxf(valid[0] ? q[0].z : -INF, valid[1] ? q[1].z : -INF)};
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], m));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m));
+            }
+        float t = INF;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            if (k0 + lane < n) {
+                const float4 a = e[k0 + lane];
+                const float fx = fmaxf(fabsf(a.x - lo[0]), fabsf(a.x - hi[0])), fy = fmaxf(fabsf(a.y - lo[1]), fabsf(a.y - hi[1])),
+                            fz = fmaxf(fabsf(a.z - lo[2]), fabsf(a.z - hi[2]));
+                t = fminf(t, fx * fx + fy * fy + fz * fz);
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t = fminf(t, __shfl_xor(t, m));
+        t = t * 1.0001f;
+        if (t < INF) {                               // (wave-uniform; an unbounded box or a non-finite bound: the whole list)
+            pruned = true;
+            // the survivors collected so far, in list order (a list that leaves more than the wave's LDS holds is drained in rounds)
+            auto drain = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                int j = 0;
+                for (; j + 8 <= ns; j += 8) {
+                    float4 a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = surv[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) step(a[u]);
+                }
+                for (; j < ns; ++j) step(surv[j]);
+                __builtin_amdgcn_wave_barrier();
+                ns = 0;
+            };
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                bool keep = false;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + lane < n) {
+                    a = e[k0 + lane];
+                    const float gx = fmaxf(fmaxf(lo[0] - a.x, a.x - hi[0]), 0.0f), gy = fmaxf(fmaxf(lo[1] - a.y, a.y - hi[1]), 0.0f),
+                                gz = fmaxf(fmaxf(lo[2] - a.z, a.z - hi[2]), 0.0f);
+                    keep = !(gx * gx + gy * gy + gz * gz > t);      // (a NaN bound keeps the candidate)
+                }
+                const unsigned long long mk = __ballot(keep);
+                const int add = __popcll(mk);
+                if (ns + add > NNS_SURVIVORS) drain();               // (wave-uniform)
+                if (keep) surv[ns + __popcll(mk & ((1ull << lane) - 1ull))] = a;
+                ns += add;
+            }
+            drain();
+        }
+    }
+    if (!pruned) {
+#endif
     for (; k + 8 <= n; k += 8) {                     // wave-uniform addresses: 128 B of candidates per scalar-load batch
         float4 a[8];
 #pragma unroll
@@ -661,6 +743,9 @@ __global__ void __launch_bounds__(NNS_THREADS) k_nns_search(const int32_t* __res
         for (int j = 0; j < 8; ++j) step(a[j]);
     }
     for (; k < n; ++k) step(e[k]);
+#if !defined(DSN_NN_NO_PRUNE)
+    }
+#endif
     }
     if (!WARP) {
         if (valid[0]) nn[__float_as_int(q[0].w)] = bi[0];
