@@ -2526,7 +2526,10 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     else lin<128, 128, false, EPI_MASK>(w.d_hl2, prm[P_L2_W], w.d_hl1, N64, nullptr, w.hl1, nullptr, st, R2);
     // (the first lighting layer keeps its two passes over d_hl1: a VALU kernel that also accumulates dW0 takes 0.39 ms against
     //  0.107 for the exact-fp32 MFMA product + 0.129 for the data gradient - tried in round 5)
-    T_CHECK(wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2));
+    if (!wgrad_mfma(N64, 32, 9, 128, w.xl, 9, w.d_hl1, 128, grd[P_L0_W], 9, st, grd[P_L0_B], R2)) {
+        if (two) (void)hipStreamSynchronize(sa);      // (a failed launch leaves no chain running on the caller's second stream behind an error)
+        return "wgrad_mfma(lights_encoding.0)";
+    }
     hipLaunchKernelGGL(k_t_light_first_bwd, dim3((unsigned)((N64 + 63) / 64)), dim3(T_THREADS), 0, st, w.d_hl1, prm[P_L0_W], N64,
                        w.d_xl, R2);
 
