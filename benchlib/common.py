@@ -49,8 +49,15 @@ def fail_line(args, rank, world, what, code=3):
     """A run that cannot measure says so in ONE JSON line on stdout (the driver parses the last line of stdout: it finds `error`, no
     value) and exits non-zero - instead of a traceback, or of N ranks waiting for each other until the driver's own clock runs out."""
     _flush_c_stdio()
-    print(json.dumps({"metric": "rendered rays/sec", "value": None, "unit": "rays/s", "n_gpus": world, "steps": getattr(args, "steps", None),
-                      "warmup": getattr(args, "warmup", None), "error": what, "failed_rank": rank}), flush=True)
+    line = json.dumps({"metric": "rendered rays/sec", "value": None, "unit": "rays/s", "n_gpus": world, "steps": getattr(args, "steps", None),
+                       "warmup": getattr(args, "warmup", None), "error": what, "failed_rank": rank})
+    # ONE write() of "\n" + line + "\n" (atomic on a pipe below PIPE_BUF): several ranks fail at the same moment and share the launcher's
+    # stdout - print() wrote the text and its newline separately and two ranks' lines could end up on one (seen once in this container)
+    try:
+        sys.stdout.flush()
+        os.write(1, ("\n" + line + "\n").encode())
+    except OSError:
+        print(line, flush=True)
     _flush_c_stdio()
     os._exit(code)
 
