@@ -10,5 +10,5 @@ q = (f"select s.kernel_name, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start
 rows = list(db.execute(q))
 tot = sum(r[2] for r in rows)
 print(f"{'kernel':58s} {'calls':>5s} {'total_ms':>10s} {'avg_ms':>9s} {'min_ms':>9s} {'max_ms':>9s} {'%':>6s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>6s}")
-for r in rows[:25]:
+for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print(f"{r[0][:58]:58s} {r[1]:5d} {r[2]:10.3f} {r[3]:9.3f} {r[4]:9.3f} {r[5]:9.3f} {100*r[2]/tot:6.1f} {r[6]:5d} {r[7]:5d} {r[8]:5d} {r[9]:6d}")
