@@ -216,12 +216,14 @@ struct GgClassify { const DsnGrid* gf; int32_t* cell_of; int32_t* counts; int32_
 __device__ __forceinline__ void gg_emit(const float* s_near, const float* s_far, const float* __restrict__ ray_o,
                                         const float* __restrict__ ray_d, int R, int S, const float* __restrict__ t_vals,
                                         const float* __restrict__ jitter, float* __restrict__ z_vals, float* __restrict__ pts,
-                                        const GgClassify cls = GgClassify{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                                        const GgClassify cls = GgClassify{nullptr, nullptr, nullptr, nullptr, nullptr},
+                                        int part = 0, int nparts = 1) {
+    // part / nparts (k_sample_gg_emit): this workgroup takes every nparts-th stripe of GG_THREADS samples of the block's rays
     const int tid = threadIdx.x;
     const int rays_here = min(GG_THREADS, R - blockIdx.x * GG_THREADS);
     const int total = rays_here * S;
     const int total_up = cls.gf ? (total + 63) & ~63 : total;      // (classification uses wave-wide ballots: whole waves iterate)
-    for (int e = tid; e < total_up; e += GG_THREADS) {
+    for (int e = part * GG_THREADS + tid; e < total_up; e += GG_THREADS * nparts) {
         // ONE convergent call of the classification per iteration: its run detection uses wave-wide shuffles / ballots, so
         // the tail lanes of a partial wave (e >= total) go through the same call site with valid = false instead of a call of their own
         // under a partial exec mask
@@ -277,7 +279,8 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg(const float* __restric
 
 // Few rays (a training batch, a 3072-ray chunk): the sweep of one block of rays is split over blockIdx.y vertex slices so the
 // launch fills the chip; the slices meet in two int keys per ray kept in the ray's first two z_vals slots (min / max do
-// not depend on the order: bit-identical to the single sweep), and k_sample_gg_finish turns them into near / far / z_vals.
+// not depend on the order: bit-identical to the single sweep), k_sample_gg_bounds turns them into near / far and k_sample_gg_emit
+// those into z_vals.
 __global__ void __launch_bounds__(GG_THREADS) k_sample_gg_init(int R, int S, float* __restrict__ z_vals) {
     const int r = blockIdx.x * GG_THREADS + threadIdx.x;
     if (r < R) {
@@ -301,29 +304,35 @@ __global__ void __launch_bounds__(GG_THREADS) k_sample_gg_slice(const float* __r
     }
 }
 
-__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_finish(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
-                                                                  float* __restrict__ near, float* __restrict__ far, int R, int S,
-                                                                  const float* __restrict__ t_vals,
-                                                                  const float* __restrict__ jitter, float* __restrict__ z_vals,
-                                                                  float* __restrict__ pts, GgClassify cls) {
+// (rounds 1-5: ONE kernel, k_sample_gg_finish, one workgroup per 256 rays for the bounds AND the emission of their 256 S samples - 32
+//  workgroups for a training batch, 128 for an eighth of a frame: 0.117 ms of a mostly idle chip, each workgroup waiting for 64 rounds
+//  of classification atomics.  Now the bounds in a kernel of their own - they replace the keys in near / far, the keys' slots are
+//  z_vals about to be written - and the emission by blockIdx.y parts per block of rays: the same z from the same near / far.)
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_bounds(const float* __restrict__ ray_d, float* __restrict__ near,
+                                                                  float* __restrict__ far, int R, int S, const float* __restrict__ z_vals) {
+    const int r = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (r >= R) return;
+    const int kmin = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S];
+    const int kmax = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S + 1];
+    const bool any = kmin != 0x7fffffff;
+    const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+    const float nrm = dsn_norm3(d);
+    const float zmin = dsn_div(any ? gg_unkey(kmin) : 99999.f, nrm);
+    const float zmax = dsn_div(any ? gg_unkey(kmax) : -99999.f, nrm);
+    if (any && zmin < zmax) { near[r] = zmin; far[r] = zmax; }
+}
+__global__ void __launch_bounds__(GG_THREADS) k_sample_gg_emit(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                const float* __restrict__ near, const float* __restrict__ far, int R, int S,
+                                                                const float* __restrict__ t_vals,
+                                                                const float* __restrict__ jitter, float* __restrict__ z_vals,
+                                                                float* __restrict__ pts, GgClassify cls) {
     __shared__ float s_near[GG_THREADS], s_far[GG_THREADS];
     const int tid = threadIdx.x;
     const int r = blockIdx.x * GG_THREADS + tid;
-    float n_ = 0.f, f_ = 0.f;
-    if (r < R) {
-        const int kmin = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S];
-        const int kmax = reinterpret_cast<const int*>(z_vals)[(int64_t)r * S + 1];
-        const bool any = kmin != 0x7fffffff;
-        const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
-        const float nrm = dsn_norm3(d);
-        const float zmin = dsn_div(any ? gg_unkey(kmin) : 99999.f, nrm);
-        const float zmax = dsn_div(any ? gg_unkey(kmax) : -99999.f, nrm);
-        n_ = near[r]; f_ = far[r];
-        if (any && zmin < zmax) { n_ = zmin; f_ = zmax; near[r] = n_; far[r] = f_; }
-    }
-    s_near[tid] = n_; s_far[tid] = f_;
-    __syncthreads();       // every key of the block has been read before the first z_vals store below
-    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts, cls);
+    s_near[tid] = r < R ? near[r] : 0.f;
+    s_far[tid] = r < R ? far[r] : 0.f;
+    __syncthreads();
+    gg_emit(s_near, s_far, ray_o, ray_d, R, S, t_vals, jitter, z_vals, pts, cls, (int)blockIdx.y, (int)gridDim.y);
 }
 
 void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const float* ray_d, float* near, float* far,
@@ -340,8 +349,12 @@ void dsn_launch_sample_gg(const float* xyz, int V, const float* ray_o, const flo
         hipLaunchKernelGGL(k_sample_gg_init, dim3(blocks), dim3(GG_THREADS), 0, st, R, S, z_vals);
         hipLaunchKernelGGL(k_sample_gg_slice, dim3(blocks, slices), dim3(GG_THREADS), 0, st, xyz, V, slice, ray_o, ray_d, R, S,
                            z_vals);
-        hipLaunchKernelGGL(k_sample_gg_finish, dim3(blocks), dim3(GG_THREADS), 0, st, ray_o, ray_d, near, far, R, S, t_vals,
-                           jitter, z_vals, pts, cls);
+        hipLaunchKernelGGL(k_sample_gg_bounds, dim3(blocks), dim3(GG_THREADS), 0, st, ray_d, near, far, R, S, (const float*)z_vals);
+        int parts = 2048 / blocks;                             // ~8 workgroups per CU for the emission
+        if (parts > S) parts = S;                              // (a block of rays has S stripes of GG_THREADS samples)
+        if (parts < 1) parts = 1;
+        hipLaunchKernelGGL(k_sample_gg_emit, dim3(blocks, parts), dim3(GG_THREADS), 0, st, ray_o, ray_d, (const float*)near, (const float*)far, R, S,
+                           t_vals, jitter, z_vals, pts, cls);
         return;
     }
     hipLaunchKernelGGL(k_sample_gg, dim3(blocks), dim3(GG_THREADS), 0, st, xyz, V, ray_o,

@@ -43,6 +43,7 @@ for step in "$@"; do
     bench) n=$(echo "bench$arg" | tr -c 'a-zA-Z0-9\n' '_'); timeout 1200 python bench.py $args > ${O}_$n.log 2> ${O}_$n.err; tail -1 ${O}_$n.log > ${O}_$n.json; summ ${O}_$n.json || tail -5 ${O}_$n.err;;
     train) for w in default w4; do timeout 400 python bench.py --train --weights $w --steps 30 --warmup 5 $args 2>/dev/null | tail -1 > ${O}_train_$w.json; summ ${O}_train_$w.json; done;;
     trace) rm -rf gpurun_out/prof_$TAG; rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o r -- $B --no-roofline $args > ${O}_trace.log 2>&1
+           python scripts/rocpd_sequence.py gpurun_out/prof_$TAG/r_results.db k_pose_setup > ${O}_frame_sequence.txt; python scripts/rocpd_period.py gpurun_out/prof_$TAG/r_results.db k_pose_setup > ${O}_frame_period.txt
            python scripts/rocpd_summary.py gpurun_out/prof_$TAG/r_results.db > ${O}_kernel_trace$(echo "$arg" | tr -c 'a-zA-Z0-9\n' '_').txt; cut -c1-160 ${O}_kernel_trace$(echo "$arg" | tr -c 'a-zA-Z0-9\n' '_').txt | head -${TRACE_LINES:-24}; rm -rf gpurun_out/prof_$TAG;;
     pmc) D=gpurun_out/pmc_$TAG; rm -rf $D; C="$B --no-roofline $args"
          pmcpass $D fetch "$C" FETCH_SIZE; pmcpass $D write "$C" WRITE_SIZE; pmcpass $D tcc "$C" TCC_HIT TCC_MISS TCC_REQ
