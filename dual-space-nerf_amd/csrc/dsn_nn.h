@@ -57,6 +57,8 @@ struct DsnGridView {        // one level
     void* list;             // [cap] entries: float4 {x,y,z,index bits} (fine level) or int32 index (coarse level)
     int32_t* super_cnt;     // [maxcell] (fine level only, else NULL): size of each super-cell's superset (> CAP: unusable)
     float4* super_list;     // [maxsuper][DSN_SUPER_CAP] supersets, ascending face order
+    unsigned long long* member;   // [maxcell][DSN_SUPER_CAP / 64] (fine level only): which entries of its super-cell's superset a cell's list
+                                  // holds, one bit per entry - k_grid_count leaves them for k_grid_fill (no third sweep of the superset)
 };
 __host__ __device__ inline int dsn_grid_maxsuper(int maxcell) { return maxcell / 32; }   // grids with more super-cells (very thin ones) build unaccelerated
 struct DsnNNView { DsnGridView fine, coarse; };
@@ -66,7 +68,8 @@ __host__ __device__ inline size_t dsn_grid_bytes(int maxcell, int cap, int entry
                dsn_align256(sizeof(float) * (size_t)maxcell) + dsn_align256((size_t)entry_bytes * (size_t)cap);
     if (entry_bytes == 16)
         b += dsn_align256(sizeof(int32_t) * (size_t)maxcell) +
-             dsn_align256(sizeof(float) * 4 * (size_t)dsn_grid_maxsuper(maxcell) * DSN_SUPER_CAP);
+             dsn_align256(sizeof(float) * 4 * (size_t)dsn_grid_maxsuper(maxcell) * DSN_SUPER_CAP) +
+             dsn_align256(8 * (size_t)(DSN_SUPER_CAP / 64) * (size_t)maxcell);
     return b;
 }
 __host__ __device__ inline DsnGridView dsn_grid_view(char*& p, int maxcell, int cap, int entry_bytes) {
@@ -77,9 +80,11 @@ __host__ __device__ inline DsnGridView dsn_grid_view(char*& p, int maxcell, int 
     v.list = (void*)p;          p += dsn_align256((size_t)entry_bytes * (size_t)cap);
     v.super_cnt = nullptr;
     v.super_list = nullptr;
+    v.member = nullptr;
     if (entry_bytes == 16) {
         v.super_cnt = (int32_t*)p;  p += dsn_align256(sizeof(int32_t) * (size_t)maxcell);
         v.super_list = (float4*)p;  p += dsn_align256(sizeof(float) * 4 * (size_t)dsn_grid_maxsuper(maxcell) * DSN_SUPER_CAP);
+        v.member = (unsigned long long*)p;  p += dsn_align256(8 * (size_t)(DSN_SUPER_CAP / 64) * (size_t)maxcell);
     }
     return v;
 }

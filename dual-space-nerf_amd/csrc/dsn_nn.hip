@@ -108,10 +108,17 @@ __global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ c
     dsn_cell_box(g, (x0 * g.ny + y0) * g.nz + z0, blo, t1);
     dsn_cell_box(g, (x1 * g.ny + y1) * g.nz + z1, t0, bhi);
     __shared__ float s_m[256];
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[4][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int SUP_U = 4;                          // rounds of 256 centroids requested together (latency-bound sweeps: see k_grid_count)
     float m = INFINITY;
-    for (int f = t; f < F; f += 256) m = fminf(m, dsn_box_dmax2(cent[f], blo, bhi));
+    for (int f0 = 0; f0 < F; f0 += 256 * SUP_U) {
+        float4 c[SUP_U];
+#pragma unroll
+        for (int u = 0; u < SUP_U; ++u) { const int f = f0 + 256 * u + t; c[u] = cent[f < F ? f : 0]; }
+#pragma unroll
+        for (int u = 0; u < SUP_U; ++u) if (f0 + 256 * u + t < F) m = fminf(m, dsn_box_dmax2(c[u], blo, bhi));
+    }
     s_m[t] = m;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
@@ -121,18 +128,27 @@ __global__ void __launch_bounds__(256) k_grid_super(const float4* __restrict__ c
     m = s_m[0];
     int base = 0;
     float4* out = super_list + (size_t)sb * DSN_SUPER_CAP;
-    for (int f0 = 0; f0 < F; f0 += 256) {
-        const int f = f0 + t;
-        const float4 c = cent[f < F ? f : 0];
-        const bool in = f < F && dsn_in_list(dsn_box_dmin2(c, blo, bhi), m);
-        const unsigned long long mask = __ballot(in);
+    for (int f0 = 0; f0 < F; f0 += 256 * SUP_U) {    // (one barrier pair per SUP_U rounds; the entries land in ascending face order as before)
+        float4 c[SUP_U];
+        bool in[SUP_U];
+        unsigned long long mask[SUP_U];
+#pragma unroll
+        for (int u = 0; u < SUP_U; ++u) { const int f = f0 + 256 * u + t; c[u] = cent[f < F ? f : 0]; }
         __syncthreads();
-        if (lane == 0) s_cnt[wave] = __popcll(mask);
+#pragma unroll
+        for (int u = 0; u < SUP_U; ++u) {
+            in[u] = f0 + 256 * u + t < F && dsn_in_list(dsn_box_dmin2(c[u], blo, bhi), m);
+            mask[u] = __ballot(in[u]);
+            if (lane == 0) s_cnt[u][wave] = __popcll(mask[u]);
+        }
         __syncthreads();
-        int at = base + __popcll(mask & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) at += s_cnt[w];
-        if (in && at < DSN_SUPER_CAP) out[at] = c;
-        base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+        for (int u = 0; u < SUP_U; ++u) {
+            int at = base + __popcll(mask[u] & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) at += s_cnt[u][w];
+            if (in[u] && at < DSN_SUPER_CAP) out[at] = c[u];
+            base += s_cnt[u][0] + s_cnt[u][1] + s_cnt[u][2] + s_cnt[u][3];
+        }
     }
     if (t == 0) super_cnt[sb] = base;
 }
@@ -151,11 +167,17 @@ __device__ __forceinline__ const float4* dsn_cell_source(const DsnGrid& g, int c
     return super_list + (size_t)sb * DSN_SUPER_CAP;
 }
 
+#ifndef DSN_GRID_U
+#define DSN_GRID_U 4
+#endif
 // pass 1+2: U(B)^2 and the list length of every cell (one wavefront per cell)
 __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                      float* __restrict__ u2, int32_t* __restrict__ offsets, int maxsuper,
                                                      const int32_t* __restrict__ super_cnt, const float4* __restrict__ super_list,
-                                                     const int32_t* __restrict__ visited, int lazy_build) {
+                                                     const int32_t* __restrict__ visited, int lazy_build,
+                                                     unsigned long long* __restrict__ member) {
+    // member (optional): the membership bits of the second sweep, 64 entries of the superset per word - k_grid_fill places the entries
+    // from them instead of sweeping the superset a third time (cells that sweep the whole table have no words: they are swept again)
     const DsnGrid g = *gp;
     if (lazy_build && !g.lazy) return;
     const int lane = threadIdx.x & 63;
@@ -169,15 +191,33 @@ __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ c
     dsn_cell_box(g, cell, blo, bhi);
     int F;
     const float4* __restrict__ cent = dsn_cell_source(g, cell, cent_all, F_all, maxsuper, super_cnt, super_list, F);
+    // The sweeps are bound by the latency of their loads (one wave per cell, ~31 rounds of 64 entries from L2), not by their arithmetic:
+    // GRID_U rounds' entries are requested together (session 4 of round 6: 0.138 -> see profiles; rounds 1-5 waited for every round).
+    constexpr int GRID_U = DSN_GRID_U;
     float m = INFINITY;
-    for (int f = lane; f < F; f += 64) m = fminf(m, dsn_box_dmax2(cent[f], blo, bhi));
+    for (int f0 = 0; f0 < F; f0 += 64 * GRID_U) {
+        float4 c[GRID_U];
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) { const int f = f0 + 64 * u + lane; c[u] = cent[f < F ? f : 0]; }
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) if (f0 + 64 * u + lane < F) m = fminf(m, dsn_box_dmax2(c[u], blo, bhi));
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fminf(m, __shfl_xor(m, o));
     int cnt = 0;
-    for (int f0 = 0; f0 < F; f0 += 64) {
-        const int f = f0 + lane;
-        const bool in = f < F && dsn_in_list(dsn_box_dmin2(cent[f < F ? f : 0], blo, bhi), m);
-        cnt += __popcll(__ballot(in));
+    unsigned long long* __restrict__ mw = (member && cent != cent_all) ? member + (size_t)cell * (DSN_SUPER_CAP / 64) : nullptr;
+    for (int f0 = 0; f0 < F; f0 += 64 * GRID_U) {
+        float4 c[GRID_U];
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) { const int f = f0 + 64 * u + lane; c[u] = cent[f < F ? f : 0]; }
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) {
+            const int fb = f0 + 64 * u;                  // (wave-uniform)
+            const bool in = fb + lane < F && dsn_in_list(dsn_box_dmin2(c[u], blo, bhi), m);
+            const unsigned long long mk = __ballot(in);
+            cnt += __popcll(mk);
+            if (mw && lane == 0 && fb < F) mw[fb >> 6] = mk;
+        }
     }
     if (lane == 0) { u2[cell] = m; offsets[cell + 1] = cnt; }
 }
@@ -252,33 +292,83 @@ template <bool INLINE>
 __global__ void __launch_bounds__(256) k_grid_fill(const float4* __restrict__ cent_all, int F_all, const DsnGrid* __restrict__ gp,
                                                     const float* __restrict__ u2, const int32_t* __restrict__ offsets,
                                                     void* __restrict__ list, int maxsuper, const int32_t* __restrict__ super_cnt,
-                                                    const float4* __restrict__ super_list, const int32_t* __restrict__ visited, int lazy_build) {
+                                                    const float4* __restrict__ super_list, const int32_t* __restrict__ visited, int lazy_build,
+                                                    const unsigned long long* __restrict__ member) {
     const DsnGrid g = *gp;
     if (lazy_build ? g.lazy != (lazy_build == 2 ? 3 : 2) : !g.ok) return;
     const int lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= g.ncell) return;
     if (visited && visited[cell] <= 0) return;
-    float blo[3], bhi[3];
-    dsn_cell_box(g, cell, blo, bhi);
     int F;
     const float4* __restrict__ cent = dsn_cell_source(g, cell, cent_all, F_all, maxsuper, super_cnt, super_list, F);
-    const float m = u2[cell];
     int base = offsets[cell];
-    for (int f0 = 0; f0 < F; f0 += 64) {
-        const int f = f0 + lane;
-        const float4 c = cent[f < F ? f : 0];   // .w already holds the face index bits
-        const bool in = f < F && dsn_in_list(dsn_box_dmin2(c, blo, bhi), m);
-        const unsigned long long mask = __ballot(in);
-        if (in) {
-            const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (INLINE) reinterpret_cast<float4*>(list)[at] = c;
-            else reinterpret_cast<int32_t*>(list)[at] = __float_as_int(c.w);
+    if (member && cent != cent_all) {
+        // the membership words k_grid_count left (round 6): lane j holds word j (F <= DSN_SUPER_CAP = 64 words) and the number of members in
+        // front of it; only words with members are visited, and only to move their entries - the same entries at the same places
+        static_assert(DSN_SUPER_CAP / 64 <= 64, "one membership word per lane");
+        const int nw = (F + 63) >> 6;
+        const unsigned long long mine = lane < nw ? member[(size_t)cell * (DSN_SUPER_CAP / 64) + lane] : 0ull;
+        const int pc = __popcll(mine);
+        int inc = pc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+        const int front = inc - pc;
+        unsigned long long todo = __ballot(pc > 0);
+        constexpr int FILL_U = 4;                    // words in flight (the loop is bound by the latency of its gathers)
+        while (todo) {                               // (wave-uniform)
+            int j[FILL_U];
+            unsigned long long mk[FILL_U];
+            float4 c[FILL_U];
+#pragma unroll
+            for (int u = 0; u < FILL_U; ++u) {
+                j[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+                todo &= todo - 1;                    // (0 stays 0)
+                mk[u] = j[u] >= 0 ? __shfl(mine, j[u]) : 0ull;
+                c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((mk[u] >> lane) & 1ull) c[u] = cent[(j[u] << 6) + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_U; ++u) {
+                if (j[u] < 0) continue;              // (wave-uniform)
+                const int b0 = base + __shfl(front, j[u]);
+                if ((mk[u] >> lane) & 1ull) {
+                    const int at = b0 + __popcll(mk[u] & ((1ull << lane) - 1ull));
+                    if (INLINE) reinterpret_cast<float4*>(list)[at] = c[u];
+                    else reinterpret_cast<int32_t*>(list)[at] = __float_as_int(c[u].w);
+                }
+            }
         }
-        base += __popcll(mask);
+        return;
+    }
+    float blo[3], bhi[3];
+    dsn_cell_box(g, cell, blo, bhi);
+    const float m = u2[cell];
+    constexpr int GRID_U = DSN_GRID_U;                // (rounds of 64 entries requested together: see k_grid_count)
+    for (int f0 = 0; f0 < F; f0 += 64 * GRID_U) {
+        float4 c[GRID_U];
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) { const int f = f0 + 64 * u + lane; c[u] = cent[f < F ? f : 0]; }   // .w already holds the face index bits
+#pragma unroll
+        for (int u = 0; u < GRID_U; ++u) {
+            const bool in = f0 + 64 * u + lane < F && dsn_in_list(dsn_box_dmin2(c[u], blo, bhi), m);
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (INLINE) reinterpret_cast<float4*>(list)[at] = c[u];
+                else reinterpret_cast<int32_t*>(list)[at] = __float_as_int(c[u].w);
+            }
+            base += __popcll(mask);
+        }
     }
 }
 
+// the membership words between k_grid_count and k_grid_fill: only where the cells sweep supersets (DSN_NN_NO_MEMBER=1: cross-check
+// switch - k_grid_fill sweeps again, as rounds 1-5)
+static unsigned long long* dsn_member_words(const DsnGridView& vv) {
+    const bool off = getenv("DSN_NN_NO_MEMBER") != nullptr;
+    return (vv.super_cnt && !off) ? vv.member : nullptr;
+}
 static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, float pad, int target, int maxcell, int cap,
                             bool inline_entries, hipStream_t st, bool params_only = false) {
     const int maxsuper = dsn_grid_maxsuper(maxcell);
@@ -290,14 +380,14 @@ static void dsn_build_level(const float4* cent, int F, const DsnGridView& v, flo
     if (vv.super_cnt)
         hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none, 0);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0, dsn_member_words(vv));
     dsn_launch_grid_scan(v, maxcell, 0, st);
     if (inline_entries)
         hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0, (const unsigned long long*)dsn_member_words(vv));
     else
         hipLaunchKernelGGL(k_grid_fill<false>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0);
+                           maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 0, (const unsigned long long*)dsn_member_words(vv));
 }
 
 // The lists of a LAZY fine level (DsnGrid::lazy = 1 after dsn_set_frame_ex with DSN_FRAME_LAZY_LISTS), for the cells the frame's samples
@@ -314,10 +404,10 @@ void dsn_launch_build_nn_visited(const float4* cent, int F, const DsnNNView& nn,
     if (vv.super_cnt)
         hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, visited, 1);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1, dsn_member_words(vv));
     dsn_launch_grid_scan(v, maxcell, 1, st);
     hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1);
+                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, visited, 1, (const unsigned long long*)dsn_member_words(vv));
 }
 
 // A lazily set level completed for EVERY cell (a lazily set frame rendered outside the fused cell-major path: small ray batches,
@@ -336,10 +426,10 @@ void dsn_launch_build_nn_complete(const float4* cent, int F, const DsnNNView& nn
     if (vv.super_cnt)
         hipLaunchKernelGGL(k_grid_super, dim3(maxsuper), dim3(256), 0, st, cent, F, v.g, maxsuper, vv.super_cnt, vv.super_list, none, 2);
     hipLaunchKernelGGL(k_grid_count, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, maxsuper,
-                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2);
+                       (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2, dsn_member_words(vv));
     dsn_launch_grid_scan(v, maxcell, 2, st);
     hipLaunchKernelGGL(k_grid_fill<true>, dim3((maxcell + 3) / 4), dim3(256), 0, st, cent, F, v.g, v.u2, v.offsets, v.list,
-                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2);
+                       maxsuper, (const int32_t*)vv.super_cnt, (const float4*)vv.super_list, none, 2, (const unsigned long long*)dsn_member_words(vv));
     hipLaunchKernelGGL(k_grid_complete, dim3(1), dim3(1), 0, st, v.g);
 }
 

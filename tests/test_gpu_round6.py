@@ -330,3 +330,55 @@ def test_two_stream_backward_equals_the_one_stream_backward(monkeypatch):
             assert torch.equal(one[k], two[k]) and torch.equal(two[k], two2[k]), k
         else:
             assert d <= 4.0 * spread + 1e-7, (k, d, spread)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# session 4: the list build's fill pass places the entries from the membership words the count pass leaves
+# ------------------------------------------------------------------------------------------------------------------------
+def _fine_level_lists(scene):
+    """(offsets, the list's entries as raw int32 [total, 4]) of the posed mesh's fine level, read out of the scene blob"""
+    a256 = lambda x: (x + 255) & ~255
+    off = scene._nn_off[0]
+    hdr = scene.buf[off:off + 64].cpu()
+    ncell, ok, total, cap = [int(x) for x in hdr[32:48].view(torch.int32)]
+    lazy = int(hdr[52:56].view(torch.int32))
+    o_offs = off + 256
+    o_list = o_offs + a256(4 * (65536 + 1)) + a256(4 * 65536)
+    offs = scene.buf[o_offs:o_offs + 4 * (ncell + 1)].view(torch.int32).cpu()
+    ent = scene.buf[o_list:o_list + 16 * total].view(torch.int32).reshape(total, 4).cpu()
+    return ncell, ok, lazy, total, offs, ent
+
+
+def test_list_fill_from_membership_words_equals_the_third_sweep(monkeypatch):
+    """k_grid_count leaves one bit per superset entry, k_grid_fill moves the entries those bits name: offsets and lists entry for entry
+    as with the fill pass that sweeps the superset again (DSN_NN_NO_MEMBER=1, rounds 1-5) - for the build of every cell (set_frame) and
+    for the lazy build of the cells a frame's samples visit (render on a lazily set frame)"""
+    from dsnerf_amd import _lib
+    canon, faces, batch = full_frame(hw=256)
+    r = renderer_with(state("x_w4"), canon, faces, density_screen=False)
+    r.eval()
+    S = 64
+    o, d, n0, f0 = _frame_inputs(r, batch)
+    pk = r.net.packed(r.device)
+    xyz, poses = r._dev(batch["xyz"][0]), r._dev(batch["poses"][0])
+
+    def lists(lazy):
+        r.scene.set_frame(pk, xyz, poses, 5, False, None, None, None, fine_only=True, lazy=lazy)
+        out = None
+        if lazy:
+            out = _lib.render_rays(r.scene, pk, _lib.RenderWorkspace(r.device), o, d, n0.clone(), f0.clone(), S, r._t_vals(S))
+        torch.cuda.synchronize()
+        return _fine_level_lists(r.scene), out
+
+    for lazy in (False, True):
+        (nc_a, ok_a, lz_a, tot_a, offs_a, ent_a), out_a = lists(lazy)
+        monkeypatch.setenv("DSN_NN_NO_MEMBER", "1")
+        (nc_b, ok_b, lz_b, tot_b, offs_b, ent_b), out_b = lists(lazy)
+        monkeypatch.delenv("DSN_NN_NO_MEMBER")
+        assert (nc_a, ok_a, lz_a, tot_a) == (nc_b, ok_b, lz_b, tot_b) and tot_a > 100000, (lazy, nc_a, ok_a, lz_a, tot_a, tot_b)
+        assert (ok_a == 1) if not lazy else (lz_a == 2)
+        assert torch.equal(offs_a, offs_b), lazy
+        assert torch.equal(ent_a, ent_b), lazy
+        if lazy:
+            for k in out_a:
+                assert _same(out_a[k], out_b[k]), k
