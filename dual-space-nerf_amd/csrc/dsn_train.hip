@@ -433,9 +433,19 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __
     const int64_t NL = rows_n(rw, N);
     const int64_t n0 = (int64_t)blockIdx.x * 64;
     if (n0 >= NL) return;          // block-uniform
-    for (int e = threadIdx.x; e < 64 * 128; e += T_THREADS) {
-        const int r = e >> 7, k = e & 127;
-        tile[r][k] = (n0 + r < NL) ? d_hl1[rows_at(rw, n0 + r) * 128 + k] : 0.0f;
+    {
+        // a wave moves half a row per load: the row is wave-uniform (scalar row numbers, rows_at_u), and the 32 loads of a thread do not
+        // wait for each other (session 4 of round 6: the element loop fetched every row number with a vector load in front of the value)
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k = ((wv & 1) << 6) + (threadIdx.x & 63);
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int r = 2 * i + (wv >> 1);
+            const int64_t q = n0 + r < NL ? n0 + r : NL - 1;
+            v[i] = d_hl1[rows_at_u(rw, q) * 128 + k];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int r = 2 * i + (wv >> 1); tile[r][k] = n0 + r < NL ? v[i] : 0.0f; }
     }
     __syncthreads();
     const int sm = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
