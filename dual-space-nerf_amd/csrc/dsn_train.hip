@@ -1451,16 +1451,16 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce(const float* __restrict_
     const int o = blockIdx.x * 64 + lane;            // float4 piece of the tile
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = part + (size_t)o * 4;
+    // (the tiles are added in the same fixed order as ever; RED_U of them are requested together - the loop is bound by the latency of
+    //  its loads, and the four bias blocks' second loop, one load at a time until session 4 of round 6, was the whole kernel's tail)
+    constexpr int RED_U = 8;
     int g = q;
-    for (; g + 12 < active; g += 16) {
-        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * W16_PART(C));
-        const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(g + 4) * W16_PART(C));
-        const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(g + 8) * W16_PART(C));
-        const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(g + 12) * W16_PART(C));
-        acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
-        acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
-        acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
-        acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+    for (; g + 4 * (RED_U - 1) < active; g += 4 * RED_U) {
+        float4 a[RED_U];
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) a[u] = *reinterpret_cast<const float4*>(src + (size_t)(g + 4 * u) * W16_PART(C));
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) { acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w; }
     }
     for (; g < active; g += 4) {
         const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * W16_PART(C));
@@ -1471,7 +1471,15 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce(const float* __restrict_
     const bool bias_block = dbias && blockIdx.x < 4;             // workgroup-uniform
     if (bias_block) {
         const float* bsrc = part + 256 * C + blockIdx.x * 64 + lane;
-        for (int gg = q; gg < active; gg += 4) bs += bsrc[(size_t)gg * W16_PART(C)];
+        int gg = q;
+        for (; gg + 4 * (RED_U - 1) < active; gg += 4 * RED_U) {
+            float b[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) b[u] = bsrc[(size_t)(gg + 4 * u) * W16_PART(C)];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) bs += b[u];
+        }
+        for (; gg < active; gg += 4) bs += bsrc[(size_t)gg * W16_PART(C)];
         s_b[q][lane] = bs;
     }
     __syncthreads();
@@ -1925,7 +1933,16 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce_q(const float* __restric
     const int active = (int)((NL + rows - 1) / rows);
     const float* src = part + ((size_t)blockIdx.x * 64 + lane) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g = q; g < active; g += 4) {
+    constexpr int RED_U = 8;                                     // (tiles requested together, added in the old order: see k_t_wgrad_reduce)
+    int g = q;
+    for (; g + 4 * (RED_U - 1) < active; g += 4 * RED_U) {
+        float4 a[RED_U];
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) a[u] = *reinterpret_cast<const float4*>(src + (size_t)(g + 4 * u) * PART);
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) { acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w; }
+    }
+    for (; g < active; g += 4) {
         const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)g * PART);
         acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
     }
@@ -1934,7 +1951,15 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce_q(const float* __restric
     if (bias_block) {
         float bs = 0.0f;
         const float* bsrc = part + YW * XW + blockIdx.x * 64 + lane;
-        for (int gg = q; gg < active; gg += 4) bs += bsrc[(size_t)gg * PART] + bsrc[(size_t)gg * PART + 128];
+        int gg = q;
+        for (; gg + 4 * (RED_U - 1) < active; gg += 4 * RED_U) {
+            float b0[RED_U], b1[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) { b0[u] = bsrc[(size_t)(gg + 4 * u) * PART]; b1[u] = bsrc[(size_t)(gg + 4 * u) * PART + 128]; }
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) bs += b0[u] + b1[u];
+        }
+        for (; gg < active; gg += 4) bs += bsrc[(size_t)gg * PART] + bsrc[(size_t)gg * PART + 128];
         s_b[q][lane] = bs;
     }
     __syncthreads();
