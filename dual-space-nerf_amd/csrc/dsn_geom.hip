@@ -126,7 +126,7 @@ __device__ __forceinline__ float gg_unkey(int k) { return __int_as_float(k ^ ((k
 __device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_begin, int v_end, const float* __restrict__ ray_o,
                                          const float* __restrict__ ray_d, int R, float& zmin, float& zmax, bool& any,
                                          float& nrm) {
-    __shared__ float4 sv[GG_TILE];
+    __shared__ float4 sv2[2][GG_TILE];      // two tiles: the next one is fetched while this one is swept (one barrier per tile)
     const float gamma2 = (float)(0.05 * 0.05);
     const int tid = threadIdx.x;
     const int r = blockIdx.x * GG_THREADS + tid;
@@ -167,14 +167,35 @@ __device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_be
         sin_t = sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
     }
     const float keep_r = 0.05f * 1.10f + 1e-4f;
-    for (int base = v_begin; base < v_end; base += GG_TILE) {
-        int n = min(GG_TILE, v_end - base);
-        __syncthreads();
-        for (int j = tid; j < n; j += GG_THREADS) {
-            float dx = xyz[3 * (base + j)] - o0x, dy = xyz[3 * (base + j) + 1] - o0y, dz = xyz[3 * (base + j) + 2] - o0z;
-            sv[j] = make_float4(dx, dy, dz, dsn_sum3(dx * dx, dy * dy, dz * dz));
+    static_assert(GG_TILE == 2 * GG_THREADS, "two vertices per thread and tile");
+    auto tile_fetch = [&](int base, float (&c)[2][3]) {           // (requests only: the values are used after the current tile's sweep)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = base + tid + u * GG_THREADS;
+            const int jj = j < v_end ? j : v_end - 1;
+            c[u][0] = xyz[3 * jj]; c[u][1] = xyz[3 * jj + 1]; c[u][2] = xyz[3 * jj + 2];
         }
-        __syncthreads();
+    };
+    auto tile_store = [&](float4* dst, const float (&c)[2][3]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float dx = c[u][0] - o0x, dy = c[u][1] - o0y, dz = c[u][2] - o0z;
+            dst[tid + u * GG_THREADS] = make_float4(dx, dy, dz, dsn_sum3(dx * dx, dy * dy, dz * dz));
+        }
+    };
+    if (v_begin < v_end) {
+        float c0[2][3];
+        tile_fetch(v_begin, c0);
+        tile_store(sv2[0], c0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int base = v_begin; base < v_end; base += GG_TILE, buf ^= 1) {
+        int n = min(GG_TILE, v_end - base);
+        const float4* __restrict__ sv = sv2[buf];
+        const bool more = base + GG_TILE < v_end;                 // (block-uniform)
+        float cn[2][3];
+        if (more) tile_fetch(base + GG_TILE, cn);
         int kept = 0;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
@@ -205,6 +226,8 @@ __device__ __forceinline__ void gg_sweep(const float* __restrict__ xyz, int v_be
                 any = true;
             }
         }
+        if (more) tile_store(sv2[buf ^ 1], cn);                   // (the other buffer was last read before the previous barrier)
+        __syncthreads();
     }
 }
 
