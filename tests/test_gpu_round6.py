@@ -329,7 +329,9 @@ def test_two_stream_backward_equals_the_one_stream_backward(monkeypatch):
         if k in stable:
             assert torch.equal(one[k], two[k]) and torch.equal(two[k], two2[k]), k
         else:
-            assert d <= 4.0 * spread + 1e-7, (k, d, spread)
+            # (5e-6: the soak's bound for atomically summed tensors, profiles/r06_soak.txt - a one-element tensor's two-run spread can be
+            #  1e-7 by chance while the next pair differs by 8e-7: seen once; a kernel on the wrong stream moves these by 1e-2)
+            assert d <= 4.0 * spread + 5e-6, (k, d, spread)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
