@@ -41,7 +41,7 @@ EXPORTS = [
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
     "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_render_workspace_bytes_for",
     "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_early_stop_colour_headroom", "dsn_render_rays_ex",
-    "dsn_render_rays_grad_ex", "dsn_aux_create", "dsn_aux_destroy",
+    "dsn_render_rays_grad_ex", "dsn_render_rays_train_ex", "dsn_aux_create", "dsn_aux_destroy",
 ]
 
 SKIP_TRANSPARENT = 1
@@ -91,8 +91,8 @@ def lib():
                   "dsn_grad_workspace_bytes", "dsn_image_workspace_bytes", "dsn_pose_state_bytes",
                   "dsn_calibrate_workspace_bytes"):
             getattr(L, n).restype = C.c_size_t
-        if L.dsn_abi_version() != 7:
-            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 7 - rebuild it "
+        if L.dsn_abi_version() != 8:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dsn_abi_version()}, this binding needs 8 - rebuild it "
                                "(python dual-space-nerf_amd/build.py)")
         _lib = L
     return _lib
@@ -711,11 +711,15 @@ def render_rays(scene: Scene, packed: PackedParams, ws: RenderWorkspace, ray_o, 
     if train_cache is not None:      # training forward: dense, and everything its backward needs stays in train_cache
         flags &= ~SKIP_TRANSPARENT
         gbuf = train_cache.get(R, S)
-        _check(lib().dsn_render_rays_train(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
-                                           _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
-                                           _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
-                                           _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
-                                           _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _ptr(gbuf), _stream()),
+        # (ABI 8: the far canonical search beside the field kernel on the backward's auxiliary stream; DSN_TRAIN_FWD_AUX=0: A/B switch -
+        #  the forward on one stream, the backward's chains still on two)
+        ax = train_cache.aux() if os.environ.get("DSN_TRAIN_FWD_AUX", "1") != "0" else (None, None, None)
+        _check(lib().dsn_render_rays_train_ex(_ptr(scene.buf), scene.V, scene.F, _ptr(packed.buf), _ptr(ray_o, torch.float32),
+                                              _ptr(ray_d, torch.float32), _ptr(near, torch.float32), _ptr(far, torch.float32), R, S,
+                                              _ptr(t_vals, torch.float32), _ptr(jitter), _ptr(noise), flags, _ptr(out["color"]),
+                                              _ptr(out["disp_map"]), _ptr(out["acc_map"]), _ptr(out["depth_map"]),
+                                              _ptr(out.get("weights")), _ptr(out["z_vals"]), _ptr(buf), _ptr(gbuf), _stream(),
+                                              ax[0], ax[1], ax[2]),
                "dsn_render_rays_train")
         return out
     # stop_schedule (early_stop only): slice lengths chosen from a probe frame's statistics (choose_stop_schedule); None = uniform slices

@@ -833,16 +833,19 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     return dsn_check_launch("dsn_render_rays");
 }
 
-int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+int dsn_render_rays_train_ex(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
                           float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
                           float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
-                          void* workspace, void* grad_workspace, void* stream) {
+                          void* workspace, void* grad_workspace, void* stream, void* aux_stream, void* ev_fork, void* ev_join) {
     DSN_REQUIRE(R > 0 && S > 0, "dsn_render_rays_train: empty ray batch");
     DSN_REQUIRE(scene && packed && ray_o && ray_d && near && far && t_vals && workspace && grad_workspace,
                 "dsn_render_rays_train: null argument");
     DSN_REQUIRE(out_rgb && out_disp && out_acc && out_depth, "dsn_render_rays_train: null output");
     DSN_REQUIRE(V > 0 && F > 0, "dsn_render_rays_train: bad V/F");
     DSN_REQUIRE(!(flags & (DSN_SKIP_TRANSPARENT | DSN_FIELD_FP32)), "dsn_render_rays_train: dense split-fp16 evaluation only");
+    DSN_REQUIRE((aux_stream != nullptr) == (ev_fork != nullptr) && (aux_stream != nullptr) == (ev_join != nullptr),
+                "dsn_render_rays_train_ex: the auxiliary stream and its two events go together");
+    DSN_REQUIRE(!aux_stream || aux_stream != stream, "dsn_render_rays_train_ex: the auxiliary stream must not be the call's own stream");
     hipStream_t st = (hipStream_t)stream;
     DsnSceneView s = dsn_scene_view((void*)scene, V, F);
     DsnWorkspace w = dsn_carve(workspace, R, S, -1);      // (train mode keeps its records in grad_workspace: the fixed part only)
@@ -883,21 +886,38 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     // (train mode has no exact-fp32 twin of the stored activations: samples outside the fp16 range are counted in count[48],
     //  which the host mirror checks - Renderer.range_overflow_count())
     if (hipMemsetAsync(w.count, 0, DSN_CNT_BYTES, st) != hipSuccess) return dsn_fail("%s", "dsn_render_rays_train: memset failed");
+    // The canonical points of transparent samples (evaluated when their noise is positive) lie far from the body, outside the fine
+    // grid: the coarse-level cell-major search finds their nearest face first (same lists, same index as k_normal's own walk;
+    // scratch: buffers of the render workspace that train mode does not use) and k_normal takes it from there.  It reads the warp
+    // stage's points and the row flags, nothing of the networks: with the caller's auxiliary stream (dsn_render_rays_train_ex) it is
+    // enqueued BESIDE the field kernel - whose last round of row blocks leaves most compute units idle - and joined in front of the
+    // normals; without one it follows the field kernel on `stream` as before.  (The matrix kernel owns its SIMDs, DESIGN 4.5: the
+    // search's waves only ever run on compute units that hold none of its workgroups.)
+    const int32_t* nn_far = nullptr;
+    const char* far_env = getenv("DSN_TRAIN_FAR_SEARCH_MIN");      // test / tuning override (a huge value switches it off)
+    const bool far_search = !exh && N >= (far_env ? atoll(far_env) : (long long)DSN_TRAIN_FAR_SEARCH_MIN);
+    hipStream_t sf = st;
+    const bool forked = far_search && aux_stream != nullptr;
+    if (forked) {
+        sf = (hipStream_t)aux_stream;
+        if (hipEventRecord((hipEvent_t)ev_fork, st) != hipSuccess || hipStreamWaitEvent(sf, (hipEvent_t)ev_fork, 0) != hipSuccess)
+            return dsn_fail("%s", "dsn_render_rays_train_ex: fork of the auxiliary stream failed");
+    }
+    auto search_far = [&]() {
+        // (scratch of the segmented search, round 6: buffers the training forward does not use - the per-slice lists + the live list,
+        //  8 N contiguous bytes, for the (distance, index) keys; the active list for the wave -> cell map and the scatter cursors)
+        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, w.sort_scratch, w.pos, w.nn_small, sf,
+                                       (void*)w.slices, F, w.active, N);
+        nn_far = w.pos;
+    };
+    if (forked) search_far();
     // (skipped rows keep whatever their density slot held: the compositor masks transparent samples itself)
     dsn_launch_field16_train((const float*)packed, s.frame, c.x_c, N, c.sigma, c.essence, c.grad, c.h0, c.a0, c.rr, c.masks, st,
                              w.count + DSN_CNT_RANGE, c.list1, c.rowcnt);
-    // The canonical points of transparent samples (evaluated when their noise is positive) lie far from the body, outside the fine
-    // grid: the coarse-level cell-major search finds their nearest face first (same lists, same index as k_normal's own walk;
-    // scratch: buffers of the render workspace that train mode does not use) and k_normal takes it from there
-    const int32_t* nn_far = nullptr;
-    const char* far_env = getenv("DSN_TRAIN_FAR_SEARCH_MIN");      // test / tuning override (a huge value switches it off)
-    if (!exh && N >= (far_env ? atoll(far_env) : (long long)DSN_TRAIN_FAR_SEARCH_MIN)) {
-        // (scratch of the segmented search, round 6: buffers the training forward does not use - the per-slice lists + the live list,
-        //  8 N contiguous bytes, for the (distance, index) keys; the active list for the wave -> cell map and the scatter cursors)
-        dsn_launch_nn_cellmajor_coarse(s.nn_canon, s.cent_canon, c.x_c, c.live, N, (int32_t*)w.grad, w.sort_scratch, w.pos, w.nn_small, st,
-                                       (void*)w.slices, F, w.active, N);
-        nn_far = w.pos;
-    }
+    if (forked) {
+        if (hipEventRecord((hipEvent_t)ev_join, sf) != hipSuccess || hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0) != hipSuccess)
+            return dsn_fail("%s", "dsn_render_rays_train_ex: join of the auxiliary stream failed");
+    } else if (far_search) search_far();
     dsn_launch_normal(s, c.x_c, c.grad, N, c.list1, c.rowcnt, c.idx_c, c.n_w, exh, st, nn_far);
     dsn_launch_light16((const float*)packed, s.frame, c.n_w, nullptr, ray_o, ray_d, z, c.essence, N, S, c.list1, c.rowcnt, w.colour, st,
                        c.hl1, c.hl2, c.pre);
@@ -905,6 +925,14 @@ int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, c
     dsn_launch_composite(w.colour, c.sigma, c.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc, out_weights,
                          out_depth, st, true);
     return dsn_check_launch("dsn_render_rays_train");
+}
+
+int dsn_render_rays_train(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                          float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
+                          float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
+                          void* workspace, void* grad_workspace, void* stream) {
+    return dsn_render_rays_train_ex(scene, V, F, packed, ray_o, ray_d, near, far, R, S, t_vals, jitter, noise, flags, out_rgb, out_disp, out_acc,
+                                    out_depth, out_weights, out_z, workspace, grad_workspace, stream, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

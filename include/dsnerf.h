@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DSN_ABI_VERSION 7
+#define DSN_ABI_VERSION 8
 #define DSN_NUM_PARAMS 33 /* DualSpaceNeRF.state_dict(), model/spacenet.py:18-81,152-172,191-205 */
 
 DSN_EXPORT int dsn_abi_version(void);
@@ -252,6 +252,15 @@ DSN_EXPORT int dsn_render_rays_train(const void* scene, int V, int F, const void
                     float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
                     float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
                     void* workspace, void* grad_workspace, void* stream);
+/* The same with the caller's auxiliary stream + fork / join events (ABI 8; the triple of dsn_render_rays_grad_ex below, all three or
+ * none).  The nearest-face search of the batch's FAR canonical points (transparent samples with positive noise: six small kernels,
+ * 0.25 ms at 8192 x 64) needs the warp stage's points only, not the networks: it is enqueued on aux_stream beside the field kernel,
+ * whose last round of row blocks leaves most of the chip idle (2 844 blocks on 256 CUs at that batch), and joined in front of the
+ * normals.  Same kernels, same arguments, same values; NULL triple = dsn_render_rays_train. */
+DSN_EXPORT int dsn_render_rays_train_ex(const void* scene, int V, int F, const void* packed, const float* ray_o, const float* ray_d, float* near,
+                    float* far, int R, int S, const float* t_vals, const float* jitter, const float* noise, int flags,
+                    float* out_rgb, float* out_disp, float* out_acc, float* out_depth, float* out_weights, float* out_z,
+                    void* workspace, void* grad_workspace, void* stream, void* aux_stream, void* ev_fork, void* ev_join);
 DSN_EXPORT int dsn_render_rays_grad(const void* scene, int V, int F, const void* packed, const float* const* params33_host, const float* poses24x3,
                          int frame_idx, int zero_code, const float* ray_o, const float* ray_d, const float* z_vals,
                          const float* noise, int R, int S, const float* d_rgb, const float* d_disp, const float* d_acc,

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.dsn_abi_version() == 7
+    assert lib.dsn_abi_version() == 8
     assert lib.dsn_pose_state_bytes() >= 256 + 4 * (64 + 256)          # header + DsnFrameState
     assert lib.dsn_calibrate_workspace_bytes(C.c_int64(1 << 20)) >= (1 << 20) * 28
     assert lib.dsn_packed_param_bytes() > 3_000_000            # fwd + transposed images of ~0.5 M params
