@@ -2619,6 +2619,38 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
     float* const* an = pairs ? w.an : w.tn;
     dsn_launch_adjoint16(packed, N64, w.masks, cur, an[0], g_adj, sa, range_cnt, R2.list, R2.cnt);
     if (two && (hipEventRecord(aux->join, sa) != hipSuccess || hipStreamWaitEvent(st, aux->join, 0) != hipSuccess)) return "join of the auxiliary stream";
+    // The first layer's product FIRST (the order of the products is free: every one has outputs of its own): what hangs on its bias
+    // column sums - the stage1.0 bias copy and two single-workgroup kernels (constant input columns, embedding row, pose code ->
+    // pose_mlp: 0.05 ms of an idle chip at the end of the step until the last session of round 6) - then runs on the auxiliary stream
+    // beside the other seven products and is joined behind them.
+    // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
+    if (pairs)
+        wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part,
+                      WgradPair{w.pe, nullptr, an[0], g_adj});
+    else
+        wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part);
+    bool tail_forked = false;
+    {
+        hipStream_t sx = st;
+        if (two) {
+            if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(sa, aux->fork, 0) != hipSuccess) return "fork of the auxiliary stream (first-layer tail)";
+            sx = sa;
+            tail_forked = true;
+        }
+        // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
+        const bool copied = hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, sx) == hipSuccess;
+        if (copied) {
+            hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, sx, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,
+                               grd[P_S1_0W], grd[P_EMB], w.small + 256);
+            hipLaunchKernelGGL(k_t_pose_mlp_adjoint, dim3(1), dim3(256), 0, sx, prm[P_PM0_W], prm[P_PM0_B], prm[P_PM2_W], prm[P_PM2_B],
+                               prm[P_PM4_W], poses, w.small + 256, grd[P_PM0_W], grd[P_PM0_B], grd[P_PM2_W], grd[P_PM2_B], grd[P_PM4_W],
+                               grd[P_PM4_B]);
+        }
+        if (!copied) {      // (an error between fork and join must not leave the auxiliary stream running beside the caller)
+            if (tail_forked) { (void)hipEventRecord(aux->join, sa); (void)hipStreamWaitEvent(st, aux->join, 0); }
+            return "bias copy";
+        }
+    }
     for (int l = 6; l >= 1; --l) {
         const float* A = l == 6 ? cur : an[l];
         if (pairs) {
@@ -2633,18 +2665,7 @@ const char* dsn_train_run(const DsnSceneView& s, const float* packed, const floa
         wgrad_mfma16(N64, w.h[l - 1], nullptr, A, g_adj, grd[kTrunkW[l]], kTrunkLd[l], st, grd[kTrunkB[l]], R2, w.wg_part);
         if (l == 4) wgrad_mfma16p(N64, w.pe, nullptr, A, g_adj, grd[kTrunkW[4]] + W4_PE_COL, 319, PE_K, st, nullptr, R2, w.wg_part);
     }
-    // (the bias gradient of stage1.0 = column sums of ahat_0 rides along into w.small[0..255])
-    if (pairs)
-        wgrad_mfma16p(N64, w.tpe, g_tpe, w.ap[0], nullptr, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part,
-                      WgradPair{w.pe, nullptr, an[0], g_adj});
-    else
-        wgrad_mfma16p(N64, w.pe, nullptr, an[0], g_adj, grd[kTrunkW[0]] + W0_PE_COL, 87, PE_K, st, w.small, R2, w.wg_part);
-    // stage1.0 bias, constant input columns, embedding row, pose code -> pose_mlp
-    if (hipMemcpyAsync(grd[P_S1_0B], w.small, 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return "bias copy";
-    hipLaunchKernelGGL(k_t_first_layer_consts, dim3(1), dim3(256), 0, st, w.small, prm[P_S1_0W], s.frame, frame_idx, zero_code,
-                       grd[P_S1_0W], grd[P_EMB], w.small + 256);
-    hipLaunchKernelGGL(k_t_pose_mlp_adjoint, dim3(1), dim3(256), 0, st, prm[P_PM0_W], prm[P_PM0_B], prm[P_PM2_W], prm[P_PM2_B],
-                       prm[P_PM4_W], poses, w.small + 256, grd[P_PM0_W], grd[P_PM0_B], grd[P_PM2_W], grd[P_PM2_B], grd[P_PM4_W],
-                       grd[P_PM4_B]);
+    if (tail_forked && (hipEventRecord(aux->join, sa) != hipSuccess || hipStreamWaitEvent(st, aux->join, 0) != hipSuccess))
+        return "join of the auxiliary stream (first-layer tail)";
     return nullptr;
 }
