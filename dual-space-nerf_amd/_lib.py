@@ -815,13 +815,19 @@ def read_stop_hist(ws, R: int, S: int):
     return c.reshape(K + 1, K), L
 
 
-def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 128 * 224, launch_rounds: float = 0.3, quantise: bool = True):
+def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 128 * 224, launch_rounds: float = 0.3, quantise: bool = True,
+                         round_weight: float = 0.5):
     """Slice lengths for dsn_render_rays_ex from a probe frame's histogram (read_stop_hist).  A slice that starts at uniform slice a
     and covers slices a .. b evaluates sum_k M[a][k], M[a][k] = samples of slice k on rays still alive at the start of a (sum over
     g > a of hist[g][k]).  Its forward launch runs in ROUNDS of the persistent grid - 128 samples per workgroup, round_samples per
     round (224 workgroups with frames in flight, DSN_SHARE_CUS) - so it costs ceil(samples / round_samples) rounds whatever its last
     round holds, plus about `launch_rounds` of a round for the small launches in front of it (transmittance, list filter).  Dynamic
-    programming over the slice borders minimises the sum; slices stay within 64 samples.  quantise=False: round 4's model (samples +
+    programming over the slice borders minimises the sum; slices stay within 64 samples.  round_weight (round 6's last session): the
+    price of a slice is round_weight x its whole rounds + (1 - round_weight) x its plain sample count - the workgroups of the
+    persistent grid fetch their tiles dynamically and the neighbours' kernels use what a last round leaves idle, so a started round
+    does not cost a whole one: with 1.0 (rounds 5-6) a rank's eighth of the bench frame was cut into 2-4 slices and evaluated 20 % more
+    samples than it had to; 0.5 measured best on the emulated partition (8 ranks 6.3 -> 6.5 x, the whole frame unchanged).
+    quantise=False: round 4's model (samples +
     0.9 rounds per slice), which ignored the half-empty last round - 4 % on a whole 512 x 512 frame (12 rounds per slice), a third of
     the forward time of a rank's eighth of it (1.5 rounds per slice).
     Returns (list of lengths in samples, evaluated samples it predicts, evaluated samples of the uniform schedule)."""
@@ -832,11 +838,14 @@ def choose_stop_schedule(hist, L: int, S: int, round_samples: int = 128 * 224, l
     for a in range(K):
         M[a] = hist[a + 1:].sum(0)
     rs = float(round_samples)
+    # (DSN_STOP_ROUND_ALPHA / DSN_STOP_LAUNCH_ROUNDS: experiment overrides of round_weight / launch_rounds)
+    alpha = float(os.environ.get("DSN_STOP_ROUND_ALPHA", round_weight))
+    launch_rounds = float(os.environ.get("DSN_STOP_LAUNCH_ROUNDS", launch_rounds))
 
     def cost(n):
         if not quantise:
             return 0.9 * 32768.0 + float(n)
-        return (float(launch_rounds) + float(-(-int(n) // int(round_samples)))) * rs
+        return (float(launch_rounds) + alpha * float(-(-int(n) // int(round_samples))) + (1.0 - alpha) * float(n) / rs) * rs
 
     best = [0.0] + [float("inf")] * K
     prev = [0] * (K + 1)

@@ -47,8 +47,12 @@ def test_slice_schedule_is_priced_in_rounds():
     assert lens[-1] >= 16                                             # the tail, where no ray ends any more, is one long slice
     # a rank's eighth of it: the same shape at an eighth of the samples - slices that hold about a round each are merged
     h8 = _hist(K, [a // 320 for a in alive], {3: 0.3, 4: 0.2, 5: 0.1, 6: 0.1, K: 0.3})      # 1/8 round per uniform slice
-    lens8, ev8, un8 = _lib.choose_stop_schedule(h8, L, S)
+    lens8, ev8, un8 = _lib.choose_stop_schedule(h8, L, S, round_weight=1.0)      # (every started round priced as a whole one)
     assert sum(lens8) == S and len(lens8) <= len(lens) and len(lens8) <= 4
+    # the default weighs whole rounds and plain samples half and half (a started round does not cost a whole one while the neighbours'
+    # kernels fill it): never fewer slices than the whole-round model, never more samples evaluated
+    lens8h, ev8h, _ = _lib.choose_stop_schedule(h8, L, S)
+    assert sum(lens8h) == S and len(lens8) <= len(lens8h) <= len(lens) and ev8h <= ev8
     # round 4's model (samples + 0.9 rounds per slice) keeps more, shorter slices there: a half-empty round each
     lens_old, _, _ = _lib.choose_stop_schedule(h8, L, S, quantise=False)
     rounds = lambda ls, hh: sum(-(-int(hh[a + 1:, a:b].sum()) // round_) for a, b in zip(np.cumsum([0] + ls[:-1]) // L, np.cumsum(ls) // L))
