@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(256) k_grid_count(const float4* __restrict__ c
     int F;
     const float4* __restrict__ cent = dsn_cell_source(g, cell, cent_all, F_all, maxsuper, super_cnt, super_list, F);
     // The sweeps are bound by the latency of their loads (one wave per cell, ~31 rounds of 64 entries from L2), not by their arithmetic:
-    // GRID_U rounds' entries are requested together (session 4 of round 6: 0.138 -> see profiles; rounds 1-5 waited for every round).
+    // GRID_U rounds' entries are requested together (the last session of round 6: k_grid_count 0.138 -> 0.120 ms per frame; rounds 1-5
+    // waited for every round of 64).
     constexpr int GRID_U = DSN_GRID_U;
     float m = INFINITY;
     for (int f0 = 0; f0 < F; f0 += 64 * GRID_U) {

@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(T_THREADS) k_t_light_first_bwd(const float* __
     if (n0 >= NL) return;          // block-uniform
     {
         // a wave moves half a row per load: the row is wave-uniform (scalar row numbers, rows_at_u), and the 32 loads of a thread do not
-        // wait for each other (session 4 of round 6: the element loop fetched every row number with a vector load in front of the value)
+        // wait for each other (round 6: the element loop fetched every row number with a vector load in front of the value)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k = ((wv & 1) << 6) + (threadIdx.x & 63);
         float v[32];
 #pragma unroll
@@ -1452,7 +1452,7 @@ __global__ void __launch_bounds__(256) k_t_wgrad_reduce(const float* __restrict_
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = part + (size_t)o * 4;
     // (the tiles are added in the same fixed order as ever; RED_U of them are requested together - the loop is bound by the latency of
-    //  its loads, and the four bias blocks' second loop, one load at a time until session 4 of round 6, was the whole kernel's tail)
+    //  its loads, and the four bias blocks' second loop, one load at a time until the end of round 6, was the whole kernel's tail)
     constexpr int RED_U = 8;
     int g = q;
     for (; g + 4 * (RED_U - 1) < active; g += 4 * RED_U) {
