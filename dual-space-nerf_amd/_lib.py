@@ -40,7 +40,7 @@ EXPORTS = [
     "dsn_pose_state_bytes", "dsn_set_pose", "dsn_light", "dsn_calibrate_workspace_bytes", "dsn_calibrate_screen",
     "dsn_set_screen_margin", "dsn_module_grad", "dsn_early_stop_eps", "dsn_calibrate_screen_frame",
     "dsn_early_stop_eps_scaled", "dsn_set_early_stop_colour_scale", "dsn_nn_header_offsets", "dsn_render_workspace_bytes_for",
-    "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_early_stop_colour_headroom", "dsn_render_rays_ex",
+    "dsn_render_workspace_record_capacity", "dsn_stop_slice_len", "dsn_stop_stats_slice_len", "dsn_early_stop_colour_headroom", "dsn_render_rays_ex",
     "dsn_render_rays_grad_ex", "dsn_render_rays_train_ex", "dsn_aux_create", "dsn_aux_destroy",
 ]
 
@@ -809,7 +809,7 @@ def read_stop_hist(ws, R: int, S: int):
     uniform slice k on rays whose first slice with T < eps at its start is g (g = K: never)"""
     import numpy as np
     buf = ws if isinstance(ws, torch.Tensor) else ws.buf
-    L = stop_slice_len(R, S)
+    L = int(lib().dsn_stop_stats_slice_len(int(R), int(S)))      # (the histogram's own slice length: half the uniform slice where K <= 32 allows)
     K = (S + L - 1) // L
     c = buf[4 * CNT_HIST:4 * CNT_HIST + 4 * (K + 1) * K].view(torch.int32).cpu().numpy().astype(np.int64)
     return c.reshape(K + 1, K), L

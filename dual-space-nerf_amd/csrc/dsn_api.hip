@@ -508,6 +508,14 @@ static inline int dsn_slice_len(int R, int S) {
     if (L > 64) L = 64;
     return (S + L - 1) / L <= DSN_STOP_MAX_SLICES ? L : (S + DSN_STOP_MAX_SLICES - 1) / DSN_STOP_MAX_SLICES;
 }
+// samples per slice of the DSN_STOP_STATS histogram: HALF the uniform slice where that keeps K <= 32 - the schedule a caller cuts from the
+// histogram (dsn_render_rays_ex) may put its borders there (round 6's last session: the bench frame's schedule from 2-sample statistics
+// evaluates 1.3 % fewer samples than from 4-sample ones, -0.05 ms); the uniform slicing itself stays as it is (2-sample uniform slices
+// measured worse: 32 launches)
+static inline int dsn_stats_slice_len(int R, int S) {
+    const int L = dsn_slice_len(R, S), half = L >= 2 ? L / 2 : L;
+    return (S + half - 1) / half <= DSN_STOP_MAX_SLICES ? half : L;
+}
 // entries of the per-slice lists: K slices of R * L each (K L < S + L) for the slice length in use - round 3 reserved R (S + 64) for any
 // length (8 bytes per sample at S = 64; now 4).  DSN_STOP_SLICE (experiments) changes L: set it before the workspace is sized.
 static inline size_t dsn_slice_entries(size_t R, int S) {
@@ -589,6 +597,8 @@ int64_t dsn_render_workspace_record_capacity(int R, int S, size_t workspace_byte
 
 // samples per uniform slice of DSN_EARLY_STOP for an R x S frame (what dsn_render_rays_ex cuts and the DSN_STOP_STATS histogram counts)
 int dsn_stop_slice_len(int R, int S) { return (R > 0 && S > 0) ? dsn_slice_len(R, S) : 0; }
+// samples per slice of the DSN_STOP_STATS histogram (<= dsn_stop_slice_len: see dsn_stats_slice_len)
+int dsn_stop_stats_slice_len(int R, int S) { return (R > 0 && S > 0) ? dsn_stats_slice_len(R, S) : 0; }
 
 float dsn_early_stop_colour_headroom(void) { return DSN_STOP_COLOUR_HEADROOM; }
 float dsn_early_stop_eps(int S) { return dsn_stop_eps_scaled(S > 0 ? S : 1, 1.0f); }
@@ -827,8 +837,8 @@ int dsn_render_rays_ex(const void* scene, int V, int F, const void* packed, cons
     dsn_launch_composite(w.colour, w.sigma, w.transparent, z, ray_d, noise, R, S, out_rgb, out_disp, out_acc,
                          out_weights, out_depth, st, skip, skip ? w.count + DSN_CNT_STOP + 3 : nullptr);
     if ((flags & DSN_STOP_STATS) && skip)
-        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_slice_len(R, S), (const float*)packed + OFF_SCAL,
-                              w.count + DSN_CNT_STOP + 2, st, w.count + DSN_CNT_HIST, w.count + DSN_CNT_STOP + 3);
+        dsn_launch_stop_stats(w.sigma, w.transparent, z, ray_d, R, S, dsn_stats_slice_len(R, S), (const float*)packed + OFF_SCAL,
+                              w.count + DSN_CNT_STOP + 2, st, w.count + DSN_CNT_HIST, w.count + DSN_CNT_STOP + 3, dsn_slice_len(R, S));
     }       // shading phase
     return dsn_check_launch("dsn_render_rays");
 }

@@ -1254,7 +1254,9 @@ __global__ void __launch_bounds__(256) k_cull_lit(const int32_t* __restrict__ po
 __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ sigma, const uint8_t* __restrict__ transparent,
                                                      const float* __restrict__ z_vals, const float* __restrict__ ray_d, int R, int S,
                                                      int L, const float* __restrict__ scal, int32_t* __restrict__ out,
-                                                     int32_t* __restrict__ hist, const int32_t* __restrict__ colour_max) {
+                                                     int32_t* __restrict__ hist, const int32_t* __restrict__ colour_max, int Lu) {
+    // L: samples per slice of the HISTOGRAM; Lu: samples per uniform slice of DSN_EARLY_STOP - what *out counts (the samples the uniform
+    // slicing would leave out) follows Lu, as ever; the histogram may be finer (dsn_stop_stats_slice_len)
     __shared__ int s_h[(DSN_STOP_MAX_SLICES + 1) * DSN_STOP_MAX_SLICES];
     const int K = (S + L - 1) / L;
     if (hist) {
@@ -1275,13 +1277,14 @@ __global__ void __launch_bounds__(256) k_stop_stats(const float* __restrict__ si
         const float dn = dsn_norm3(d);
         const int64_t g0 = (int64_t)r * S;
         float z = z_vals[g0];
-        bool dead = false;
+        bool dead = false, dead_u = false;
         int gstar = K;                     // first slice that finds the ray finished at its start
         unsigned long long nt_lo = 0, nt_hi = 0;      // non-transparent samples per slice, 4 bits each would overflow at L > 15: counted below
         for (int i = 0; i < S; ++i) {
             if (i % L == 0) { dead = t < eps; if (dead && gstar == K) gstar = i / L; }
+            if (i % Lu == 0) dead_u = t < eps;
             const bool tr = transparent && transparent[g0 + i];
-            if (dead && !tr) ++skipped;
+            if (dead_u && !tr) ++skipped;
             const float zn = (i + 1 < S) ? z_vals[g0 + i + 1] : 0.f;
             const float dist = ((i + 1 < S) ? (zn - z) : 1e10f) * dn;
             float s = tr ? 0.f : sigma[g0 + i];
@@ -1342,8 +1345,8 @@ void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N
                        lit_count, culled, colour);
 }
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist, const int32_t* colour_max) {
-    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out, hist, colour_max);
+                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist, const int32_t* colour_max, int Lu) {
+    hipLaunchKernelGGL(k_stop_stats, dim3((R + 255) / 256), dim3(256), 0, st, sigma, transparent, z_vals, ray_d, R, S, L, packed_scal, out, hist, colour_max, Lu > 0 ? Lu : L);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -172,4 +172,5 @@ void dsn_launch_cull_lit(const int32_t* pos, const int32_t* pos_count, int64_t N
                          const float* sigma, int S, const float* packed_scal, int32_t* sel, int32_t* sel_count, int32_t* lit, int32_t* lit_count,
                          int32_t* culled, float* colour, hipStream_t st);
 void dsn_launch_stop_stats(const float* sigma, const uint8_t* transparent, const float* z_vals, const float* ray_d, int R, int S, int L,
-                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist = nullptr, const int32_t* colour_max = nullptr);
+                           const float* packed_scal, int32_t* out, hipStream_t st, int32_t* hist = nullptr, const int32_t* colour_max = nullptr,
+                           int Lu = 0);      // (Lu: the uniform slice length *out counts by; 0 = L)

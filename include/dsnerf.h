@@ -342,6 +342,9 @@ DSN_EXPORT float dsn_early_stop_eps(int S);
 /* samples per uniform slice of an R x S frame: 4 on frames of >= 4 M samples, 8 below, S / 32 (rounded up) beyond 32 slices; rays of
  * more than 2048 samples (a slice would exceed 64 samples) render in one pass whatever the flag says */
 DSN_EXPORT int dsn_stop_slice_len(int R, int S);
+/* samples per slice of the DSN_STOP_STATS histogram (ABI 8: half the uniform slice where that keeps at most 32 slices - finer borders for
+ * the schedule a caller cuts from it; the histogram is (K + 1) x K ints with K = ceil(S / this)) */
+DSN_EXPORT int dsn_stop_stats_slice_len(int R, int S);
 DSN_EXPORT float dsn_early_stop_eps_scaled(int S, float colour_scale);
 /* the factor between the largest colour a frame weighed (word 59 of its workspace) and the colour scale a caller should set from it:
  * 2.  DSN_STOP_STATS applies it itself: its counts and histogram use the threshold for max(the scale in `packed`, 2 x the frame's own

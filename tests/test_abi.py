@@ -153,6 +153,9 @@ def test_round4_host_functions(lib):
     # the uniform slice length comes from the library (the binding mirrored it by hand)
     assert lib.dsn_stop_slice_len(512 * 512, 64) == 4 and lib.dsn_stop_slice_len(4096, 64) == 8 and lib.dsn_stop_slice_len(4096, 512) == 16
     assert lib.dsn_stop_slice_len(0, 64) == 0
+    # the DSN_STOP_STATS histogram counts in half slices where that keeps K <= 32 (finer borders for a caller's schedule)
+    assert lib.dsn_stop_stats_slice_len(512 * 512, 64) == 2 and lib.dsn_stop_stats_slice_len(4096, 64) == 4
+    assert lib.dsn_stop_stats_slice_len(1024 * 1024, 128) == 4 and lib.dsn_stop_stats_slice_len(4096, 512) == 16 and lib.dsn_stop_stats_slice_len(0, 64) == 0
 
 
 def test_no_fallback_without_gpu():
