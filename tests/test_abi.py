@@ -114,6 +114,13 @@ def test_round4_host_functions(lib):
                          C.c_size_t(0), (C.c_int32 * len(lens))(*lens), len(lens), None)
     for lens, msg in (([4, 4, 4], b"add up to S"), ([0, 8, 8], b"1 to 64"), ([1] * 33, b"32 slices")):
         assert lib.dsn_render_rays_ex(*args(lens)) != 0 and msg in lib.dsn_last_error(), (lens, lib.dsn_last_error())
+    # ABI 7 / 8: the auxiliary stream and its two events go together, and the stream must not be the call's own - checked before any
+    # device work (dsn_render_rays_train_ex, dsn_render_rays_grad_ex)
+    two = C.c_void_p(128)
+    targs = (one, 1, 1, one, one, one, one, one, 4, 16, one, None, None, 0, one, one, one, one, None, None, one, one)
+    assert lib.dsn_render_rays_train_ex(*targs, None, two, None, None) != 0 and b"go together" in lib.dsn_last_error()
+    assert lib.dsn_render_rays_train_ex(*targs, None, two, two, None) != 0 and b"go together" in lib.dsn_last_error()
+    assert lib.dsn_render_rays_train_ex(*targs, two, two, two, two) != 0 and b"must not be the call's own stream" in lib.dsn_last_error()
     # level headers: four distinct 64-byte slots inside the scene blob, in the order of dsn_debug_nn_stats
     off = (C.c_size_t * 4)()
     assert lib.dsn_nn_header_offsets(6890, 13776, off) == 0
